@@ -1,0 +1,121 @@
+"""Generate encoder/decoder goldens with an INDEPENDENT implementation of the architecture.
+
+The reference's encoder/decoder arithmetic lives in the un-vendored package
+openai-whisper==20240930 (model_convert/requirements.txt:1; monkey-patched by
+model_convert/export_onnx.py:103-387) which is not installed here, and the reference holds no
+golden vectors for it. transformers' WhisperForConditionalGeneration implements the same
+published architecture from a different code lineage, so it is used — in this container only —
+to pin the CPU oracle: seeded synthetic weights (numpy PCG64, regenerated from the seed at test
+time) are loaded into the HF model, and its cross-K/V, per-step logits and greedy ids are
+stored as small fixtures.
+
+    python tests/golden/make_model_goldens.py
+"""
+import os, sys
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "whisper.axera_amd", "tools"))
+import modelgen  # noqa: E402
+from transformers import WhisperConfig, WhisperForConditionalGeneration  # noqa: E402
+
+
+def hf_from_weights(dims, w):
+    d = dims["d"]
+    cfg = WhisperConfig(vocab_size=dims["n_vocab"], num_mel_bins=dims["n_mels"], d_model=d,
+                        encoder_layers=dims["enc_layers"], encoder_attention_heads=dims["heads"],
+                        decoder_layers=dims["dec_layers"], decoder_attention_heads=dims["heads"],
+                        encoder_ffn_dim=4 * d, decoder_ffn_dim=4 * d, max_source_positions=1500,
+                        max_target_positions=448, activation_function="gelu", dropout=0.0,
+                        attention_dropout=0.0, activation_dropout=0.0, attn_implementation="eager")
+    m = WhisperForConditionalGeneration(cfg).eval().float()
+    sd = {}
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    sd["model.encoder.conv1.weight"] = T(w["encoder.conv1.weight"]); sd["model.encoder.conv1.bias"] = T(w["encoder.conv1.bias"])
+    sd["model.encoder.conv2.weight"] = T(w["encoder.conv2.weight"]); sd["model.encoder.conv2.bias"] = T(w["encoder.conv2.bias"])
+    sd["model.encoder.embed_positions.weight"] = T(w["encoder.positional_embedding"])
+    sd["model.encoder.layer_norm.weight"] = T(w["encoder.ln_post.weight"]); sd["model.encoder.layer_norm.bias"] = T(w["encoder.ln_post.bias"])
+    sd["model.decoder.embed_tokens.weight"] = T(w["decoder.token_embedding.weight"])
+    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+    sd["model.decoder.embed_positions.weight"] = T(w["decoder.positional_embedding"])
+    sd["model.decoder.layer_norm.weight"] = T(w["decoder.ln.weight"]); sd["model.decoder.layer_norm.bias"] = T(w["decoder.ln.bias"])
+
+    def attn(src, dst):
+        for a, b in (("query", "q_proj"), ("key", "k_proj"), ("value", "v_proj"), ("out", "out_proj")):
+            sd[f"{dst}.{b}.weight"] = T(w[f"{src}.{a}.weight"])
+            if a != "key":
+                sd[f"{dst}.{b}.bias"] = T(w[f"{src}.{a}.bias"])
+
+    for side, n in (("encoder", dims["enc_layers"]), ("decoder", dims["dec_layers"])):
+        for i in range(n):
+            s, t = f"{side}.blocks.{i}", f"model.{side}.layers.{i}"
+            attn(f"{s}.attn", f"{t}.self_attn")
+            sd[f"{t}.self_attn_layer_norm.weight"] = T(w[f"{s}.attn_ln.weight"]); sd[f"{t}.self_attn_layer_norm.bias"] = T(w[f"{s}.attn_ln.bias"])
+            if side == "decoder":
+                attn(f"{s}.cross_attn", f"{t}.encoder_attn")
+                sd[f"{t}.encoder_attn_layer_norm.weight"] = T(w[f"{s}.cross_attn_ln.weight"]); sd[f"{t}.encoder_attn_layer_norm.bias"] = T(w[f"{s}.cross_attn_ln.bias"])
+            sd[f"{t}.fc1.weight"] = T(w[f"{s}.mlp.0.weight"]); sd[f"{t}.fc1.bias"] = T(w[f"{s}.mlp.0.bias"])
+            sd[f"{t}.fc2.weight"] = T(w[f"{s}.mlp.2.weight"]); sd[f"{t}.fc2.bias"] = T(w[f"{s}.mlp.2.bias"])
+            sd[f"{t}.final_layer_norm.weight"] = T(w[f"{s}.mlp_ln.weight"]); sd[f"{t}.final_layer_norm.bias"] = T(w[f"{s}.mlp_ln.bias"])
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("k_proj.bias" in k for k in missing), missing
+    return m
+
+
+def synth_mel(seed, n_mels, n_real):
+    """A mel-like input: smooth random values in the front-end's range, zeros past n_real."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mel = np.zeros((n_mels, 3000), dtype=np.float32)
+    mel[:, :n_real] = np.clip(rng.standard_normal((n_mels, n_real)).astype(np.float32) * 0.4, -1.0, 1.5)
+    return mel
+
+
+@torch.no_grad()
+def run_case(name, model_type, seed, mel, n_new, language_idx=1):
+    dims = modelgen.DIMS[model_type]
+    w = modelgen.synth_weights(dims, seed, bf16=True)
+    cfg = modelgen.make_config(model_type, dims)
+    m = hf_from_weights(dims, w)
+    enc = m.model.encoder(input_features=torch.from_numpy(mel)[None]).last_hidden_state  # [1,1500,d]
+    ck = torch.stack([l.encoder_attn.k_proj(enc)[0] for l in m.model.decoder.layers]).numpy()
+    cv = torch.stack([l.encoder_attn.v_proj(enc)[0] for l in m.model.decoder.layers]).numpy()
+    lang_tok = int(cfg["all_language_tokens"].split(",")[language_idx])
+    toks = [cfg["sot"], lang_tok, cfg["transcribe"], cfg["no_timestamps"]]
+    step_logits, ids = [], []
+    for _ in range(n_new + 1):
+        out = m.model.decoder(input_ids=torch.tensor([toks]), encoder_hidden_states=enc).last_hidden_state
+        logits = m.proj_out(out[:, -1])[0].numpy()
+        step_logits.append(logits)
+        nxt = int(logits.argmax())
+        ids.append(nxt)
+        toks.append(nxt)
+    step_logits = np.stack(step_logits)
+    top = np.argsort(-step_logits, axis=1)[:, :8]
+    probe = np.arange(0, dims["n_vocab"], 997)
+    np.savez_compressed(
+        os.path.join(HERE, f"model_{name}.npz"), model_type=model_type, seed=seed, n_new=n_new,
+        sot_seq=np.array(toks[:4]), ids=np.array(ids), top_ids=top,
+        top_vals=np.take_along_axis(step_logits, top, axis=1), probe_idx=probe,
+        probe_vals=step_logits[:, probe], cross_k_sub=ck[:, ::53, ::7], cross_v_sub=cv[:, ::53, ::7],
+        cross_k_sum=np.float64(ck.astype(np.float64).sum()), cross_v_sum=np.float64(cv.astype(np.float64).sum()),
+        cross_k_abs=np.float64(np.abs(ck).astype(np.float64).sum()))
+    print(name, "ids", ids[:8], "top gap", (np.sort(step_logits, axis=1)[:, -1] - np.sort(step_logits, axis=1)[:, -2]).min())
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    demo = np.load(os.path.join(HERE, "frontend_demo_80.npz"))
+    mel_demo = np.zeros((80, 3000), dtype=np.float32)
+    mel_demo[:, : int(demo["n_frames"])] = demo["mel_real"]
+    run_case("micro_demo", "micro", 11, mel_demo, 12)
+    run_case("micro_synth", "micro", 12, synth_mel(5, 80, 3000), 12, language_idx=0)
+    run_case("mini_synth", "mini", 13, synth_mel(6, 80, 1777), 10)
+    run_case("tiny_demo", "tiny", 14, mel_demo, 8)
+
+
+if __name__ == "__main__":
+    main()
