@@ -1,0 +1,110 @@
+/**
+ * ax_whisper_api.h — C ABI of libax_whisper.so, MI355X (gfx950) build.
+ *
+ * Drop-in boundary of the reference (paths relative to the reference tree):
+ *   AX_WHISPER_Init     replaces cpp/src/api/ax_whisper_api.h:54  (impl ax_whisper_api.cpp:48)
+ *   AX_WHISPER_Uninit   replaces cpp/src/api/ax_whisper_api.h:67  (impl :69)
+ *   AX_WHISPER_RunFile  replaces cpp/src/api/ax_whisper_api.h:81  (impl :88)
+ *   AX_WHISPER_RunPCM   replaces cpp/src/api/ax_whisper_api.h:98  (impl :139)
+ * Same names, argument meaning, ownership (malloc'd result, caller free()s) and error
+ * behaviour (NULL / -1). The application no longer calls AX_SYS_Init / AX_ENGINE_Init
+ * (whisper_cli.cpp:37-61): the library initialises HIP inside Init.
+ *
+ * Everything below the four legacy symbols is an ADDITION with no reference counterpart:
+ * batched entry points (the reference is strictly batch 1, Whisper.hpp:15-25), token-id
+ * variants for parity tests, device-resident inputs for benchmarking, and stage-level
+ * entry points so each stage can be checked against the CPU oracle.
+ *
+ * Plain C types only: pointers, ints, sizes. No C++ or torch types cross this boundary.
+ */
+#ifndef _AX_WHISPER_API_H_
+#define _AX_WHISPER_API_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AX_WHISPER_API __attribute__((visibility("default")))
+
+typedef void* AX_WHISPER_HANDLE;
+
+/* ---- legacy (byte-compatible with the reference) ------------------------------------ */
+
+/** model files: {model_path}/{model_type}/{model_type}.safetensors (replaces the two
+ *  .axmodel NPU blobs), {model_type}-tokens.txt, {model_type}_config.json.
+ *  language not in the config falls back to "zh" (Whisper.cpp:241-251). NULL on failure. */
+AX_WHISPER_API AX_WHISPER_HANDLE AX_WHISPER_Init(const char* model_type, const char* model_path,
+                                                 const char* language);
+AX_WHISPER_API void AX_WHISPER_Uninit(AX_WHISPER_HANDLE handle);
+/** 16 kHz WAV (int16/int24/int32/float32 PCM; stereo is averaged). 0 ok, -1 error. */
+AX_WHISPER_API int AX_WHISPER_RunFile(AX_WHISPER_HANDLE handle, const char* wav_file, char** result);
+/** 16 kHz mono f32 PCM in [-1, 1]. *result is malloc'd; caller frees. 0 ok, -1 error. */
+AX_WHISPER_API int AX_WHISPER_RunPCM(AX_WHISPER_HANDLE handle, float* pcm_data, int num_samples,
+                                     char** result);
+
+/* ---- additions: init / info ---------------------------------------------------------- */
+
+/** device: HIP device ordinal (-1: env AX_WHISPER_DEVICE, else 0). max_batch: number of
+ *  utterance slots to allocate (<=0: env AX_WHISPER_MAX_BATCH, else 1; grows on demand). */
+AX_WHISPER_API AX_WHISPER_HANDLE AX_WHISPER_InitEx(const char* model_type, const char* model_path,
+                                                   const char* language, int device, int max_batch);
+/** Integer config value by the key names of {type}_config.json (n_mels, n_vocab, eot, ...),
+ *  plus "sot_seq0".."sot_seq3". Returns INT32_MIN for an unknown key. */
+AX_WHISPER_API int AX_WHISPER_GetConfigInt(AX_WHISPER_HANDLE handle, const char* key);
+/** Last error text of this handle (or of the last failed Init when handle is NULL). */
+AX_WHISPER_API const char* AX_WHISPER_LastError(AX_WHISPER_HANDLE handle);
+/** Run all device work of this handle on the caller's hipStream_t (NULL: the library's own). */
+AX_WHISPER_API int AX_WHISPER_SetStream(AX_WHISPER_HANDLE handle, void* hip_stream);
+
+/* ---- additions: batched / token-id entry points -------------------------------------- */
+
+/** ids: [batch][n_text_ctx] int32 (row b holds n_ids[b] generated ids, eot excluded);
+ *  max_new <= 0 means "until eot or context" (Whisper.cpp:219-222). */
+AX_WHISPER_API int AX_WHISPER_RunPCMBatchTokens(AX_WHISPER_HANDLE handle, const float* const* pcm,
+                                                const int* num_samples, int batch, int max_new,
+                                                int32_t* ids, int* n_ids);
+/** results: caller-provided array of `batch` char*; each entry malloc'd, caller frees. */
+AX_WHISPER_API int AX_WHISPER_RunPCMBatch(AX_WHISPER_HANDLE handle, const float* const* pcm,
+                                          const int* num_samples, int batch, char** results);
+/** PCM already resident in HBM: d_pcm is a DEVICE pointer to [batch][stride] f32. */
+AX_WHISPER_API int AX_WHISPER_RunDeviceBatchTokens(AX_WHISPER_HANDLE handle, const float* d_pcm,
+                                                   int stride, const int* num_samples, int batch,
+                                                   int max_new, int32_t* ids, int* n_ids);
+/** ids -> bytes (base64 table of {type}-tokens.txt, Whisper.cpp:224-229); ids >= the table
+ *  size are skipped. *result malloc'd. */
+AX_WHISPER_API int AX_WHISPER_Detokenize(AX_WHISPER_HANDLE handle, const int32_t* ids, int n, char** result);
+
+/* ---- additions: stage-level entry points (parity tests, profiling) ------------------- */
+
+/** Whisper::preprocess (Whisper.cpp:151-184) on the GPU. mel_out: host [n_mels*3000] f32. */
+AX_WHISPER_API int AX_WHISPER_ComputeMel(AX_WHISPER_HANDLE handle, const float* pcm, int num_samples,
+                                         float* mel_out);
+/** Encoder + cross-KV projection for `batch` clips given host mels [batch][n_mels*3000];
+ *  results stay in the handle's slots 0..batch-1. */
+AX_WHISPER_API int AX_WHISPER_EncodeMel(AX_WHISPER_HANDLE handle, const float* mel, int batch);
+/** Copy slot's cross K/V back as fp32 [n_text_layer][1500][n_text_state] (reference layout). */
+AX_WHISPER_API int AX_WHISPER_GetCrossKV(AX_WHISPER_HANDLE handle, int slot, float* k_out, float* v_out);
+/** Teacher-forced decode over the slots filled by EncodeMel: after the 4 SOT steps feed
+ *  forced[b][0..n_forced-1]; logits: host [batch][n_forced+1][n_vocab] f32 (may be NULL);
+ *  argmax_ids: host [batch][n_forced+1] (may be NULL). */
+AX_WHISPER_API int AX_WHISPER_DecodeForced(AX_WHISPER_HANDLE handle, int batch, const int32_t* forced,
+                                           int n_forced, float* logits, int32_t* argmax_ids);
+/** Greedy decode over the slots filled by EncodeMel (same loop as RunPCM*). */
+AX_WHISPER_API int AX_WHISPER_DecodeGreedy(AX_WHISPER_HANDLE handle, int batch, int max_new,
+                                           int32_t* ids, int* n_ids);
+/** Stage timings of the last Run* call, ms (hipEvent): [0] front-end, [1] encoder,
+ *  [2] decode loop, [3] whole call (wall), [4] decode steps executed. */
+AX_WHISPER_API int AX_WHISPER_GetTimings(AX_WHISPER_HANDLE handle, float* out5);
+/** Time `iters` launches of one named piece on the handle's stream with hipEvents; returns
+ *  total ms in *ms_total. what: "decode_step" (one captured step graph at decode offset
+ *  `arg`), "encoder", "frontend", or a kernel name listed in DESIGN.md. */
+AX_WHISPER_API int AX_WHISPER_Bench(AX_WHISPER_HANDLE handle, const char* what, int batch, int arg,
+                                    int iters, float* ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* _AX_WHISPER_API_H_ */

@@ -1,0 +1,67 @@
+import os
+import sys
+import wave
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "whisper.axera_amd", "tools"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_demo_pcm():
+    w = wave.open(os.path.join(GOLDEN, "demo.wav"))
+    return np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32) / np.float32(32768.0)
+
+
+@pytest.fixture(scope="session")
+def demo_pcm():
+    return load_demo_pcm()
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """libax_whisper.so, built once per session (hipcc cross-compiles without a GPU)."""
+    import whisper_axera_amd as wa
+
+    if not os.path.exists(wa.LIB_PATH):
+        wa.build()
+    return wa
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle
+
+    oracle.build(ref=False)
+    return oracle
+
+
+class ModelCase:
+    """A seeded synthetic model on disk + the matching oracle objects."""
+
+    def __init__(self, tmpdir, model_type, seed):
+        import modelgen
+        import oracle
+
+        self.model_type, self.seed, self.root = model_type, seed, str(tmpdir)
+        self.dims = modelgen.DIMS[model_type]
+        self.weights = modelgen.synth_weights(self.dims, seed)
+        self.cfg = modelgen.make_config(model_type, self.dims)
+        modelgen.write_model_dir(self.root, model_type, self.dims, weights=self.weights,
+                                 tiktoken_path=os.path.join(GOLDEN, "multilingual.tiktoken"))
+        self.oracle_fp32 = oracle.Oracle(self.cfg, self.weights, bf16_policy=False)
+        self.oracle_bf16 = oracle.Oracle(self.cfg, self.weights, bf16_policy=True)
+
+
+@pytest.fixture(scope="session")
+def micro_case(tmp_path_factory, oracle_mod):
+    return ModelCase(tmp_path_factory.mktemp("models_micro"), "micro", 11)

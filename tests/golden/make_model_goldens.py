@@ -65,12 +65,8 @@ def hf_from_weights(dims, w):
     return m
 
 
-def synth_mel(seed, n_mels, n_real):
-    """A mel-like input: smooth random values in the front-end's range, zeros past n_real."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    mel = np.zeros((n_mels, 3000), dtype=np.float32)
-    mel[:, :n_real] = np.clip(rng.standard_normal((n_mels, n_real)).astype(np.float32) * 0.4, -1.0, 1.5)
-    return mel
+sys.path.insert(0, HERE)
+from make_model_goldens_inputs import synth_mel, demo_mel  # noqa: E402
 
 
 @torch.no_grad()
@@ -108,9 +104,7 @@ def run_case(name, model_type, seed, mel, n_new, language_idx=1):
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    demo = np.load(os.path.join(HERE, "frontend_demo_80.npz"))
-    mel_demo = np.zeros((80, 3000), dtype=np.float32)
-    mel_demo[:, : int(demo["n_frames"])] = demo["mel_real"]
+    mel_demo = demo_mel(80)
     run_case("micro_demo", "micro", 11, mel_demo, 12)
     run_case("micro_synth", "micro", 12, synth_mel(5, 80, 3000), 12, language_idx=0)
     run_case("mini_synth", "mini", 13, synth_mel(6, 80, 1777), 10)

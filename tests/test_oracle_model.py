@@ -1,0 +1,71 @@
+"""CPU: the oracle's encoder/decoder against goldens produced by an independent implementation
+(transformers.WhisperForConditionalGeneration on the same seeded weights; tests/golden/make_model_goldens.py).
+fp32 vs fp32: tolerance 2e-5 abs on cross K/V (values up to ~2) and on logits."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+def _mel_for(name):
+    from make_model_goldens_inputs import golden_mel
+
+    return golden_mel(name)
+
+
+@pytest.mark.parametrize("name", ["micro_demo", "micro_synth", "mini_synth", "tiny_demo"])
+def test_oracle_matches_transformers(oracle_mod, name):
+    import modelgen
+
+    g = np.load(os.path.join(GOLDEN, f"model_{name}.npz"))
+    mt = str(g["model_type"])
+    dims = modelgen.DIMS[mt]
+    w = modelgen.synth_weights(dims, int(g["seed"]))
+    cfg = modelgen.make_config(mt, dims)
+    o = oracle_mod.Oracle(cfg, w)
+    ck, cv = o.encoder(_mel_for(name))
+    assert np.abs(ck[:, ::53, ::7] - g["cross_k_sub"]).max() < 2e-5
+    assert np.abs(cv[:, ::53, ::7] - g["cross_v_sub"]).max() < 2e-5
+    assert abs(ck.astype(np.float64).sum() - float(g["cross_k_sum"])) < 1e-2
+    assert abs(np.abs(ck).astype(np.float64).sum() - float(g["cross_k_abs"])) < 1e-1
+    sot = [int(x) for x in g["sot_seq"]]
+    codes = cfg["all_language_codes"].split(",")
+    toks = [int(t) for t in cfg["all_language_tokens"].split(",")]
+    lang = codes[toks.index(sot[1])]
+    assert o.sot_seq(lang) == sot
+    n_new = int(g["n_new"])
+    ids, lg = o.greedy(ck, cv, language=lang, max_new=n_new, want_logits=True)
+    assert ids == [int(x) for x in g["ids"][:n_new]]
+    top = np.take_along_axis(lg, g["top_ids"][: len(lg)], axis=1)
+    assert np.abs(top - g["top_vals"][: len(lg)]).max() < 2e-5
+    assert np.abs(lg[:, g["probe_idx"]] - g["probe_vals"][: len(lg)]).max() < 2e-5
+
+
+def test_teacher_forcing_equals_free_running(oracle_mod, micro_case):
+    """Feeding the oracle its own greedy ids reproduces the same logits (loop bookkeeping check)."""
+    o = micro_case.oracle_fp32
+    ck, cv = o.encoder(_mel_for("micro_demo"))
+    ids, lg = o.greedy(ck, cv, "zh", max_new=6, want_logits=True)
+    ids2, lg2 = o.greedy(ck, cv, "zh", max_new=6, forced=ids, want_logits=True)
+    assert ids2 == ids and np.array_equal(lg, lg2)
+
+
+def test_bf16_policy_is_close_to_fp32(oracle_mod, micro_case):
+    ck, cv = micro_case.oracle_fp32.encoder(_mel_for("micro_demo"))
+    ckb, cvb = micro_case.oracle_bf16.encoder(_mel_for("micro_demo"))
+    assert 0 < np.abs(ck - ckb).max() < 6e-2
+    assert np.array_equal(ckb, oracle_round(ckb))
+
+
+def oracle_round(a):
+    import modelgen
+
+    return modelgen.bf16_round(a)
+
+
+def test_unknown_language_falls_back_to_zh(oracle_mod, micro_case):
+    """Whisper.cpp:241-251."""
+    assert micro_case.oracle_fp32.sot_seq("xx") == micro_case.oracle_fp32.sot_seq("zh")
+    assert micro_case.oracle_fp32.sot_seq("zh") == [50258, 50260, 50359, 50363]

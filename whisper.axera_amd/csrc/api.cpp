@@ -1,0 +1,199 @@
+// api.cpp — the C ABI of libax_whisper.so (include/ax_whisper_api.h).
+//
+// The four legacy entry points keep the reference's contract (cpp/src/api/ax_whisper_api.cpp:
+// 48-56 Init, 69-74 Uninit, 88-124 RunFile, 139-163 RunPCM): NULL / -1 on failure, *result set to
+// NULL before any failure after the argument checks, result strdup'd for the caller to free().
+// Differences, all fixes of reference defects: no exception crosses the ABI
+// (json / file errors become NULL), a failed Init does not leak, a handle is serialised by a
+// mutex (the reference's handle is not re-entrant although whisper_srv calls it from a thread
+// pool), and the OpenCC Traditional->Simplified pass (Whisper.cpp:231-236) is not applied: parity
+// is defined on token ids and the raw detokenised bytes.
+#include "../../include/ax_whisper_api.h"
+
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "engine.hpp"
+#include "host_io.hpp"
+
+using axw::Engine;
+
+namespace {
+thread_local std::string g_init_error;
+struct Handle {
+  Engine* engine = nullptr;
+  std::string last_error;
+};
+inline Handle* H(AX_WHISPER_HANDLE h) { return static_cast<Handle*>(h); }
+
+template <typename F>
+int guarded(AX_WHISPER_HANDLE handle, F&& f) {
+  Handle* h = H(handle);
+  if (!h || !h->engine) return -1;
+  std::lock_guard<std::mutex> lock(h->engine->mutex());
+  try {
+    f(*h->engine);
+    return 0;
+  } catch (const std::exception& e) {
+    h->last_error = e.what();
+    fprintf(stderr, "[ax_whisper] %s\n", e.what());
+    return -1;
+  } catch (...) {
+    h->last_error = "unknown error";
+    return -1;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+AX_WHISPER_API AX_WHISPER_HANDLE AX_WHISPER_InitEx(const char* model_type, const char* model_path, const char* language,
+                                                   int device, int max_batch) {
+  if (!model_type || !model_path || !language) {
+    g_init_error = "null argument";
+    return nullptr;
+  }
+  try {
+    Handle* h = new Handle();
+    try {
+      h->engine = new Engine(model_type, model_path, language, device, max_batch);
+    } catch (...) {
+      delete h;  // the reference leaks here (ax_whisper_api.cpp:49-53)
+      throw;
+    }
+    return h;
+  } catch (const std::exception& e) {
+    g_init_error = e.what();
+    fprintf(stderr, "[ax_whisper] init failed: %s\n", e.what());
+    return nullptr;
+  } catch (...) {
+    g_init_error = "unknown error";
+    return nullptr;
+  }
+}
+
+AX_WHISPER_API AX_WHISPER_HANDLE AX_WHISPER_Init(const char* model_type, const char* model_path, const char* language) {
+  return AX_WHISPER_InitEx(model_type, model_path, language, -1, 0);
+}
+
+AX_WHISPER_API void AX_WHISPER_Uninit(AX_WHISPER_HANDLE handle) {
+  Handle* h = H(handle);
+  if (!h) return;
+  delete h->engine;
+  delete h;
+}
+
+AX_WHISPER_API int AX_WHISPER_RunPCM(AX_WHISPER_HANDLE handle, float* pcm_data, int num_samples, char** result) {
+  if (!handle || !pcm_data || !result) return -1;
+  *result = nullptr;
+  return AX_WHISPER_RunPCMBatch(handle, &pcm_data, &num_samples, 1, result);
+}
+
+AX_WHISPER_API int AX_WHISPER_RunFile(AX_WHISPER_HANDLE handle, const char* wav_file, char** result) {
+  if (!handle || !wav_file || !result) return -1;
+  *result = nullptr;
+  axw::WavData wav;
+  std::string err;
+  if (!axw::load_wav(wav_file, wav, err)) {
+    H(handle)->last_error = "load wav failed: " + err;
+    fprintf(stderr, "[ax_whisper] load wav failed: %s\n", err.c_str());
+    return -1;
+  }
+  if (wav.mono.empty()) {
+    H(handle)->last_error = "wav file holds no samples";
+    return -1;
+  }
+  if (wav.sample_rate != 16000)  // the reference silently mis-transcribes (no resampler anywhere in its C++)
+    fprintf(stderr, "[ax_whisper] warning: %s is %d Hz, expected 16000 Hz (see cpp/resample_wav.sh of the reference)\n",
+            wav_file, wav.sample_rate);
+  return AX_WHISPER_RunPCM(handle, wav.mono.data(), (int)wav.mono.size(), result);
+}
+
+AX_WHISPER_API int AX_WHISPER_RunPCMBatchTokens(AX_WHISPER_HANDLE handle, const float* const* pcm, const int* num_samples,
+                                                int batch, int max_new, int32_t* ids, int* n_ids) {
+  if (!handle || !pcm || !num_samples || !ids || !n_ids || batch < 1) return -1;
+  return guarded(handle, [&](Engine& e) { e.run_tokens(pcm, nullptr, 0, num_samples, batch, max_new, ids, n_ids); });
+}
+
+AX_WHISPER_API int AX_WHISPER_RunDeviceBatchTokens(AX_WHISPER_HANDLE handle, const float* d_pcm, int stride,
+                                                   const int* num_samples, int batch, int max_new, int32_t* ids, int* n_ids) {
+  if (!handle || !d_pcm || !num_samples || !ids || !n_ids || batch < 1) return -1;
+  return guarded(handle, [&](Engine& e) { e.run_tokens(nullptr, d_pcm, stride, num_samples, batch, max_new, ids, n_ids); });
+}
+
+AX_WHISPER_API int AX_WHISPER_RunPCMBatch(AX_WHISPER_HANDLE handle, const float* const* pcm, const int* num_samples, int batch,
+                                          char** results) {
+  if (!handle || !pcm || !num_samples || !results || batch < 1) return -1;
+  for (int b = 0; b < batch; ++b) results[b] = nullptr;
+  return guarded(handle, [&](Engine& e) {
+    const int Tc = e.config().n_text_ctx;
+    std::vector<int32_t> ids((size_t)batch * Tc);
+    std::vector<int> n(batch);
+    e.run_tokens(pcm, nullptr, 0, num_samples, batch, 0, ids.data(), n.data());
+    for (int b = 0; b < batch; ++b) results[b] = strdup(e.detokenize(ids.data() + (size_t)b * Tc, n[b]).c_str());
+  });
+}
+
+AX_WHISPER_API int AX_WHISPER_Detokenize(AX_WHISPER_HANDLE handle, const int32_t* ids, int n, char** result) {
+  if (!handle || (!ids && n > 0) || !result) return -1;
+  *result = nullptr;
+  return guarded(handle, [&](Engine& e) { *result = strdup(e.detokenize(ids, n).c_str()); });
+}
+
+AX_WHISPER_API int AX_WHISPER_GetConfigInt(AX_WHISPER_HANDLE handle, const char* key) {
+  Handle* h = H(handle);
+  if (!h || !key) return INT_MIN;
+  auto& m = h->engine->config().ints;
+  auto it = m.find(key);
+  return it == m.end() ? INT_MIN : (int)it->second;
+}
+
+AX_WHISPER_API const char* AX_WHISPER_LastError(AX_WHISPER_HANDLE handle) {
+  Handle* h = H(handle);
+  return h ? h->last_error.c_str() : g_init_error.c_str();
+}
+
+AX_WHISPER_API int AX_WHISPER_SetStream(AX_WHISPER_HANDLE handle, void* hip_stream) {
+  return guarded(handle, [&](Engine& e) { e.set_stream(static_cast<hipStream_t>(hip_stream)); });
+}
+
+AX_WHISPER_API int AX_WHISPER_ComputeMel(AX_WHISPER_HANDLE handle, const float* pcm, int num_samples, float* mel_out) {
+  if (!handle || !pcm || !mel_out || num_samples < 1) return -1;
+  return guarded(handle, [&](Engine& e) { e.compute_mel(pcm, num_samples, mel_out); });
+}
+
+AX_WHISPER_API int AX_WHISPER_EncodeMel(AX_WHISPER_HANDLE handle, const float* mel, int batch) {
+  if (!handle || !mel || batch < 1) return -1;
+  return guarded(handle, [&](Engine& e) { e.encode_mel(mel, batch); });
+}
+
+AX_WHISPER_API int AX_WHISPER_GetCrossKV(AX_WHISPER_HANDLE handle, int slot, float* k_out, float* v_out) {
+  if (!handle || !k_out || !v_out) return -1;
+  return guarded(handle, [&](Engine& e) { e.get_cross_kv(slot, k_out, v_out); });
+}
+
+AX_WHISPER_API int AX_WHISPER_DecodeForced(AX_WHISPER_HANDLE handle, int batch, const int32_t* forced, int n_forced,
+                                           float* logits, int32_t* argmax_ids) {
+  if (!handle || (n_forced > 0 && !forced)) return -1;
+  return guarded(handle, [&](Engine& e) { e.decode_forced(batch, forced, n_forced, logits, argmax_ids); });
+}
+
+AX_WHISPER_API int AX_WHISPER_DecodeGreedy(AX_WHISPER_HANDLE handle, int batch, int max_new, int32_t* ids, int* n_ids) {
+  if (!handle || !ids || !n_ids) return -1;
+  return guarded(handle, [&](Engine& e) { e.decode_greedy(batch, max_new, ids, n_ids); });
+}
+
+AX_WHISPER_API int AX_WHISPER_GetTimings(AX_WHISPER_HANDLE handle, float* out5) {
+  if (!handle || !out5) return -1;
+  return guarded(handle, [&](Engine& e) { memcpy(out5, e.timings, sizeof(float) * 5); });
+}
+
+AX_WHISPER_API int AX_WHISPER_Bench(AX_WHISPER_HANDLE handle, const char* what, int batch, int arg, int iters, float* ms_total) {
+  if (!handle || !what || !ms_total || batch < 1 || iters < 1) return -1;
+  return guarded(handle, [&](Engine& e) { *ms_total = e.bench(what, batch, arg, iters); });
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+// common.hpp — shared device helpers and the launch interface of the HIP kernels (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace axw {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kNFFT = 400;
+constexpr int kHop = 160;
+constexpr int kBins = 201;
+constexpr int kFramesOut = 3000;   // Whisper.cpp:172 resize(3000)
+constexpr int kHeadDim = 64;       // all Whisper sizes
+constexpr int kKeyBlk = 64;        // keys per block of the decode K layout
+
+// ------------------------------------------------------------------ device helpers
+#ifdef __HIPCC__
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// exact-erf GELU (nn.GELU default; export_onnx.py:158-159 F.gelu)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+#endif
+
+// ------------------------------------------------------------------ GEMM (encoder)
+// C[M,N] = A[M,K] (bf16, row stride lda, rows may overlap) * W[N,K]^T (bf16) with a fused epilogue.
+enum GemmEpilogue : int {
+  EPI_BIAS_BF16 = 0,       // C bf16 = acc + bias
+  EPI_BIAS_GELU_BF16 = 1,  // C bf16 = gelu(acc + bias)
+  EPI_GELU_POS_F32 = 2,    // C f32  = gelu(acc + bias) + aux[m][n]      (conv2 + positional embedding)
+  EPI_RESID_F32 = 3,       // C f32 += acc + bias                        (out-proj / FFN2 residual)
+  EPI_QKV = 4,             // n<d: Q bf16 [m][d]; d<=n<2d: K bf16 [m][d]; else V^T bf16 [h][64][Tp]
+  EPI_CROSS_KV = 5,        // decode layouts: K blocked [l][b][h][blk][8][64][8], V [l][b][h][Tp][64]
+};
+
+struct GemmParams {
+  const bf16* A; long lda; long a_batch_stride;
+  const bf16* W;                     // [N][K]
+  const float* bias;                 // [N] fp32
+  void* C; long ldc; long c_batch_stride;
+  const float* aux;                  // EPI_GELU_POS_F32: pos [M][N]
+  void* C2; void* C3;                // EPI_QKV: K, V^T ; EPI_CROSS_KV: C=K blocked, C2=V
+  long c2_batch_stride, c3_batch_stride;
+  int M, N, K, batch;
+  int d_model;                       // EPI_QKV / EPI_CROSS_KV
+  int t_pad;                         // padded key count (multiple of 64)
+  int n_batch_total;                 // EPI_CROSS_KV: slot count B in [l][B][h]...
+  int n_layer;                       // EPI_CROSS_KV: decoder layers (weight rows: all K, then all V)
+  int n_begin;                       // set by launch_gemm: first output column of this launch
+  int epilogue;
+};
+void launch_gemm(const GemmParams& p, hipStream_t s);
+
+// fp32 [rows][d] -> bf16 [rows][d] LayerNorm (eps 1e-5)
+void launch_layernorm_bf16(const float* x, const float* g, const float* b, bf16* y, long rows, int d, hipStream_t s);
+
+// encoder self-attention (non-causal, T keys), Q/K bf16 [B][T][d], V^T bf16 [B][H][64][Tp] -> O bf16 [B][T][d]
+void launch_encoder_attention(const bf16* q, const bf16* k, const bf16* vt, bf16* o, int batch, int T, int t_pad,
+                              int d_model, int n_head, hipStream_t s);
+
+// ------------------------------------------------------------------ front-end
+struct FrontendParams {
+  const float* pcm;        // device [batch][stride]
+  int stride;
+  const int* n_samples;    // device [batch]
+  int batch, n_mels;
+  const float* twiddle;    // device [400][2] cos,sin
+  const float* window;     // device [400]
+  const float* mel_basis;  // device [n_mels][201]
+  float* power;            // device scratch [batch][n_frames_max][208]
+  float* logmel;           // device scratch [batch][n_mels][3008]
+  unsigned* gmax;          // device [batch] (float bits, ordered-int encoded)
+  float* mel_ref;          // device [batch][n_mels][3000] f32 (reference layout) or nullptr
+  bf16* mel_tm;            // device [batch][mel_rows][n_mels] bf16 time-major, row 0 = left pad, or nullptr
+  int mel_rows;
+  int max_frames;          // frames computed per clip (<= 3001)
+};
+void launch_frontend(const FrontendParams& p, hipStream_t s);
+void launch_mel_to_tm(const float* mel_ref, bf16* mel_tm, int batch, int n_mels, int mel_rows, hipStream_t s);
+
+// ------------------------------------------------------------------ decoder
+struct DecState {          // device-resident loop state, one per engine
+  int step;                // global decode step = offset fed to this step
+  int n_done;
+  int pad0, pad1;
+};
+
+struct DecLayerW {
+  const float *attn_ln_w, *attn_ln_b, *cross_ln_w, *cross_ln_b, *mlp_ln_w, *mlp_ln_b;
+  const bf16 *w_qkv, *w_o, *w_cq, *w_co, *w_fc1, *w_fc2;
+  const float *b_qkv, *b_o, *b_cq, *b_co, *b_fc1, *b_fc2;
+};
+
+enum GemvPrologue : int { PRO_PLAIN = 0, PRO_LAYERNORM = 1, PRO_ATTN_COMBINE = 2 };
+enum GemvEpilogue : int {
+  GEPI_STORE = 0,      // out[b][n] = y + bias
+  GEPI_GELU = 1,       // out[b][n] = gelu(y + bias)
+  GEPI_RESID = 2,      // out[b][n] += y + bias
+  GEPI_QKV_CACHE = 3,  // n<d: q; then self-K (blocked) / self-V cache rows at `step`
+  GEPI_LOGITS = 4,     // per-WG argmax partials (+ optional full logits dump)
+};
+
+struct GemvParams {
+  const bf16* W; const float* bias; int N, K, batch;
+  // prologue
+  int prologue;
+  const float* in;            // PRO_PLAIN: [B][K]; PRO_LAYERNORM: x [B][K]
+  const float* ln_w; const float* ln_b;
+  const float* part; int n_split; int n_head;   // PRO_ATTN_COMBINE: partials [B][H][n_split][66]
+  // epilogue
+  int epilogue;
+  float* out;                 // [B][N]
+  bf16* k_cache; bf16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;  // GEPI_QKV_CACHE (this layer)
+  const DecState* state;
+  float* amax_val; int* amax_idx; int amax_stride;  // GEPI_LOGITS: partials [grid][amax_stride]
+  float* logits_dump;              // optional logits row of this step for clip b at logits_dump + b*logits_dump_stride
+  long logits_dump_stride;
+  int skip_before_step;            // GEPI_LOGITS: do nothing while state->step < this (SOT steps)
+};
+void launch_gemv(const GemvParams& p, hipStream_t s);
+int gemv_grid(const GemvParams& p);  // number of workgroups launch_gemv will use
+
+// x[b] = tok_emb[tok[b]] + pos[step]
+void launch_embed(const bf16* tok_emb, const float* pos, const int* tok, const DecState* st, float* x, int batch, int d,
+                  hipStream_t s);
+
+// single-query attention over blocked K / row-major V, writes split partials [B][H][n_split][66]
+struct DecAttnParams {
+  const float* q;             // [B][d]
+  const bf16* k; const bf16* v; long kv_batch_stride;   // this layer, slot 0
+  float* part; int n_split;
+  int batch, n_head, d_model;
+  int n_keys;                 // fixed key count (cross) or -1: state->step + 1 (self)
+  int cap_blocks;             // allocated 64-key blocks per (slot, head): 24 cross, 7 self
+  const DecState* state;
+};
+void launch_decode_attention(const DecAttnParams& p, hipStream_t s);
+
+struct AdvanceParams {
+  const float* amax_val; const int* amax_idx; int n_part; int amax_stride;
+  DecState* state; int* tok; int* done; int* n_out; int* out_ids; int batch;
+  int n_ctx, eot, max_new;
+  const int* sot;             // device [4]
+  const int* forced; int n_forced;   // teacher forcing (device [B][n_forced]) or nullptr
+  int* argmax_dump;           // optional [B][n_forced+1]
+};
+void launch_advance(const AdvanceParams& p, hipStream_t s);
+
+// weight preparation (device): raw file dtype -> bf16 / fp32, with the layout changes the kernels want
+void launch_convert_to_bf16(const void* src, int src_dtype /*0 f32,1 bf16,2 f16*/, bf16* dst, long n, hipStream_t s);
+void launch_convert_to_f32(const void* src, int src_dtype, float* dst, long n, hipStream_t s);
+// conv weight [Cout][Cin][3] -> [Cout][Kpad] with k-major taps: dst[n][k*Cin + c]
+void launch_conv_weight_pack(const void* src, int src_dtype, bf16* dst, int cout, int cin, int kpad, hipStream_t s);
+
+}  // namespace axw

@@ -1,0 +1,173 @@
+// encoder_attn.hip — fused non-causal self-attention of the audio encoder (K7 of SURVEY §8a).
+//
+// Replaces upstream qkv_attention with SDPA disabled (export_onnx.py:714-717) inside the
+// encoder blob: softmax_fp32((q*s)(k*s)^T) v with s = 64^-0.25, T = 1500 keys, no mask (the
+// zero-padded mel frames ARE attended to, as in the reference; only the 36 rows that pad
+// 1500 -> 1536 are masked).
+//
+// Structure (wave64, flash-style, scores never leave registers):
+//   workgroup = 4 waves = 128 query rows of one (clip, head); wave = 32 query rows.
+//   S^T = K Q^T  (A = K tile rows from LDS, B = Q rows held in registers for the whole kernel):
+//     the 32x32 accumulator then has the QUERY on the lane and the keys in registers, so the
+//     row max / row sum are per-lane reductions plus one lane^32 exchange;
+//   the exponentiated accumulator registers, narrowed pairwise to bf16, ARE the B operand of
+//   O^T = V^T P^T with no lane movement (cdna guide §3, accumulator-as-operand); the A operand
+//   is read from the V^T tile with the matching permuted key order (two 8-byte reads).
+//   V^T comes for free from the QKV GEMM's swapped-operand epilogue (gemm.hip).
+// LDS: K tile [64 keys][64 d] + V^T tile [64 d][64 keys], bf16, XOR-swizzled 16-byte chunks.
+// Work per (clip, layer): 4*T^2*64*H flops = 6.9 GFLOP (small); HBM: Q,K,V read once per
+// 128-row block (K,V stay in L2 across the 12 blocks of a head), O written once.
+#include "common.hpp"
+
+namespace axw {
+
+__device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + 16 * (chunk ^ ((row >> 1) & 7)); }
+
+__global__ __launch_bounds__(256) void encoder_attention_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                                const bf16* __restrict__ VT, bf16* __restrict__ O, int T,
+                                                                int t_pad, int d_model, int n_head) {
+  __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
+  __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q_row = blockIdx.x * 128 + wave * 32 + r;
+  const int q_ld = min(q_row, T - 1);
+
+  const bf16* Qb = Q + ((long)b * T) * d_model + head * 64;
+  const bf16* Kb = K + ((long)b * T) * d_model + head * 64;
+  const bf16* Vb = VT + ((long)b * n_head + head) * 64 * t_pad;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qb + (long)q_ld * d_model + 16 * s + 8 * h);
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ld_row = tid >> 3, ld_c = tid & 7;
+  const int nkt = t_pad / 64;
+  uint4 rk[2], rv[2];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = min(kt * 64 + ld_row + 32 * i, T - 1);
+      rk[i] = *reinterpret_cast<const uint4*>(Kb + (long)key * d_model + ld_c * 8);
+      rv[i] = *reinterpret_cast<const uint4*>(Vb + (long)(ld_row + 32 * i) * t_pad + kt * 64 + ld_c * 8);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<uint4*>(Ks + swz128(ld_row + 32 * i, ld_c)) = rk[i];
+      *reinterpret_cast<uint4*>(Vs + swz128(ld_row + 32 * i, ld_c)) = rv[i];
+    }
+  };
+
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+
+  const float sc = 0.125f * 1.44269504088896340736f;  // (64^-0.25)^2 * log2(e)
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) load_tile(kt + 1);
+
+    // ---- S^T = K Q^T : sacc[kb][e] = score(key = kt*64 + kb*32 + (e&3) + 8*(e>>2) + 4h, query = lane r)
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + swz128(kb * 32 + r, 2 * s + h));
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (fp32, base-2)
+    float mt = -INFINITY;
+    const bool tail = (kt + 1) * 64 > T;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = sacc[kb][e] * sc;
+        if (tail) {
+          int key = kt * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= T) v = -INFINITY;
+        }
+        sacc[kb][e] = v;
+        mt = fmaxf(mt, v);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float ls = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float pv = __builtin_amdgcn_exp2f(sacc[kb][e] - m_new);
+        ls += pv;
+        pf[kb][e >> 3][e & 7] = (bf16)pv;
+      }
+    l_run = l_run * alpha + ls;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+
+    // ---- O^T += V^T P^T : A element j of lane half h = V^T[d][key = kb*32 + 16*s2 + 8*(j>>2) + 4h + (j&3)]
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int row = db * 32 + r, c0 = 4 * kb + 2 * s2;
+          bf16x4 lo = *reinterpret_cast<const bf16x4*>(Vs + swz128(row, c0) + 8 * h);
+          bf16x4 hi = *reinterpret_cast<const bf16x4*>(Vs + swz128(row, c0 + 1) + 8 * h);
+          bf16x8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], oacc[db], 0, 0, 0);
+        }
+
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  const float l = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l;
+  if (q_row < T) {
+    bf16* orow = O + ((long)b * T + q_row) * d_model + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = (bf16)(oacc[db][4 * g + e] * inv);
+        *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * g + 4 * h) = pk;
+      }
+  }
+}
+
+void launch_encoder_attention(const bf16* q, const bf16* k, const bf16* vt, bf16* o, int batch, int T, int t_pad, int d_model,
+                              int n_head, hipStream_t s) {
+  dim3 grid((T + 127) / 128, n_head, batch);
+  hipLaunchKernelGGL(encoder_attention_kernel, grid, dim3(256), 0, s, q, k, vt, o, T, t_pad, d_model, n_head);
+}
+
+}  // namespace axw

@@ -1,0 +1,764 @@
+// engine.cpp — host side of the MI355X Whisper engine (see engine.hpp for what it replaces).
+#include "engine.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "host_io.hpp"
+
+namespace axw {
+
+#define HIP_CHECK(expr)                                                                                  \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess)                                                                                \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);       \
+  } while (0)
+
+static int dtype_code(const std::string& d) { return d == "F32" ? 0 : d == "BF16" ? 1 : 2; }
+
+// ------------------------------------------------------------------------------ construction
+Engine::Engine(const std::string& model_type, const std::string& model_path, const std::string& language, int device,
+               int max_batch) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+    throw std::runtime_error("no HIP device visible: the MI355X engine has no CPU fallback");
+  if (device < 0) {
+    const char* e = getenv("AX_WHISPER_DEVICE");
+    device = e ? atoi(e) : 0;
+  }
+  if (device >= n_dev) throw std::runtime_error("HIP device ordinal out of range");
+  device_ = device;
+  HIP_CHECK(hipSetDevice(device_));
+  HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+  for (auto& e : ev_) HIP_CHECK(hipEventCreate(&e));
+
+  const std::string dir = model_path + "/" + model_type;
+  load_config(dir, model_type, language);
+  tokens_ = load_token_table(dir + "/" + model_type + "-tokens.txt");
+  load_weights(dir + "/" + model_type + ".safetensors");
+
+  if (max_batch <= 0) {
+    const char* e = getenv("AX_WHISPER_MAX_BATCH");
+    max_batch = e ? atoi(e) : 1;
+  }
+  HIP_CHECK(hipHostMalloc((void**)&h_poll_, 64 * sizeof(int), hipHostMallocDefault));
+  ensure_capacity(std::max(1, max_batch));
+  HIP_CHECK(hipStreamSynchronize(own_stream_));
+}
+
+Engine::~Engine() {
+  (void)hipSetDevice(device_);
+  (void)hipDeviceSynchronize();
+  for (auto& g : graphs_) (void)hipGraphExecDestroy(g.second);
+  free_slot_buffers();
+  for (void* p : allocs_) (void)hipFree(p);
+  if (h_poll_) (void)hipHostFree(h_poll_);
+  for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+  if (own_stream_) (void)hipStreamDestroy(own_stream_);
+}
+
+void* Engine::dalloc(size_t bytes, bool zero) {
+  void* p = nullptr;
+  HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 256)));
+  if (zero) HIP_CHECK(hipMemset(p, 0, std::max<size_t>(bytes, 256)));
+  return p;
+}
+
+// Whisper.cpp:86-101,129-139,241-251: config keys, comma-joined language lists, SOT sequence.
+void Engine::load_config(const std::string& dir, const std::string& type, const std::string& language) {
+  JsonValue j = JsonParser(read_text_file(dir + "/" + type + "_config.json")).parse();
+  for (auto& kv : j.obj)
+    if (kv.second.kind == JsonValue::Number) cfg_.ints[kv.first] = kv.second.as_int();
+  auto geti = [&](const char* k) { return (int)j.at(k).as_int(); };
+  cfg_.n_mels = geti("n_mels");
+  cfg_.n_vocab = geti("n_vocab");
+  cfg_.n_text_state = geti("n_text_state");
+  cfg_.n_text_ctx = geti("n_text_ctx");
+  cfg_.n_text_layer = geti("n_text_layer");
+  cfg_.n_text_head = j.has("n_text_head") ? geti("n_text_head") : cfg_.n_text_state / 64;
+  cfg_.n_audio_ctx = j.has("n_audio_ctx") ? geti("n_audio_ctx") : 1500;
+  cfg_.n_audio_state = j.has("n_audio_state") ? geti("n_audio_state") : cfg_.n_text_state;
+  cfg_.n_audio_head = j.has("n_audio_head") ? geti("n_audio_head") : cfg_.n_audio_state / 64;
+  cfg_.n_audio_layer = geti("n_audio_layer");
+  cfg_.sot = geti("sot");
+  cfg_.eot = geti("eot");
+  cfg_.transcribe = geti("transcribe");
+  cfg_.no_timestamps = geti("no_timestamps");
+  for (auto& t : split_csv(j.at("all_language_tokens").as_str())) cfg_.lang_tokens.push_back(std::stoi(t));
+  cfg_.lang_codes = split_csv(j.at("all_language_codes").as_str());
+  if (cfg_.lang_tokens.size() != cfg_.lang_codes.size() || cfg_.lang_codes.empty())
+    throw std::runtime_error("config: all_language_tokens / all_language_codes mismatch");
+  if (cfg_.n_audio_state != cfg_.n_text_state) throw std::runtime_error("config: n_audio_state != n_text_state unsupported");
+  if (cfg_.n_text_state % 128 != 0 || cfg_.n_text_state / cfg_.n_text_head != 64 || cfg_.n_audio_state / cfg_.n_audio_head != 64)
+    throw std::runtime_error("config: d_model must be a multiple of 128 with head_dim 64");
+  if (cfg_.n_audio_ctx != 1500 || cfg_.n_text_ctx != 448) throw std::runtime_error("config: expected n_audio_ctx 1500 and n_text_ctx 448");
+  if (cfg_.n_text_state > 2048) throw std::runtime_error("config: d_model > 2048 unsupported");
+  // get_lang_token (Whisper.cpp:241-251): unknown language falls back to DEFAULT_LANG "zh"
+  auto it = std::find(cfg_.lang_codes.begin(), cfg_.lang_codes.end(), language);
+  if (it == cfg_.lang_codes.end()) it = std::find(cfg_.lang_codes.begin(), cfg_.lang_codes.end(), std::string("zh"));
+  if (it == cfg_.lang_codes.end()) it = cfg_.lang_codes.begin();
+  sot_seq_[0] = cfg_.sot;
+  sot_seq_[1] = cfg_.lang_tokens[it - cfg_.lang_codes.begin()];
+  sot_seq_[2] = cfg_.transcribe;
+  sot_seq_[3] = cfg_.no_timestamps;
+  for (int i = 0; i < 4; ++i) cfg_.ints["sot_seq" + std::to_string(i)] = sot_seq_[i];
+}
+
+// Slaney mel filterbank, arithmetic as librosa.h:102-144 (fp32), stored transposed [201][n_mels].
+static std::vector<float> make_mel_basis_t(int n_mels) {
+  const int sr = 16000, n_fft = kNFFT, n_f = kBins, fmin = 0, fmax = 8000;
+  const float f_min = 0.f, f_sp = 200.f / 3.f, min_log_hz = 1000.f;
+  const float min_log_mel = (min_log_hz - f_min) / f_sp, logstep = logf(6.4f) / 27.f;
+  auto hz_to_mel = [&](int hz) {
+    float mel = (hz - f_min) / f_sp;
+    if (hz >= min_log_hz) mel = min_log_mel + logf(hz / min_log_hz) / logstep;
+    return mel;
+  };
+  const float min_mel = hz_to_mel(fmin), max_mel = hz_to_mel(fmax);
+  const int nm2 = n_mels + 2;
+  std::vector<float> mel_f(nm2);
+  const float stepv = (max_mel - min_mel) / (float)(nm2 - 1);
+  for (int i = 0; i < nm2; ++i) {
+    float mel = (i == nm2 - 1) ? max_mel : min_mel + (float)i * stepv;  // Eigen LinSpaced
+    mel_f[i] = (mel > min_log_mel) ? expf((mel - min_log_mel) * logstep) * min_log_hz : mel * f_sp + f_min;
+  }
+  std::vector<float> out((size_t)n_f * n_mels);
+  for (int m = 0; m < n_mels; ++m) {
+    const float fd0 = mel_f[m + 1] - mel_f[m], fd1 = mel_f[m + 2] - mel_f[m + 1];
+    const float enorm = (float)(2.0 / (double)(mel_f[m + 2] - mel_f[m]));
+    for (int k = 0; k < n_f; ++k) {
+      const float freq = ((float)k * sr) / n_fft;
+      const float lower = -(mel_f[m] - freq) / fd0, upper = (mel_f[m + 2] - freq) / fd1;
+      out[(size_t)k * n_mels + m] = std::max(0.f, std::min(lower, upper)) * enorm;
+    }
+  }
+  return out;
+}
+
+void Engine::load_weights(const std::string& path) {
+  SafeTensors st(path);
+  const int d = cfg_.n_text_state, nm = cfg_.n_mels, L = cfg_.n_text_layer, Le = cfg_.n_audio_layer;
+  hipStream_t s = own_stream_;
+
+  size_t max_bytes = 0;
+  auto note = [&](const std::string& n) { max_bytes = std::max(max_bytes, st.get(n).nbytes); };
+  note("decoder.token_embedding.weight");
+  note("encoder.conv2.weight");
+  note("encoder.blocks.0.mlp.0.weight");
+  void* stage = dalloc(max_bytes);
+
+  auto check = [&](const std::string& n, std::vector<int64_t> shape) -> const TensorView& {
+    const TensorView& t = st.get(n);
+    if (t.shape != shape) throw std::runtime_error("tensor '" + n + "' has an unexpected shape");
+    return t;
+  };
+  // upload one tensor into the staging buffer; conversions run on `s` in order
+  auto up = [&](const TensorView& t) {
+    HIP_CHECK(hipStreamSynchronize(s));  // staging buffer is reused
+    HIP_CHECK(hipMemcpy(stage, t.data, t.nbytes, hipMemcpyHostToDevice));
+  };
+  auto to_f32 = [&](const std::string& n, std::vector<int64_t> shape) {
+    const TensorView& t = check(n, shape);
+    float* dst = (float*)dalloc((size_t)t.numel() * 4);
+    allocs_.push_back(dst);
+    up(t);
+    launch_convert_to_f32(stage, dtype_code(t.dtype), dst, t.numel(), s);
+    return dst;
+  };
+  auto to_bf16_into = [&](const std::string& n, std::vector<int64_t> shape, bf16* dst) {
+    const TensorView& t = check(n, shape);
+    up(t);
+    launch_convert_to_bf16(stage, dtype_code(t.dtype), dst, t.numel(), s);
+  };
+  auto to_f32_into = [&](const std::string& n, std::vector<int64_t> shape, float* dst) {
+    const TensorView& t = check(n, shape);
+    up(t);
+    launch_convert_to_f32(stage, dtype_code(t.dtype), dst, t.numel(), s);
+  };
+  auto new_bf16 = [&](size_t n) { bf16* p = (bf16*)dalloc(n * 2, true); allocs_.push_back(p); return p; };
+  auto new_f32 = [&](size_t n) { float* p = (float*)dalloc(n * 4, true); allocs_.push_back(p); return p; };
+
+  // conv stem: [Cout][Cin][3] -> GEMM weights with k-major taps (gemm.hip header)
+  conv1_k_ = ((3 * nm + 63) / 64) * 64;
+  conv1_w_ = new_bf16((size_t)d * conv1_k_);
+  {
+    const TensorView& t = check("encoder.conv1.weight", {d, nm, 3});
+    up(t);
+    launch_conv_weight_pack(stage, dtype_code(t.dtype), conv1_w_, d, nm, conv1_k_, s);
+  }
+  conv2_w_ = new_bf16((size_t)d * 3 * d);
+  {
+    const TensorView& t = check("encoder.conv2.weight", {d, d, 3});
+    up(t);
+    launch_conv_weight_pack(stage, dtype_code(t.dtype), conv2_w_, d, d, 3 * d, s);
+  }
+  conv1_b_ = to_f32("encoder.conv1.bias", {d});
+  conv2_b_ = to_f32("encoder.conv2.bias", {d});
+  if (st.has("encoder.positional_embedding")) {
+    enc_pos_ = to_f32("encoder.positional_embedding", {cfg_.n_audio_ctx, d});
+  } else {  // upstream sinusoids(n_audio_ctx, d)
+    std::vector<float> pe((size_t)cfg_.n_audio_ctx * d);
+    const int half = d / 2;
+    const float inc = logf(10000.f) / (float)(half - 1);
+    for (int t = 0; t < cfg_.n_audio_ctx; ++t)
+      for (int c = 0; c < half; ++c) {
+        float v = (float)t * expf(-inc * (float)c);
+        pe[(size_t)t * d + c] = sinf(v);
+        pe[(size_t)t * d + half + c] = cosf(v);
+      }
+    enc_pos_ = new_f32(pe.size());
+    HIP_CHECK(hipMemcpy(enc_pos_, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
+  }
+  ln_post_w_ = to_f32("encoder.ln_post.weight", {d});
+  ln_post_b_ = to_f32("encoder.ln_post.bias", {d});
+
+  // attention block: q,k,v rows concatenated [3d][d]; key has no bias (upstream: bias=False)
+  auto load_attn = [&](const std::string& pre, bf16*& w_qkv, float*& b_qkv, bf16*& w_o, float*& b_o) {
+    w_qkv = new_bf16((size_t)3 * d * d);
+    b_qkv = new_f32((size_t)3 * d);
+    to_bf16_into(pre + ".query.weight", {d, d}, w_qkv);
+    to_bf16_into(pre + ".key.weight", {d, d}, w_qkv + (size_t)d * d);
+    to_bf16_into(pre + ".value.weight", {d, d}, w_qkv + (size_t)2 * d * d);
+    to_f32_into(pre + ".query.bias", {d}, b_qkv);
+    to_f32_into(pre + ".value.bias", {d}, b_qkv + 2 * d);
+    w_o = new_bf16((size_t)d * d);
+    to_bf16_into(pre + ".out.weight", {d, d}, w_o);
+    b_o = to_f32(pre + ".out.bias", {d});
+  };
+  auto load_mlp = [&](const std::string& pre, bf16*& w1, float*& b1, bf16*& w2, float*& b2) {
+    w1 = new_bf16((size_t)4 * d * d);
+    to_bf16_into(pre + ".mlp.0.weight", {4 * d, d}, w1);
+    b1 = to_f32(pre + ".mlp.0.bias", {4 * d});
+    w2 = new_bf16((size_t)4 * d * d);
+    to_bf16_into(pre + ".mlp.2.weight", {d, 4 * d}, w2);
+    b2 = to_f32(pre + ".mlp.2.bias", {d});
+  };
+
+  enc_.resize(Le);
+  for (int i = 0; i < Le; ++i) {
+    const std::string pre = "encoder.blocks." + std::to_string(i);
+    EncLayer& e = enc_[i];
+    e.ln1_w = to_f32(pre + ".attn_ln.weight", {d});
+    e.ln1_b = to_f32(pre + ".attn_ln.bias", {d});
+    load_attn(pre + ".attn", e.w_qkv, e.b_qkv, e.w_o, e.b_o);
+    e.ln2_w = to_f32(pre + ".mlp_ln.weight", {d});
+    e.ln2_b = to_f32(pre + ".mlp_ln.bias", {d});
+    load_mlp(pre, e.w_fc1, e.b_fc1, e.w_fc2, e.b_fc2);
+  }
+
+  // cross K/V projection of every decoder layer as ONE GEMM: rows [all K | all V] (gemm.hip EPI_CROSS_KV)
+  w_cross_kv_ = new_bf16((size_t)2 * L * d * d);
+  b_cross_kv_ = new_f32((size_t)2 * L * d);
+  dec_.resize(L);
+  for (int i = 0; i < L; ++i) {
+    const std::string pre = "decoder.blocks." + std::to_string(i);
+    DecLayerW& w = dec_[i];
+    bf16 *wq, *wo, *w1, *w2;
+    float *bq, *bo, *b1, *b2;
+    w.attn_ln_w = to_f32(pre + ".attn_ln.weight", {d});
+    w.attn_ln_b = to_f32(pre + ".attn_ln.bias", {d});
+    load_attn(pre + ".attn", wq, bq, wo, bo);
+    w.w_qkv = wq; w.b_qkv = bq; w.w_o = wo; w.b_o = bo;
+    w.cross_ln_w = to_f32(pre + ".cross_attn_ln.weight", {d});
+    w.cross_ln_b = to_f32(pre + ".cross_attn_ln.bias", {d});
+    bf16* wcq = new_bf16((size_t)d * d);
+    to_bf16_into(pre + ".cross_attn.query.weight", {d, d}, wcq);
+    w.w_cq = wcq;
+    w.b_cq = to_f32(pre + ".cross_attn.query.bias", {d});
+    to_bf16_into(pre + ".cross_attn.key.weight", {d, d}, w_cross_kv_ + (size_t)i * d * d);
+    to_bf16_into(pre + ".cross_attn.value.weight", {d, d}, w_cross_kv_ + (size_t)(L + i) * d * d);
+    to_f32_into(pre + ".cross_attn.value.bias", {d}, b_cross_kv_ + (size_t)(L + i) * d);
+    bf16* wco = new_bf16((size_t)d * d);
+    to_bf16_into(pre + ".cross_attn.out.weight", {d, d}, wco);
+    w.w_co = wco;
+    w.b_co = to_f32(pre + ".cross_attn.out.bias", {d});
+    w.mlp_ln_w = to_f32(pre + ".mlp_ln.weight", {d});
+    w.mlp_ln_b = to_f32(pre + ".mlp_ln.bias", {d});
+    load_mlp(pre, w1, b1, w2, b2);
+    w.w_fc1 = w1; w.b_fc1 = b1; w.w_fc2 = w2; w.b_fc2 = b2;
+  }
+  tok_emb_ = new_bf16((size_t)cfg_.n_vocab * d);
+  to_bf16_into("decoder.token_embedding.weight", {cfg_.n_vocab, d}, tok_emb_);
+  dec_pos_ = to_f32("decoder.positional_embedding", {cfg_.n_text_ctx, d});
+  dec_ln_w_ = to_f32("decoder.ln.weight", {d});
+  dec_ln_b_ = to_f32("decoder.ln.bias", {d});
+  HIP_CHECK(hipStreamSynchronize(s));
+  HIP_CHECK(hipFree(stage));
+
+  // front-end constants: DFT twiddles (double -> f32), periodic Hann (librosa.h:81), mel basis
+  std::vector<float> tw(2 * kNFFT), win(kNFFT);
+  for (int i = 0; i < kNFFT; ++i) {
+    tw[2 * i] = (float)cos(2.0 * M_PI * i / kNFFT);
+    tw[2 * i + 1] = (float)sin(2.0 * M_PI * i / kNFFT);
+    win[i] = 0.5f * (1.f - cosf((float)i * 2.f * (float)M_PI / (float)kNFFT));
+  }
+  std::vector<float> mb = make_mel_basis_t(nm);
+  twiddle_ = new_f32(tw.size());
+  window_ = new_f32(win.size());
+  mel_basis_t_ = new_f32(mb.size());
+  HIP_CHECK(hipMemcpy(twiddle_, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(window_, win.data(), win.size() * 4, hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(mel_basis_t_, mb.data(), mb.size() * 4, hipMemcpyHostToDevice));
+  d_sot_ = (int*)dalloc(16);
+  allocs_.push_back(d_sot_);
+  HIP_CHECK(hipMemcpy(d_sot_, sot_seq_, 16, hipMemcpyHostToDevice));
+}
+
+// ------------------------------------------------------------------------------ slot buffers
+void Engine::free_slot_buffers() {
+  for (auto& g : graphs_) (void)hipGraphExecDestroy(g.second);
+  graphs_.clear();
+  for (void* p : slot_allocs_) (void)hipFree(p);
+  slot_allocs_.clear();
+  if (h_pcm_) { (void)hipHostFree(h_pcm_); h_pcm_ = nullptr; }
+  cap_ = 0;
+}
+
+void Engine::ensure_capacity(int batch) {
+  if (batch <= cap_) return;
+  HIP_CHECK(hipDeviceSynchronize());
+  free_slot_buffers();
+  const int B = batch, d = cfg_.n_text_state, nm = cfg_.n_mels, H = cfg_.n_text_head, L = cfg_.n_text_layer;
+  const int T = cfg_.n_audio_ctx, Tc = cfg_.n_text_ctx;
+  auto A = [&](size_t bytes, bool zero = false) { void* p = dalloc(bytes, zero); slot_allocs_.push_back(p); return p; };
+  pcm_stride_ = 2 * 480000;  // up to 60 s per clip is kept for the global-max scan; the window itself is 30 s
+  d_pcm_ = (float*)A((size_t)B * pcm_stride_ * 4, true);
+  HIP_CHECK(hipHostMalloc((void**)&h_pcm_, (size_t)B * pcm_stride_ * 4, hipHostMallocDefault));
+  d_nsamp_ = (int*)A((size_t)B * 4);
+  d_gmax_ = (unsigned*)A((size_t)B * 4);
+  d_logmel_ = (float*)A((size_t)B * kFramesOut * nm * 4);
+  d_mel_ref_ = (float*)A((size_t)B * nm * kFramesOut * 4);
+  d_mel_tm_ = (bf16*)A((size_t)B * mel_rows_ * nm * 2 + 4096, true);
+  d_h1_ = (bf16*)A((size_t)B * h1_rows_ * d * 2 + 4096, true);
+  d_x_ = (float*)A((size_t)B * T * d * 4);
+  d_ln_ = (bf16*)A((size_t)B * T * d * 2);
+  d_q_ = (bf16*)A((size_t)B * T * d * 2);
+  d_k_ = (bf16*)A((size_t)B * T * d * 2);
+  d_vt_ = (bf16*)A((size_t)B * d * t_pad_ * 2, true);
+  d_attn_ = (bf16*)A((size_t)B * T * d * 2);
+  d_ffn_ = (bf16*)A((size_t)B * T * 4 * d * 2);
+  d_cross_k_ = (bf16*)A((size_t)L * B * H * t_pad_ * 64 * 2, true);
+  d_cross_v_ = (bf16*)A((size_t)L * B * H * t_pad_ * 64 * 2, true);
+  d_self_k_ = (bf16*)A((size_t)L * B * H * Tc * 64 * 2, true);
+  d_self_v_ = (bf16*)A((size_t)L * B * H * Tc * 64 * 2, true);
+  d_xdec_ = (float*)A((size_t)B * d * 4, true);
+  d_qdec_ = (float*)A((size_t)B * d * 4, true);
+  d_hid_ = (float*)A((size_t)B * 4 * d * 4, true);
+  split_cross_ = B <= 2 ? 6 : (B <= 8 ? 3 : 2);
+  split_self_ = B <= 8 ? 2 : 1;
+  d_part_self_ = (float*)A((size_t)B * H * split_self_ * 66 * 4, true);
+  d_part_cross_ = (float*)A((size_t)B * H * split_cross_ * 66 * 4, true);
+  GemvParams lp{};
+  lp.N = cfg_.n_vocab; lp.K = d;
+  n_amax_part_ = gemv_grid(lp);
+  d_amax_val_ = (float*)A((size_t)n_amax_part_ * B * 4, true);
+  d_amax_idx_ = (int*)A((size_t)n_amax_part_ * B * 4, true);
+  d_tok_ = (int*)A((size_t)B * 4, true);
+  d_done_ = (int*)A((size_t)B * 4, true);
+  d_nout_ = (int*)A((size_t)B * 4, true);
+  d_out_ids_ = (int*)A((size_t)B * Tc * 4, true);
+  d_state_ = (DecState*)A(sizeof(DecState), true);
+  cap_ = B;
+}
+
+// ------------------------------------------------------------------------------ front-end
+void Engine::upload_pcm(const float* const* pcm, const int* n_samples, int batch) {
+  for (int b = 0; b < batch; ++b) {
+    const int n = (int)std::min<long>(n_samples[b], pcm_stride_);
+    memcpy(h_pcm_ + (size_t)b * pcm_stride_, pcm[b], (size_t)n * 4);  // pcm_data is copied, not retained (api.cpp:151-152)
+    HIP_CHECK(hipMemcpyAsync(d_pcm_ + (size_t)b * pcm_stride_, h_pcm_ + (size_t)b * pcm_stride_, (size_t)n * 4,
+                             hipMemcpyHostToDevice, stream()));
+  }
+}
+
+void Engine::run_frontend(const float* d_pcm, int stride, const int* n_samples, int batch, bool want_ref_layout) {
+  std::vector<int> ns(batch);
+  int max_frames = 1;
+  for (int b = 0; b < batch; ++b) {
+    if (n_samples[b] < 1) throw std::runtime_error("empty audio clip");
+    ns[b] = std::min(n_samples[b], stride);
+    max_frames = std::max(max_frames, 1 + ns[b] / kHop);
+  }
+  HIP_CHECK(hipMemcpyAsync(d_nsamp_, ns.data(), (size_t)batch * 4, hipMemcpyHostToDevice, stream()));
+  HIP_CHECK(hipStreamSynchronize(stream()));  // ns is a stack vector
+  FrontendParams p{};
+  p.pcm = d_pcm; p.stride = stride; p.n_samples = d_nsamp_; p.batch = batch; p.n_mels = cfg_.n_mels;
+  p.twiddle = twiddle_; p.window = window_; p.mel_basis = mel_basis_t_;
+  p.logmel = d_logmel_; p.gmax = d_gmax_;
+  p.mel_ref = want_ref_layout ? d_mel_ref_ : nullptr;
+  p.mel_tm = d_mel_tm_; p.mel_rows = mel_rows_; p.max_frames = max_frames;
+  launch_frontend(p, stream());
+}
+
+// ------------------------------------------------------------------------------ encoder
+void Engine::run_encoder(int batch) {
+  const int d = cfg_.n_text_state, nm = cfg_.n_mels, T = cfg_.n_audio_ctx, H = cfg_.n_audio_head, L = cfg_.n_text_layer;
+  hipStream_t s = stream();
+  GemmParams g{};
+  // conv1 + GELU (export_onnx.py:158): A row t = mel frames t-1,t,t+1 (time-major, row 0 = zero pad)
+  g.A = d_mel_tm_; g.lda = nm; g.a_batch_stride = (long)mel_rows_ * nm;
+  g.W = conv1_w_; g.bias = conv1_b_;
+  g.C = d_h1_ + d; g.ldc = d; g.c_batch_stride = (long)h1_rows_ * d;  // output row t -> h1 row t+1
+  g.M = kFramesOut; g.N = d; g.K = conv1_k_; g.batch = batch; g.d_model = d; g.epilogue = EPI_BIAS_GELU_BF16;
+  launch_gemm(g, s);
+  // conv2 (stride 2) + GELU + positional embedding (export_onnx.py:159-176): A row t = h1 rows 2t-1,2t,2t+1
+  g = GemmParams{};
+  g.A = d_h1_; g.lda = 2 * d; g.a_batch_stride = (long)h1_rows_ * d;
+  g.W = conv2_w_; g.bias = conv2_b_; g.aux = enc_pos_;
+  g.C = d_x_; g.ldc = d; g.c_batch_stride = (long)T * d;
+  g.M = T; g.N = d; g.K = 3 * d; g.batch = batch; g.d_model = d; g.epilogue = EPI_GELU_POS_F32;
+  launch_gemm(g, s);
+
+  auto linear = [&](const bf16* A, int K, const bf16* W, const float* bias, void* C, int N, int epi) {
+    GemmParams q{};
+    q.A = A; q.lda = K; q.a_batch_stride = (long)T * K;
+    q.W = W; q.bias = bias; q.C = C; q.ldc = N; q.c_batch_stride = (long)T * N;
+    q.M = T; q.N = N; q.K = K; q.batch = batch; q.d_model = d; q.epilogue = epi;
+    launch_gemm(q, s);
+  };
+  for (int l = 0; l < cfg_.n_audio_layer; ++l) {
+    const EncLayer& e = enc_[l];
+    launch_layernorm_bf16(d_x_, e.ln1_w, e.ln1_b, d_ln_, (long)batch * T, d, s);
+    GemmParams q{};
+    q.A = d_ln_; q.lda = d; q.a_batch_stride = (long)T * d;
+    q.W = e.w_qkv; q.bias = e.b_qkv;
+    q.C = d_q_; q.c_batch_stride = (long)T * d;
+    q.C2 = d_k_; q.c2_batch_stride = (long)T * d;
+    q.C3 = d_vt_; q.c3_batch_stride = (long)d * t_pad_;
+    q.M = T; q.N = 3 * d; q.K = d; q.batch = batch; q.d_model = d; q.t_pad = t_pad_; q.epilogue = EPI_QKV;
+    launch_gemm(q, s);
+    launch_encoder_attention(d_q_, d_k_, d_vt_, d_attn_, batch, T, t_pad_, d, H, s);
+    linear(d_attn_, d, e.w_o, e.b_o, d_x_, d, EPI_RESID_F32);
+    launch_layernorm_bf16(d_x_, e.ln2_w, e.ln2_b, d_ln_, (long)batch * T, d, s);
+    linear(d_ln_, d, e.w_fc1, e.b_fc1, d_ffn_, 4 * d, EPI_BIAS_GELU_BF16);
+    linear(d_ffn_, 4 * d, e.w_fc2, e.b_fc2, d_x_, d, EPI_RESID_F32);
+  }
+  launch_layernorm_bf16(d_x_, ln_post_w_, ln_post_b_, d_ln_, (long)batch * T, d, s);
+  // cross K/V of all decoder layers (export_onnx.py:205-210), written in the decoder's layouts
+  GemmParams c{};
+  c.A = d_ln_; c.lda = d; c.a_batch_stride = (long)T * d;
+  c.W = w_cross_kv_; c.bias = b_cross_kv_;
+  c.C = d_cross_k_; c.C2 = d_cross_v_;
+  c.M = T; c.N = 2 * L * d; c.K = d; c.batch = batch; c.d_model = d; c.t_pad = t_pad_;
+  c.n_batch_total = cap_; c.n_layer = L; c.epilogue = EPI_CROSS_KV;
+  launch_gemm(c, s);
+}
+
+// ------------------------------------------------------------------------------ decoder
+void Engine::reset_decode_state(int batch) {
+  hipStream_t s = stream();
+  HIP_CHECK(hipMemsetAsync(d_state_, 0, sizeof(DecState), s));
+  HIP_CHECK(hipMemsetAsync(d_done_, 0, (size_t)batch * 4, s));
+  HIP_CHECK(hipMemsetAsync(d_nout_, 0, (size_t)batch * 4, s));
+  std::vector<int> t0(batch, sot_seq_[0]);
+  HIP_CHECK(hipMemcpyAsync(d_tok_, t0.data(), (size_t)batch * 4, hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// One decoder step for `batch` slots: the launch sequence that is captured into the step graph.
+void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits,
+                                 long logits_stride, int* d_argmax) {
+  const int d = cfg_.n_text_state, H = cfg_.n_text_head, L = cfg_.n_text_layer, Tc = cfg_.n_text_ctx;
+  hipStream_t s = stream();
+  launch_embed(tok_emb_, dec_pos_, d_tok_, d_state_, d_xdec_, batch, d, s);
+
+  // the VALU GEMV handles <= 4 clips per launch; tile the batch
+  auto gemv = [&](GemvParams p, auto&& offset) {
+    for (int b0 = 0; b0 < batch; b0 += 4) {
+      GemvParams q = p;
+      q.batch = std::min(4, batch - b0);
+      offset(q, b0);
+      launch_gemv(q, s);
+    }
+  };
+  auto attn = [&](const bf16* kc, const bf16* vc, long stride, int n_keys, int cap_blocks, float* part, int n_split) {
+    DecAttnParams a{};
+    a.q = d_qdec_; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = part; a.n_split = n_split;
+    a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
+    launch_decode_attention(a, s);
+  };
+
+  const long self_stride = (long)H * Tc * 64, cross_stride = (long)H * t_pad_ * 64;
+  for (int l = 0; l < L; ++l) {
+    const DecLayerW& w = dec_[l];
+    bf16* sk = d_self_k_ + (size_t)l * cap_ * self_stride;
+    bf16* sv = d_self_v_ + (size_t)l * cap_ * self_stride;
+    const bf16* ck = d_cross_k_ + (size_t)l * cap_ * cross_stride;
+    const bf16* cv = d_cross_v_ + (size_t)l * cap_ * cross_stride;
+    GemvParams p{};
+    // q,k,v = Linear(attn_ln(x)); k,v appended to the self cache at row `step` (export_onnx.py:245-247, Whisper.cpp:328-342)
+    p.W = w.w_qkv; p.bias = w.b_qkv; p.N = 3 * d; p.K = d;
+    p.prologue = PRO_LAYERNORM; p.in = d_xdec_; p.ln_w = w.attn_ln_w; p.ln_b = w.attn_ln_b;
+    p.epilogue = GEPI_QKV_CACHE; p.out = d_qdec_; p.k_cache = sk; p.v_cache = sv; p.kv_batch_stride = self_stride;
+    p.d_model = d; p.n_ctx_pad = Tc; p.state = d_state_;
+    gemv(p, [&](GemvParams& q, int b0) { q.in += (long)b0 * d; q.out += (long)b0 * d; q.k_cache += b0 * self_stride; q.v_cache += b0 * self_stride; });
+    attn(sk, sv, self_stride, -1, Tc / 64, d_part_self_, split_self_);
+    // x += out(attention)
+    p = GemvParams{};
+    p.W = w.w_o; p.bias = w.b_o; p.N = d; p.K = d;
+    p.prologue = PRO_ATTN_COMBINE; p.part = d_part_self_; p.n_split = split_self_; p.n_head = H;
+    p.epilogue = GEPI_RESID; p.out = d_xdec_; p.state = d_state_;
+    gemv(p, [&](GemvParams& q, int b0) { q.part += (long)b0 * H * split_self_ * 66; q.out += (long)b0 * d; });
+    // cross attention (export_onnx.py:221-230)
+    p = GemvParams{};
+    p.W = w.w_cq; p.bias = w.b_cq; p.N = d; p.K = d;
+    p.prologue = PRO_LAYERNORM; p.in = d_xdec_; p.ln_w = w.cross_ln_w; p.ln_b = w.cross_ln_b;
+    p.epilogue = GEPI_STORE; p.out = d_qdec_; p.state = d_state_;
+    gemv(p, [&](GemvParams& q, int b0) { q.in += (long)b0 * d; q.out += (long)b0 * d; });
+    attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64, d_part_cross_, split_cross_);
+    p = GemvParams{};
+    p.W = w.w_co; p.bias = w.b_co; p.N = d; p.K = d;
+    p.prologue = PRO_ATTN_COMBINE; p.part = d_part_cross_; p.n_split = split_cross_; p.n_head = H;
+    p.epilogue = GEPI_RESID; p.out = d_xdec_; p.state = d_state_;
+    gemv(p, [&](GemvParams& q, int b0) { q.part += (long)b0 * H * split_cross_ * 66; q.out += (long)b0 * d; });
+    // mlp (export_onnx.py:298)
+    p = GemvParams{};
+    p.W = w.w_fc1; p.bias = w.b_fc1; p.N = 4 * d; p.K = d;
+    p.prologue = PRO_LAYERNORM; p.in = d_xdec_; p.ln_w = w.mlp_ln_w; p.ln_b = w.mlp_ln_b;
+    p.epilogue = GEPI_GELU; p.out = d_hid_; p.state = d_state_;
+    gemv(p, [&](GemvParams& q, int b0) { q.in += (long)b0 * d; q.out += (long)b0 * 4 * d; });
+    p = GemvParams{};
+    p.W = w.w_fc2; p.bias = w.b_fc2; p.N = d; p.K = 4 * d;
+    p.prologue = PRO_PLAIN; p.in = d_hid_;
+    p.epilogue = GEPI_RESID; p.out = d_xdec_; p.state = d_state_;
+    gemv(p, [&](GemvParams& q, int b0) { q.in += (long)b0 * 4 * d; q.out += (long)b0 * d; });
+  }
+  // logits = token_embedding . ln(x) (tied, export_onnx.py:364-385) fused with the argmax partials
+  GemvParams p{};
+  p.W = tok_emb_; p.bias = nullptr; p.N = cfg_.n_vocab; p.K = d;
+  p.prologue = PRO_LAYERNORM; p.in = d_xdec_; p.ln_w = dec_ln_w_; p.ln_b = dec_ln_b_;
+  p.epilogue = GEPI_LOGITS; p.state = d_state_; p.amax_val = d_amax_val_; p.amax_idx = d_amax_idx_; p.amax_stride = cap_;
+  p.skip_before_step = 3; p.logits_dump = d_logits; p.logits_dump_stride = logits_stride;
+  gemv(p, [&](GemvParams& q, int b0) {
+    q.in += (long)b0 * d; q.amax_val += b0; q.amax_idx += b0;
+    if (q.logits_dump) q.logits_dump += (long)b0 * logits_stride;
+  });
+  AdvanceParams a{};
+  a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = n_amax_part_; a.amax_stride = cap_;
+  a.state = d_state_; a.tok = d_tok_; a.done = d_done_; a.n_out = d_nout_; a.out_ids = d_out_ids_; a.batch = batch;
+  a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.sot = d_sot_;
+  a.forced = d_forced; a.n_forced = n_forced; a.argmax_dump = d_argmax;
+  launch_advance(a, s);
+}
+
+hipGraphExec_t Engine::step_graph(int batch, int max_new) {
+  const long key = (long)batch * 1024 + max_new;
+  auto it = graphs_.find(key);
+  if (it != graphs_.end()) return it->second;
+  hipStream_t s = stream();
+  hipGraph_t graph = nullptr;
+  HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  try {
+    enqueue_decode_step(batch, max_new, nullptr, 0, nullptr, 0, nullptr);
+  } catch (...) {
+    (void)hipStreamEndCapture(s, &graph);
+    throw;
+  }
+  HIP_CHECK(hipStreamEndCapture(s, &graph));
+  hipGraphExec_t exec = nullptr;
+  HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  HIP_CHECK(hipGraphDestroy(graph));
+  graphs_[key] = exec;
+  return exec;
+}
+
+// Whisper.cpp:207-222. Returns the number of decoder steps executed.
+int Engine::greedy_loop(int batch, int max_new) {
+  const int Tc = cfg_.n_text_ctx;
+  if (max_new <= 0 || max_new > Tc - 4) max_new = Tc - 4;
+  reset_decode_state(batch);
+  hipGraphExec_t g = step_graph(batch, max_new);
+  hipStream_t s = stream();
+  const int total = std::min(Tc, 4 + max_new);
+  const int kPoll = 8;  // steps between done-counter polls; at most 2*kPoll steps run past the last eot
+  hipEvent_t pe[2] = {ev_[3], ev_[4]};
+  int steps = 0, polls = 0;
+  for (int st = 0; st < total; ++st) {
+    HIP_CHECK(hipGraphLaunch(g, s));
+    ++steps;
+    if ((st + 1) % kPoll == 0 && st >= 4) {
+      if (polls >= 1) {  // look at the poll issued kPoll steps ago (keeps the queue full)
+        HIP_CHECK(hipEventSynchronize(pe[(polls - 1) & 1]));
+        if (h_poll_[(polls - 1) & 1] >= batch) break;
+      }
+      HIP_CHECK(hipMemcpyAsync(&h_poll_[polls & 1], &d_state_->n_done, 4, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipEventRecord(pe[polls & 1], s));
+      ++polls;
+    }
+  }
+  return steps;
+}
+
+void Engine::fetch_ids(int batch, int32_t* ids, int* n_ids) {
+  hipStream_t s = stream();
+  HIP_CHECK(hipMemcpyAsync(ids, d_out_ids_, (size_t)batch * cfg_.n_text_ctx * 4, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipMemcpyAsync(n_ids, d_nout_, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// ------------------------------------------------------------------------------ public entry points
+void Engine::run_tokens(const float* const* pcm, const float* d_pcm, int d_stride, const int* n_samples, int batch, int max_new,
+                        int32_t* ids, int* n_ids) {
+  if (batch < 1) throw std::runtime_error("batch must be >= 1");
+  HIP_CHECK(hipSetDevice(device_));
+  auto t0 = std::chrono::steady_clock::now();
+  ensure_capacity(batch);
+  hipStream_t s = stream();
+  HIP_CHECK(hipEventRecord(ev_[0], s));
+  if (pcm) {
+    upload_pcm(pcm, n_samples, batch);
+    run_frontend(d_pcm_, (int)pcm_stride_, n_samples, batch, false);
+  } else {
+    run_frontend(d_pcm, d_stride, n_samples, batch, false);
+  }
+  HIP_CHECK(hipEventRecord(ev_[1], s));
+  run_encoder(batch);
+  HIP_CHECK(hipEventRecord(ev_[2], s));
+  const int steps = greedy_loop(batch, max_new);
+  fetch_ids(batch, ids, n_ids);
+  // stage timings (events 3/4 are reused by the poll; bracket decode with a fresh record)
+  HIP_CHECK(hipEventRecord(ev_[3], s));
+  HIP_CHECK(hipEventSynchronize(ev_[3]));
+  (void)hipEventElapsedTime(&timings[0], ev_[0], ev_[1]);
+  (void)hipEventElapsedTime(&timings[1], ev_[1], ev_[2]);
+  (void)hipEventElapsedTime(&timings[2], ev_[2], ev_[3]);
+  timings[3] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  timings[4] = (float)steps;
+}
+
+// Whisper.cpp:224-229 with bounds checks: bytes are concatenated, ids beyond the table skipped.
+std::string Engine::detokenize(const int32_t* ids, int n) const {
+  std::string out;
+  for (int i = 0; i < n; ++i)
+    if (ids[i] >= 0 && (size_t)ids[i] < tokens_.size()) out += tokens_[ids[i]];
+  return out;
+}
+
+void Engine::compute_mel(const float* pcm, int n_samples, float* mel_out) {
+  HIP_CHECK(hipSetDevice(device_));
+  ensure_capacity(1);
+  const float* arr[1] = {pcm};
+  upload_pcm(arr, &n_samples, 1);
+  run_frontend(d_pcm_, (int)pcm_stride_, &n_samples, 1, true);
+  HIP_CHECK(hipMemcpyAsync(mel_out, d_mel_ref_, (size_t)cfg_.n_mels * kFramesOut * 4, hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipStreamSynchronize(stream()));
+}
+
+void Engine::encode_mel(const float* mel, int batch) {
+  HIP_CHECK(hipSetDevice(device_));
+  ensure_capacity(batch);
+  HIP_CHECK(hipMemcpyAsync(d_mel_ref_, mel, (size_t)batch * cfg_.n_mels * kFramesOut * 4, hipMemcpyHostToDevice, stream()));
+  launch_mel_to_tm(d_mel_ref_, d_mel_tm_, batch, cfg_.n_mels, mel_rows_, stream());
+  run_encoder(batch);
+  HIP_CHECK(hipStreamSynchronize(stream()));
+}
+
+// back to the reference's layout [n_text_layer][1500][d] fp32 (export_onnx.py:212-213)
+void Engine::get_cross_kv(int slot, float* k_out, float* v_out) {
+  HIP_CHECK(hipSetDevice(device_));
+  if (slot < 0 || slot >= cap_) throw std::runtime_error("slot out of range");
+  const int d = cfg_.n_text_state, H = cfg_.n_text_head, L = cfg_.n_text_layer, T = cfg_.n_audio_ctx;
+  const size_t per = (size_t)H * t_pad_ * 64;
+  std::vector<uint16_t> hk(per), hv(per);
+  HIP_CHECK(hipStreamSynchronize(stream()));
+  for (int l = 0; l < L; ++l) {
+    HIP_CHECK(hipMemcpy(hk.data(), d_cross_k_ + ((size_t)l * cap_ + slot) * per, per * 2, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(hv.data(), d_cross_v_ + ((size_t)l * cap_ + slot) * per, per * 2, hipMemcpyDeviceToHost));
+    for (int h = 0; h < H; ++h)
+      for (int t = 0; t < T; ++t)
+        for (int c = 0; c < 64; ++c) {
+          uint32_t kb = (uint32_t)hk[(size_t)h * t_pad_ * 64 + (size_t)(t >> 6) * 4096 + (c >> 3) * 512 + (t & 63) * 8 + (c & 7)] << 16;
+          uint32_t vb = (uint32_t)hv[(size_t)h * t_pad_ * 64 + (size_t)t * 64 + c] << 16;
+          float kf, vf;
+          memcpy(&kf, &kb, 4);
+          memcpy(&vf, &vb, 4);
+          k_out[((size_t)l * T + t) * d + h * 64 + c] = kf;
+          v_out[((size_t)l * T + t) * d + h * 64 + c] = vf;
+        }
+  }
+}
+
+void Engine::decode_forced(int batch, const int32_t* forced, int n_forced, float* logits, int32_t* argmax_ids) {
+  HIP_CHECK(hipSetDevice(device_));
+  if (batch < 1 || batch > cap_) throw std::runtime_error("decode_forced: batch exceeds the encoded slots");
+  if (n_forced < 0 || n_forced + 4 > cfg_.n_text_ctx) throw std::runtime_error("decode_forced: n_forced out of range");
+  hipStream_t s = stream();
+  const int nv = cfg_.n_vocab, rows = n_forced + 1;
+  int* d_forced = nullptr;
+  float* d_logits = nullptr;
+  int* d_arg = nullptr;
+  HIP_CHECK(hipMalloc((void**)&d_forced, std::max<size_t>((size_t)batch * n_forced * 4, 256)));
+  HIP_CHECK(hipMalloc((void**)&d_arg, (size_t)batch * rows * 4));
+  if (logits) HIP_CHECK(hipMalloc((void**)&d_logits, (size_t)batch * rows * nv * 4));
+  if (n_forced) HIP_CHECK(hipMemcpy(d_forced, forced, (size_t)batch * n_forced * 4, hipMemcpyHostToDevice));
+  reset_decode_state(batch);
+  for (int st = 0; st < 4 + n_forced; ++st) {
+    const int gi = st - 3;
+    float* lrow = (d_logits && gi >= 0) ? d_logits + (size_t)gi * nv : nullptr;
+    enqueue_decode_step(batch, cfg_.n_text_ctx, d_forced, n_forced, lrow, (long)rows * nv, d_arg);
+  }
+  HIP_CHECK(hipStreamSynchronize(s));
+  if (logits) HIP_CHECK(hipMemcpy(logits, d_logits, (size_t)batch * rows * nv * 4, hipMemcpyDeviceToHost));
+  if (argmax_ids) HIP_CHECK(hipMemcpy(argmax_ids, d_arg, (size_t)batch * rows * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d_forced);
+  (void)hipFree(d_arg);
+  if (d_logits) (void)hipFree(d_logits);
+}
+
+void Engine::decode_greedy(int batch, int max_new, int32_t* ids, int* n_ids) {
+  HIP_CHECK(hipSetDevice(device_));
+  if (batch < 1 || batch > cap_) throw std::runtime_error("decode_greedy: batch exceeds the encoded slots");
+  greedy_loop(batch, max_new);
+  fetch_ids(batch, ids, n_ids);
+}
+
+float Engine::bench(const std::string& what, int batch, int arg, int iters) {
+  HIP_CHECK(hipSetDevice(device_));
+  ensure_capacity(batch);
+  hipStream_t s = stream();
+  hipEvent_t a, b;
+  HIP_CHECK(hipEventCreate(&a));
+  HIP_CHECK(hipEventCreate(&b));
+  float ms = 0.f;
+  if (what == "decode_step") {
+    const int Tc = cfg_.n_text_ctx;
+    reset_decode_state(batch);
+    hipGraphExec_t g = step_graph(batch, Tc - 4);
+    arg = std::max(0, std::min(arg, Tc - 1 - iters));
+    DecState st{arg, 0, 0, 0};
+    HIP_CHECK(hipMemcpy(d_state_, &st, sizeof(st), hipMemcpyHostToDevice));
+    HIP_CHECK(hipGraphLaunch(g, s));  // warm
+    st.step = arg;
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipMemcpy(d_state_, &st, sizeof(st), hipMemcpyHostToDevice));
+    HIP_CHECK(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) HIP_CHECK(hipGraphLaunch(g, s));
+    HIP_CHECK(hipEventRecord(b, s));
+  } else if (what == "encoder") {
+    run_encoder(batch);
+    HIP_CHECK(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) run_encoder(batch);
+    HIP_CHECK(hipEventRecord(b, s));
+  } else if (what == "frontend") {
+    std::vector<int> ns(batch, 480000);
+    run_frontend(d_pcm_, (int)pcm_stride_, ns.data(), batch, false);
+    HIP_CHECK(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) run_frontend(d_pcm_, (int)pcm_stride_, ns.data(), batch, false);
+    HIP_CHECK(hipEventRecord(b, s));
+  } else {
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    throw std::runtime_error("bench: unknown target '" + what + "'");
+  }
+  HIP_CHECK(hipEventSynchronize(b));
+  HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return ms;
+}
+
+}  // namespace axw

@@ -1,0 +1,116 @@
+// engine.hpp — the MI355X Whisper engine behind the AX_WHISPER_* C ABI.
+//
+// Replaces class Whisper (cpp/src/Whisper.hpp:28-59, cpp/src/Whisper.cpp) together with the two
+// AxModelRunner NPU executors it owns (cpp/src/ax_model_runner/ax_model_runner.hpp:23-80): model
+// directory loading (Whisper.cpp:86-149), preprocess (:151-184), encoder call (:190-195),
+// cross-KV hand-off (:260-288, here: none — the encoder writes the decoder's layouts in place),
+// the greedy loop (:207-222) and detokenisation (:224-229). The reference handles one utterance at
+// a time; this engine runs B utterance slots through every stage as one batch.
+#pragma once
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace axw {
+
+struct ModelConfig {
+  int n_mels = 0, n_audio_ctx = 1500, n_audio_state = 0, n_audio_head = 0, n_audio_layer = 0;
+  int n_vocab = 0, n_text_ctx = 448, n_text_state = 0, n_text_head = 0, n_text_layer = 0;
+  int sot = 0, eot = 0, transcribe = 0, translate = 0, no_timestamps = 0;
+  std::vector<int> lang_tokens;
+  std::vector<std::string> lang_codes;
+  std::map<std::string, long> ints;  // every integer-valued key of the config file
+};
+
+class Engine {
+ public:
+  Engine(const std::string& model_type, const std::string& model_path, const std::string& language, int device, int max_batch);
+  ~Engine();
+  Engine(const Engine&) = delete;
+
+  // full path, host PCM or device PCM; ids [batch][n_text_ctx], n_ids [batch]
+  void run_tokens(const float* const* pcm, const float* d_pcm, int d_stride, const int* n_samples, int batch, int max_new,
+                  int32_t* ids, int* n_ids);
+  std::string detokenize(const int32_t* ids, int n) const;
+
+  // stage-level
+  void compute_mel(const float* pcm, int n_samples, float* mel_out);
+  void encode_mel(const float* mel, int batch);
+  void get_cross_kv(int slot, float* k_out, float* v_out);
+  void decode_forced(int batch, const int32_t* forced, int n_forced, float* logits, int32_t* argmax_ids);
+  void decode_greedy(int batch, int max_new, int32_t* ids, int* n_ids);
+  float bench(const std::string& what, int batch, int arg, int iters);
+
+  void set_stream(hipStream_t s) { user_stream_ = s; }
+  const ModelConfig& config() const { return cfg_; }
+  const int* sot_seq() const { return sot_seq_; }
+  std::mutex& mutex() { return mu_; }
+  float timings[5] = {0, 0, 0, 0, 0};
+
+ private:
+  struct EncLayer {
+    float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    bf16 *w_qkv, *w_o, *w_fc1, *w_fc2;
+    float *b_qkv, *b_o, *b_fc1, *b_fc2;
+  };
+
+  hipStream_t stream() const { return user_stream_ ? user_stream_ : own_stream_; }
+  void* dalloc(size_t bytes, bool zero = false);
+  void load_config(const std::string& dir, const std::string& type, const std::string& language);
+  void load_weights(const std::string& path);
+  void ensure_capacity(int batch);
+  void free_slot_buffers();
+  void upload_pcm(const float* const* pcm, const int* n_samples, int batch);
+  void run_frontend(const float* d_pcm, int stride, const int* n_samples, int batch, bool want_ref_layout);
+  void run_encoder(int batch);
+  void reset_decode_state(int batch);
+  void enqueue_decode_step(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits, long logits_stride,
+                           int* d_argmax);
+  hipGraphExec_t step_graph(int batch, int max_new);
+  int greedy_loop(int batch, int max_new);
+  void fetch_ids(int batch, int32_t* ids, int* n_ids);
+
+  ModelConfig cfg_;
+  int sot_seq_[4] = {0, 0, 0, 0};
+  std::vector<std::string> tokens_;
+  std::mutex mu_;
+  int device_ = 0;
+  hipStream_t own_stream_ = nullptr, user_stream_ = nullptr;
+  std::vector<void*> allocs_;       // weights + constants (freed at destruction)
+  std::vector<void*> slot_allocs_;  // capacity-dependent buffers
+
+  // weights
+  bf16 *conv1_w_ = nullptr, *conv2_w_ = nullptr, *w_cross_kv_ = nullptr, *tok_emb_ = nullptr;
+  float *conv1_b_ = nullptr, *conv2_b_ = nullptr, *enc_pos_ = nullptr, *ln_post_w_ = nullptr, *ln_post_b_ = nullptr;
+  float *b_cross_kv_ = nullptr, *dec_pos_ = nullptr, *dec_ln_w_ = nullptr, *dec_ln_b_ = nullptr;
+  int conv1_k_ = 0;
+  std::vector<EncLayer> enc_;
+  std::vector<DecLayerW> dec_;
+  // front-end constants
+  float *twiddle_ = nullptr, *window_ = nullptr, *mel_basis_t_ = nullptr;
+  int* d_sot_ = nullptr;
+
+  // capacity-dependent
+  int cap_ = 0;
+  int t_pad_ = 1536, mel_rows_ = 3004, h1_rows_ = 3002;
+  float* d_pcm_ = nullptr; long pcm_stride_ = 0; float* h_pcm_ = nullptr;
+  int* d_nsamp_ = nullptr; unsigned* d_gmax_ = nullptr; float* d_logmel_ = nullptr; float* d_mel_ref_ = nullptr;
+  bf16 *d_mel_tm_ = nullptr, *d_h1_ = nullptr, *d_ln_ = nullptr, *d_q_ = nullptr, *d_k_ = nullptr, *d_vt_ = nullptr,
+       *d_attn_ = nullptr, *d_ffn_ = nullptr;
+  float* d_x_ = nullptr;
+  bf16 *d_cross_k_ = nullptr, *d_cross_v_ = nullptr, *d_self_k_ = nullptr, *d_self_v_ = nullptr;
+  float *d_xdec_ = nullptr, *d_qdec_ = nullptr, *d_hid_ = nullptr, *d_part_self_ = nullptr, *d_part_cross_ = nullptr;
+  float* d_amax_val_ = nullptr; int* d_amax_idx_ = nullptr; int n_amax_part_ = 0;
+  int *d_tok_ = nullptr, *d_done_ = nullptr, *d_nout_ = nullptr, *d_out_ids_ = nullptr;
+  DecState* d_state_ = nullptr;
+  int* h_poll_ = nullptr;  // pinned
+  int split_self_ = 2, split_cross_ = 6;
+  std::map<long, hipGraphExec_t> graphs_;  // key: batch * 1024 + max_new
+  hipEvent_t ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+}  // namespace axw

@@ -1,0 +1,261 @@
+// gemm.hip — bf16 MFMA GEMM with fused epilogues for the encoder (K3, K4, K6, K8 of SURVEY §8a).
+//
+// C[M,N] = A[M,K] * W[N,K]^T, A and W bf16 with K contiguous (nn.Linear weights are [out][in],
+// so no transposition is ever needed), fp32 accumulation in v_mfma_f32_32x32x16_bf16.
+//
+// Replaces, inside the reference's opaque encoder blob (cpp/src/ax_model_runner/
+// ax_model_runner.cpp:95-108 running export_onnx.py:153-213): conv1/conv2 (as GEMMs over
+// overlapping time-major rows: A row t = 3 consecutive input frames, lda = stride*C_in),
+// every nn.Linear of the encoder blocks and the per-decoder-layer cross K/V projections.
+//
+// Tiling (wave64): 128x128 output tile, BK = 64, 256 threads = 4 waves in 2x2, each wave a
+// 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs). A and W tiles are staged
+// global -> registers -> LDS with an XOR swizzle of the 16-byte chunks (chunk ^ ((row>>1)&7))
+// which makes every ds_read_b128 fragment read conflict-free; the loads of k-tile t+1 are issued
+// before the MFMAs of k-tile t and written to the other LDS buffer afterwards (one barrier per
+// k-tile). Epilogues write the layouts the consumers want (V^T for the encoder attention, the
+// blocked K / row-major V of the decoder's cross-attention) so no transposition kernel exists;
+// where the consumer wants M contiguous the MFMA operands are swapped so lanes run along M.
+#include "common.hpp"
+
+namespace axw {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KB per operand tile
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * (BK * 2) + 16 * (chunk ^ ((row >> 1) & 7)); }
+
+template <int EPI, bool SWAPPED>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                     // [2][TILE_BYTES]
+  char* Ws = smem + 2 * TILE_BYTES;    // [2][TILE_BYTES]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int n0 = p.n_begin + blockIdx.x * BN, m0 = blockIdx.y * BM, bz = blockIdx.z;
+
+  const bf16* A = p.A + (long)bz * p.a_batch_stride;
+  const bf16* W = p.W;
+
+  // per-thread staging coordinates: chunk t + 256*i -> row = t/8 + 32*i, col chunk = t%8
+  const int ld_row = tid >> 3, ld_c = tid & 7;
+  const bf16* a_src[4];
+  const bf16* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int ra = min(m0 + ld_row + 32 * i, p.M - 1);
+    a_src[i] = A + (long)ra * p.lda + ld_c * 8;
+    w_src[i] = W + (long)(n0 + ld_row + 32 * i) * p.K + ld_c * 8;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // SWAPPED: MFMA operands exchanged so that lanes run along M (the consumer wants M contiguous)
+  constexpr bool swapped = SWAPPED;
+
+  uint4 ra[4], rw[4];
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ra[i] = *reinterpret_cast<const uint4*>(a_src[i]);
+    rw[i] = *reinterpret_cast<const uint4*>(w_src[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<uint4*>(As + swz(ld_row + 32 * i, ld_c)) = ra[i];
+    *reinterpret_cast<uint4*>(Ws + swz(ld_row + 32 * i, ld_c)) = rw[i];
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const uint4*>(a_src[i] + (kt + 1) * BK);
+        rw[i] = *reinterpret_cast<const uint4*>(w_src[i] + (kt + 1) * BK);
+      }
+    }
+    const char* Ab = As + cur * TILE_BYTES;
+    const char* Wb = Ws + cur * TILE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 af[2], wf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + swz(wm * 64 + i * 32 + r, 2 * s + h));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(Wb + swz(wn * 64 + j * 32 + r, 2 * s + h));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = SWAPPED ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      char* An = As + (cur ^ 1) * TILE_BYTES;
+      char* Wn = Ws + (cur ^ 1) * TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<uint4*>(An + swz(ld_row + 32 * i, ld_c)) = ra[i];
+        *reinterpret_cast<uint4*>(Wn + swz(ld_row + 32 * i, ld_c)) = rw[i];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // normal:  acc[i][j][e] = C[m = mb + i*32 + row(e,h)][n = nb + j*32 + r]
+  // swapped: acc[i][j][e] = C[m = mb + i*32 + r][n = nb + j*32 + row(e,h)],  row(e,h) = (e&3) + 8*(e>>2) + 4*h
+  const int mb = m0 + wm * 64, nb = n0 + wn * 64;
+  const int d = p.d_model;
+
+  if constexpr (!SWAPPED) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = nb + j * 32 + r;
+      const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = mb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (m >= p.M) continue;
+          float v = acc[i][j][e] + bias;
+          if constexpr (EPI == EPI_BIAS_BF16) {
+            reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] = (bf16)v;
+          } else if constexpr (EPI == EPI_BIAS_GELU_BF16) {
+            reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] = (bf16)gelu_erf(v);
+          } else if constexpr (EPI == EPI_GELU_POS_F32) {
+            reinterpret_cast<float*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] =
+                gelu_erf(v) + p.aux[(long)m * p.N + n];
+          } else if constexpr (EPI == EPI_RESID_F32) {
+            float* c = reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n;
+            *c += v;
+          } else if constexpr (EPI == EPI_QKV) {  // Q (n < d) or K (d <= n < 2d), both bf16 [m][d]
+            if (n < d) reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * d + n] = (bf16)v;
+            else reinterpret_cast<bf16*>(p.C2)[(long)bz * p.c2_batch_stride + (long)m * d + (n - d)] = (bf16)v;
+          } else {  // EPI_CROSS_KV, V rows [n_layer*d, 2*n_layer*d): [l][slot][head][t_pad][64]
+            const int nv = n - p.n_layer * d;
+            const int l = nv / d, c = nv - l * d;
+            const int head = c >> 6, dd = c & 63;
+            const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + head;
+            reinterpret_cast<bf16*>(p.C2)[(slot * p.t_pad + m) * 64 + dd] = (bf16)v;
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mb + i * 32 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (EPI == EPI_QKV) {  // V^T [head][64][t_pad], lanes run along m (coalesced)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int n = nb + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float v = acc[i][j][e] + (p.bias ? p.bias[n] : 0.f);
+            const int c = n - 2 * d;
+            reinterpret_cast<bf16*>(p.C3)[(long)bz * p.c3_batch_stride + (long)c * p.t_pad + m] = (bf16)v;
+          }
+        } else {  // EPI_CROSS_KV K rows [0, n_layer*d): blocked [l][slot][head][m/64][dd/8][m%64][8]; 4 consecutive dd per quad
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = nb + j * 32 + 8 * q + 4 * h;
+            const int l = n / d, c = n - l * d;
+            const int head = c >> 6, dd = c & 63;
+            bf16x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = (bf16)(acc[i][j][4 * q + e] + (p.bias ? p.bias[n + e] : 0.f));
+            const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + head;
+            bf16* dst = reinterpret_cast<bf16*>(p.C) + slot * p.t_pad * 64 + (long)(m >> 6) * 4096 + (dd >> 3) * 512 + (m & 63) * 8 + (dd & 7);
+            *reinterpret_cast<bf16x4*>(dst) = pk;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, bool SW>
+static void launch_one(GemmParams p, int n_begin, int n_end, hipStream_t s) {
+  if (n_end <= n_begin) return;
+  p.n_begin = n_begin;
+  dim3 grid((n_end - n_begin) / BN, (p.M + BM - 1) / BM, p.batch);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, SW>), grid, dim3(256), 4 * TILE_BYTES, s, p);
+}
+
+void launch_gemm(const GemmParams& p, hipStream_t s) {
+  switch (p.epilogue) {
+    case EPI_BIAS_BF16: launch_one<EPI_BIAS_BF16, false>(p, 0, p.N, s); break;
+    case EPI_BIAS_GELU_BF16: launch_one<EPI_BIAS_GELU_BF16, false>(p, 0, p.N, s); break;
+    case EPI_GELU_POS_F32: launch_one<EPI_GELU_POS_F32, false>(p, 0, p.N, s); break;
+    case EPI_RESID_F32: launch_one<EPI_RESID_F32, false>(p, 0, p.N, s); break;
+    case EPI_QKV:  // Q,K rows normal; V rows with swapped operands (V^T output)
+      launch_one<EPI_QKV, false>(p, 0, 2 * p.d_model, s);
+      launch_one<EPI_QKV, true>(p, 2 * p.d_model, 3 * p.d_model, s);
+      break;
+    case EPI_CROSS_KV:  // weight rows: all layers' K first (swapped, blocked layout), then all layers' V
+      launch_one<EPI_CROSS_KV, true>(p, 0, p.n_layer * p.d_model, s);
+      launch_one<EPI_CROSS_KV, false>(p, p.n_layer * p.d_model, 2 * p.n_layer * p.d_model, s);
+      break;
+  }
+}
+
+// ---------------------------------------------------------------------------- LayerNorm
+// fp32 rows -> bf16 rows, eps 1e-5, biased variance (nn.LayerNorm [upstream]); one wave per row.
+__global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                             const float* __restrict__ b, bf16* __restrict__ y, long rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + row * d);
+  const int nv = d >> 2;  // float4 per row
+  float4 v[8];            // d <= 2048
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int c = lane + 64 * i;
+    if (c < nv) { v[i] = xr[c]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+  }
+  const float mean = wave_sum(s) / d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int c = lane + 64 * i;
+    if (c < nv) {
+      float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+      q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / d + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int c = lane + 64 * i;
+    if (c < nv) {
+      float4 gg = reinterpret_cast<const float4*>(g)[c], bb = reinterpret_cast<const float4*>(b)[c];
+      bf16x4 o;
+      o[0] = (bf16)((v[i].x - mean) * rstd * gg.x + bb.x);
+      o[1] = (bf16)((v[i].y - mean) * rstd * gg.y + bb.y);
+      o[2] = (bf16)((v[i].z - mean) * rstd * gg.z + bb.z);
+      o[3] = (bf16)((v[i].w - mean) * rstd * gg.w + bb.w);
+      reinterpret_cast<bf16x4*>(y + row * d)[c] = o;
+    }
+  }
+}
+
+void launch_layernorm_bf16(const float* x, const float* g, const float* b, bf16* y, long rows, int d, hipStream_t s) {
+  hipLaunchKernelGGL(layernorm_bf16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, g, b, y, rows, d);
+}
+
+}  // namespace axw

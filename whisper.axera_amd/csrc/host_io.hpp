@@ -1,0 +1,279 @@
+// host_io.hpp — host-side file formats of the model directory and the audio input.
+//
+//   * a small JSON reader for {type}_config.json (the reference uses nlohmann::json,
+//     cpp/src/Whisper.cpp:98-100; only objects/strings/numbers are needed here)
+//   * a safetensors reader (mmap) for {type}.safetensors
+//   * {type}-tokens.txt: "<base64> <rank>" lines (cpp/src/Whisper.cpp:115-127) + base64 decode
+//     (cpp/src/base64.cpp:84-120), bounds-checked (fixes SURVEY B8)
+//   * a WAV reader with the reference's sample conventions (cpp/src/AudioFile.h:1241-1243:
+//     int16 -> /32768; ax_whisper_api.cpp:105-113: stereo -> (L+R)/2)
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace axw {
+
+// ------------------------------------------------------------------------------- JSON
+struct JsonValue {
+  enum Kind { Null, Bool, Number, String, Object, Array } kind = Null;
+  double num = 0;
+  bool b = false;
+  std::string str;
+  std::map<std::string, JsonValue> obj;
+  std::vector<JsonValue> arr;
+
+  bool has(const std::string& k) const { return kind == Object && obj.count(k); }
+  const JsonValue& at(const std::string& k) const {
+    auto it = obj.find(k);
+    if (kind != Object || it == obj.end()) throw std::runtime_error("json: missing key '" + k + "'");
+    return it->second;
+  }
+  long as_int() const {
+    if (kind == Number) return (long)num;
+    if (kind == String) return std::stol(str);
+    if (kind == Bool) return b;
+    throw std::runtime_error("json: not a number");
+  }
+  const std::string& as_str() const {
+    if (kind != String) throw std::runtime_error("json: not a string");
+    return str;
+  }
+};
+
+class JsonParser {
+ public:
+  explicit JsonParser(const std::string& s) : s_(s) {}
+  JsonValue parse() {
+    JsonValue v = value();
+    ws();
+    if (p_ != s_.size()) fail("trailing characters");
+    return v;
+  }
+
+ private:
+  const std::string& s_;
+  size_t p_ = 0;
+  [[noreturn]] void fail(const char* m) { throw std::runtime_error(std::string("json: ") + m + " at " + std::to_string(p_)); }
+  void ws() { while (p_ < s_.size() && (s_[p_] == ' ' || s_[p_] == '\n' || s_[p_] == '\t' || s_[p_] == '\r')) ++p_; }
+  char peek() { ws(); if (p_ >= s_.size()) fail("unexpected end"); return s_[p_]; }
+  JsonValue value() {
+    char c = peek();
+    JsonValue v;
+    if (c == '{') {
+      v.kind = JsonValue::Object; ++p_;
+      if (peek() == '}') { ++p_; return v; }
+      for (;;) {
+        if (peek() != '"') fail("expected key");
+        std::string k = string();
+        if (peek() != ':') fail("expected ':'");
+        ++p_;
+        v.obj[k] = value();
+        char d = peek(); ++p_;
+        if (d == '}') break;
+        if (d != ',') fail("expected ',' or '}'");
+      }
+    } else if (c == '[') {
+      v.kind = JsonValue::Array; ++p_;
+      if (peek() == ']') { ++p_; return v; }
+      for (;;) {
+        v.arr.push_back(value());
+        char d = peek(); ++p_;
+        if (d == ']') break;
+        if (d != ',') fail("expected ',' or ']'");
+      }
+    } else if (c == '"') {
+      v.kind = JsonValue::String; v.str = string();
+    } else if (c == 't' && s_.compare(p_, 4, "true") == 0) { v.kind = JsonValue::Bool; v.b = true; p_ += 4;
+    } else if (c == 'f' && s_.compare(p_, 5, "false") == 0) { v.kind = JsonValue::Bool; v.b = false; p_ += 5;
+    } else if (c == 'n' && s_.compare(p_, 4, "null") == 0) { p_ += 4;
+    } else {
+      size_t e = p_;
+      while (e < s_.size() && (isdigit((unsigned char)s_[e]) || strchr("+-.eE", s_[e]))) ++e;
+      if (e == p_) fail("unexpected character");
+      v.kind = JsonValue::Number; v.num = std::stod(s_.substr(p_, e - p_)); p_ = e;
+    }
+    return v;
+  }
+  std::string string() {
+    std::string out; ++p_;
+    while (p_ < s_.size() && s_[p_] != '"') {
+      char c = s_[p_++];
+      if (c == '\\') {
+        if (p_ >= s_.size()) fail("bad escape");
+        char e = s_[p_++];
+        switch (e) {
+          case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break;
+          case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+          case 'u': {
+            if (p_ + 4 > s_.size()) fail("bad \\u");
+            unsigned cp = (unsigned)std::stoul(s_.substr(p_, 4), nullptr, 16); p_ += 4;
+            if (cp < 0x80) out += (char)cp;
+            else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+            else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+            break;
+          }
+          default: out += e;
+        }
+      } else out += c;
+    }
+    if (p_ >= s_.size()) fail("unterminated string");
+    ++p_;
+    return out;
+  }
+};
+
+inline std::string read_text_file(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f.is_open()) throw std::runtime_error("cannot open " + path);
+  std::stringstream ss; ss << f.rdbuf();
+  return ss.str();
+}
+
+inline std::vector<std::string> split_csv(const std::string& s) {
+  std::vector<std::string> out; std::string cur;
+  for (char c : s) { if (c == ',') { out.push_back(cur); cur.clear(); } else cur += c; }
+  if (!s.empty()) out.push_back(cur);
+  return out;
+}
+
+// ------------------------------------------------------------------------------- safetensors
+struct TensorView {
+  std::string dtype;            // "BF16" | "F16" | "F32"
+  std::vector<int64_t> shape;
+  const uint8_t* data = nullptr;
+  size_t nbytes = 0;
+  int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+class SafeTensors {
+ public:
+  explicit SafeTensors(const std::string& path) {
+    fd_ = open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) throw std::runtime_error("cannot open weights file " + path);
+    struct stat st; fstat(fd_, &st); size_ = (size_t)st.st_size;
+    base_ = (const uint8_t*)mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+    if (base_ == MAP_FAILED) { close(fd_); throw std::runtime_error("mmap failed for " + path); }
+    if (size_ < 8) throw std::runtime_error("weights file too small");
+    uint64_t hl; memcpy(&hl, base_, 8);
+    if (8 + hl > size_) throw std::runtime_error("bad safetensors header length");
+    std::string hdr((const char*)base_ + 8, (size_t)hl);
+    JsonValue j = JsonParser(hdr).parse();
+    const uint8_t* data0 = base_ + 8 + hl;
+    for (auto& kv : j.obj) {
+      if (kv.first == "__metadata__") continue;
+      TensorView t;
+      t.dtype = kv.second.at("dtype").as_str();
+      for (auto& d : kv.second.at("shape").arr) t.shape.push_back(d.as_int());
+      auto& off = kv.second.at("data_offsets").arr;
+      size_t s = (size_t)off.at(0).as_int(), e = (size_t)off.at(1).as_int();
+      if (e < s || 8 + hl + e > size_) throw std::runtime_error("tensor '" + kv.first + "' out of file bounds");
+      t.data = data0 + s; t.nbytes = e - s;
+      size_t es = t.dtype == "F32" ? 4 : (t.dtype == "BF16" || t.dtype == "F16") ? 2 : 0;
+      if (!es) throw std::runtime_error("tensor '" + kv.first + "': unsupported dtype " + t.dtype);
+      if ((size_t)t.numel() * es != t.nbytes) throw std::runtime_error("tensor '" + kv.first + "': size mismatch");
+      tensors_[kv.first] = t;
+    }
+  }
+  ~SafeTensors() { if (base_ && base_ != MAP_FAILED) munmap((void*)base_, size_); if (fd_ >= 0) close(fd_); }
+  SafeTensors(const SafeTensors&) = delete;
+  bool has(const std::string& n) const { return tensors_.count(n) != 0; }
+  const TensorView& get(const std::string& n) const {
+    auto it = tensors_.find(n);
+    if (it == tensors_.end()) throw std::runtime_error("weights file lacks tensor '" + n + "'");
+    return it->second;
+  }
+
+ private:
+  int fd_ = -1; size_t size_ = 0; const uint8_t* base_ = nullptr;
+  std::map<std::string, TensorView> tensors_;
+};
+
+// ------------------------------------------------------------------------------- tokens
+inline bool base64_decode(const std::string& in, std::string& out) {
+  static int8_t map[256]; static bool init = false;
+  if (!init) {
+    memset(map, -1, sizeof(map));
+    const char* a = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    for (int i = 0; i < 64; ++i) map[(unsigned char)a[i]] = (int8_t)i;
+    init = true;
+  }
+  out.clear();
+  uint32_t acc = 0; int bits = 0;
+  for (unsigned char c : in) {
+    if (c == '=') break;
+    int v = map[c];
+    if (v < 0) return false;
+    acc = (acc << 6) | (uint32_t)v; bits += 6;
+    if (bits >= 8) { bits -= 8; out += (char)((acc >> bits) & 0xFF); }
+  }
+  return true;
+}
+
+// Decoded byte strings, index = rank (= line index). The reference keeps the base64 text and
+// decodes per token at run time (Whisper.cpp:224-229); decoding once at load is equivalent.
+inline std::vector<std::string> load_token_table(const std::string& path) {
+  std::ifstream f(path);
+  if (!f.is_open()) throw std::runtime_error("cannot open tokens file " + path);
+  std::vector<std::string> table; std::string line;
+  while (std::getline(f, line)) {
+    size_t i = line.find(' ');
+    std::string b64 = line.substr(0, i), bytes;
+    if (!base64_decode(b64, bytes)) throw std::runtime_error("bad base64 in tokens file line " + std::to_string(table.size()));
+    table.push_back(bytes);
+  }
+  return table;
+}
+
+// ------------------------------------------------------------------------------- WAV
+struct WavData { int sample_rate = 0; int channels = 0; std::vector<float> mono; };
+
+inline bool load_wav(const std::string& path, WavData& out, std::string& err) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f.is_open()) { err = "cannot open " + path; return false; }
+  std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  if (d.size() < 44 || memcmp(d.data(), "RIFF", 4) || memcmp(d.data() + 8, "WAVE", 4)) { err = "not a RIFF/WAVE file"; return false; }
+  auto u16 = [&](size_t o) { return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8); };
+  auto u32 = [&](size_t o) { return u16(o) | (u16(o + 2) << 16); };
+  size_t p = 12; int fmt = 0, ch = 0, bits = 0, rate = 0; size_t data_off = 0, data_len = 0;
+  while (p + 8 <= d.size()) {
+    uint32_t len = u32(p + 4);
+    if (!memcmp(d.data() + p, "fmt ", 4) && p + 8 + 16 <= d.size()) {
+      fmt = u16(p + 8); ch = u16(p + 10); rate = u32(p + 12); bits = u16(p + 22);
+      if (fmt == 0xFFFE && len >= 26) fmt = u16(p + 8 + 24);  // WAVE_FORMAT_EXTENSIBLE sub-format
+    } else if (!memcmp(d.data() + p, "data", 4)) {
+      data_off = p + 8; data_len = std::min<size_t>(len, d.size() - data_off); break;
+    }
+    p += 8 + len + (len & 1);
+  }
+  if (!data_off || ch < 1 || !(fmt == 1 || fmt == 3)) { err = "unsupported WAV (need PCM or IEEE float)"; return false; }
+  int bps = bits / 8;
+  if (!((fmt == 1 && (bps == 1 || bps == 2 || bps == 3 || bps == 4)) || (fmt == 3 && bps == 4))) { err = "unsupported bit depth"; return false; }
+  size_t frames = data_len / ((size_t)bps * ch);
+  out.sample_rate = rate; out.channels = ch; out.mono.resize(frames);
+  auto sample = [&](size_t frame, int c) -> float {
+    const uint8_t* s = d.data() + data_off + (frame * ch + c) * bps;
+    if (fmt == 3) { float v; memcpy(&v, s, 4); return v; }
+    if (bps == 1) return ((int)s[0] - 128) / 128.f;
+    if (bps == 2) { int16_t v; memcpy(&v, s, 2); return (float)v / 32768.f; }  // AudioFile.h:1241-1243
+    if (bps == 3) { int32_t v = (s[0] | (s[1] << 8) | (s[2] << 16)); if (v & 0x800000) v |= ~0xFFFFFF; return (float)v / 8388608.f; }
+    int32_t v; memcpy(&v, s, 4); return (float)((double)v / 2147483648.0);
+  };
+  for (size_t i = 0; i < frames; ++i)
+    out.mono[i] = (ch == 2) ? (sample(i, 0) + sample(i, 1)) / 2 : sample(i, 0);  // api.cpp:105-113
+  return true;
+}
+
+}  // namespace axw

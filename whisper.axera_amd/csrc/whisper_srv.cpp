@@ -1,0 +1,216 @@
+// whisper_srv.cpp — HTTP entry point, MI355X build.
+//
+// Keeps the reference server's contract (cpp/whisper_srv.cpp:10-70, cpp/src/WhisperHTTPServer.hpp:
+// 37-100): flags --port (8080), --model_type/-t, --model_path/-p, --language/-l; route POST /asr
+// with Content-Type application/octet-stream and a body of raw little-endian f32 PCM (16 kHz mono);
+// replies {"success": true, "text": ...}; 400 with the reference's error strings for a wrong
+// content type / empty body / size % 4 != 0 / failed run. Adds GET /health.
+//
+// What is new: the reference calls one non-re-entrant handle from cpp-httplib's thread pool with
+// no lock. Here connection threads only parse requests and enqueue them; ONE
+// batcher thread drains the queue into micro-batches (up to --max_batch clips, waiting at most
+// --batch_wait_ms for stragglers) and runs them through AX_WHISPER_RunPCMBatch, which is where the
+// GPU's utterance-level data parallelism comes from under concurrent load.
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <csignal>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <future>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ax_whisper_api.h"
+
+struct Job {
+  std::vector<float> pcm;
+  std::promise<std::pair<bool, std::string>> done;
+};
+
+static std::mutex g_mu;
+static std::condition_variable g_cv;
+static std::deque<Job*> g_queue;
+static std::atomic<bool> g_stop{false};
+
+static std::string json_escape(const std::string& s) {
+  std::string o;
+  for (unsigned char c : s) {
+    switch (c) {
+      case '"': o += "\\\""; break;
+      case '\\': o += "\\\\"; break;
+      case '\n': o += "\\n"; break;
+      case '\r': o += "\\r"; break;
+      case '\t': o += "\\t"; break;
+      default:
+        if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; }
+        else o += (char)c;
+    }
+  }
+  return o;
+}
+
+static void batcher(AX_WHISPER_HANDLE model, int max_batch, int wait_ms) {
+  while (!g_stop) {
+    std::vector<Job*> jobs;
+    {
+      std::unique_lock<std::mutex> lk(g_mu);
+      g_cv.wait(lk, [] { return g_stop || !g_queue.empty(); });
+      if (g_stop) break;
+      auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(wait_ms);
+      while ((int)g_queue.size() < max_batch && g_cv.wait_until(lk, deadline) != std::cv_status::timeout) {}
+      while (!g_queue.empty() && (int)jobs.size() < max_batch) { jobs.push_back(g_queue.front()); g_queue.pop_front(); }
+    }
+    const int n = (int)jobs.size();
+    std::vector<const float*> ptrs(n);
+    std::vector<int> lens(n);
+    std::vector<char*> texts(n, nullptr);
+    for (int i = 0; i < n; ++i) { ptrs[i] = jobs[i]->pcm.data(); lens[i] = (int)jobs[i]->pcm.size(); }
+    const int rc = AX_WHISPER_RunPCMBatch(model, ptrs.data(), lens.data(), n, texts.data());
+    for (int i = 0; i < n; ++i) {
+      jobs[i]->done.set_value({rc == 0 && texts[i], texts[i] ? std::string(texts[i]) : std::string()});
+      free(texts[i]);  // the reference never frees it (WhisperHTTPServer.hpp:77-90)
+    }
+  }
+}
+
+static void send_response(int fd, int status, const std::string& body) {
+  const char* reason = status == 200 ? "OK" : status == 400 ? "Bad Request" : status == 404 ? "Not Found" : "Internal Server Error";
+  std::string h = "HTTP/1.1 " + std::to_string(status) + " " + reason +
+                  "\r\nContent-Type: application/json\r\nContent-Length: " + std::to_string(body.size()) +
+                  "\r\nAccess-Control-Allow-Origin: *\r\nAccess-Control-Allow-Methods: POST, GET, OPTIONS\r\n"
+                  "Access-Control-Allow-Headers: Content-Type, X-Array-Name, X-Array-Description, X-Array-Size\r\n"
+                  "Connection: close\r\n\r\n";
+  std::string out = h + body;
+  size_t off = 0;
+  while (off < out.size()) {
+    ssize_t w = send(fd, out.data() + off, out.size() - off, MSG_NOSIGNAL);
+    if (w <= 0) break;
+    off += (size_t)w;
+  }
+}
+
+static std::string lower(std::string s) { std::transform(s.begin(), s.end(), s.begin(), ::tolower); return s; }
+
+static void serve(int fd) {
+  std::string buf;
+  char tmp[65536];
+  size_t hdr_end = std::string::npos;
+  while (hdr_end == std::string::npos && buf.size() < (1u << 20)) {
+    ssize_t r = recv(fd, tmp, sizeof tmp, 0);
+    if (r <= 0) { close(fd); return; }
+    buf.append(tmp, (size_t)r);
+    hdr_end = buf.find("\r\n\r\n");
+  }
+  if (hdr_end == std::string::npos) { close(fd); return; }
+  const std::string head = buf.substr(0, hdr_end);
+  const std::string lhead = lower(head);
+  const std::string first = head.substr(0, head.find("\r\n"));
+  size_t clen = 0;
+  size_t p = lhead.find("content-length:");
+  if (p != std::string::npos) clen = strtoul(lhead.c_str() + p + 15, nullptr, 10);
+  if (lhead.find("expect: 100-continue") != std::string::npos) {
+    const char* c = "HTTP/1.1 100 Continue\r\n\r\n";
+    (void)!send(fd, c, strlen(c), MSG_NOSIGNAL);
+  }
+  std::string body = buf.substr(hdr_end + 4);
+  while (body.size() < clen && clen <= (1u << 30)) {
+    ssize_t r = recv(fd, tmp, sizeof tmp, 0);
+    if (r <= 0) break;
+    body.append(tmp, (size_t)r);
+  }
+  if (first.rfind("GET /health", 0) == 0) {
+    send_response(fd, 200, R"({"status": "ok"})");
+  } else if (first.rfind("OPTIONS ", 0) == 0) {
+    send_response(fd, 200, "{}");
+  } else if (first.rfind("POST /asr", 0) != 0) {
+    send_response(fd, 404, R"({"error": "Not found"})");
+  } else {
+    size_t ct = lhead.find("content-type:");
+    size_t ct_end = ct == std::string::npos ? ct : lhead.find("\r\n", ct);
+    std::string ctv = ct == std::string::npos ? "" : lhead.substr(ct, ct_end == std::string::npos ? std::string::npos : ct_end - ct);
+    if (ctv.find("application/octet-stream") == std::string::npos) {                       // hpp:50-55
+      send_response(fd, 400, R"({"error": "Content-Type must be application/octet-stream"})");
+    } else if (body.empty()) {                                                               // hpp:58-62
+      send_response(fd, 400, R"({"error": "Request body is empty"})");
+    } else if (body.size() % sizeof(float) != 0) {                                           // hpp:65-71
+      send_response(fd, 400, R"({"error": "Data size must be multiple of 4 bytes"})");
+    } else {
+      Job job;
+      job.pcm.resize(body.size() / sizeof(float));
+      memcpy(job.pcm.data(), body.data(), body.size());                                      // hpp:103-113
+      auto fut = job.done.get_future();
+      { std::lock_guard<std::mutex> lk(g_mu); g_queue.push_back(&job); }
+      g_cv.notify_all();
+      auto res = fut.get();
+      if (!res.first) send_response(fd, 400, R"({"error": "Run model failed!"})");           // hpp:79-83
+      else send_response(fd, 200, "{\n  \"success\": true,\n  \"text\": \"" + json_escape(res.second) + "\"\n}");  // hpp:86-90
+    }
+  }
+  shutdown(fd, SHUT_RDWR);
+  close(fd);
+}
+
+int main(int argc, char** argv) {
+  int port = 8080, max_batch = 16, wait_ms = 5;
+  std::string model_type = "turbo", model_path = "../models-mi355x", language = "zh";
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    auto val = [&](const char* lng, const char* sht, std::string& dst) -> bool {
+      std::string l = std::string("--") + lng;
+      if (a.rfind(l + "=", 0) == 0) { dst = a.substr(l.size() + 1); return true; }
+      if ((a == l || (sht && a == sht)) && i + 1 < argc) { dst = argv[++i]; return true; }
+      return false;
+    };
+    std::string v;
+    if (val("port", nullptr, v)) { port = atoi(v.c_str()); continue; }
+    if (val("max_batch", nullptr, v)) { max_batch = std::max(1, atoi(v.c_str())); continue; }
+    if (val("batch_wait_ms", nullptr, v)) { wait_ms = std::max(0, atoi(v.c_str())); continue; }
+    if (val("model_type", "-t", model_type) || val("model_path", "-p", model_path) || val("language", "-l", language)) continue;
+    fprintf(stderr, "usage: %s [--port 8080] [-t model_type] [-p model_path] [-l language] [--max_batch 16] [--batch_wait_ms 5]\n", argv[0]);
+    return a == "--help" || a == "-?" ? 0 : 1;
+  }
+  printf("port: %d\n", port);
+  printf("model_path: %s\n", model_path.c_str());
+  printf("model_type: %s\n", model_type.c_str());
+  printf("language: %s\n", language.c_str());
+
+  AX_WHISPER_HANDLE model = AX_WHISPER_InitEx(model_type.c_str(), model_path.c_str(), language.c_str(), -1, max_batch);
+  if (!model) { printf("init server failed!\n"); return -1; }
+
+  int srv = socket(AF_INET, SOCK_STREAM, 0);
+  int one = 1;
+  setsockopt(srv, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+  sockaddr_in addr{};
+  addr.sin_family = AF_INET;
+  addr.sin_addr.s_addr = htonl(INADDR_ANY);  // the reference listens on 0.0.0.0 (hpp:33)
+  addr.sin_port = htons((uint16_t)port);
+  if (bind(srv, (sockaddr*)&addr, sizeof addr) != 0 || listen(srv, 128) != 0) { perror("bind/listen"); return -1; }
+  printf("Start server at port %d, POST binary stream to IP:%d/asr\n", port, port);
+  fflush(stdout);
+
+  std::thread bt(batcher, model, max_batch, wait_ms);
+  signal(SIGPIPE, SIG_IGN);
+  for (;;) {
+    int fd = accept(srv, nullptr, nullptr);
+    if (fd < 0) break;
+    setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+    std::thread(serve, fd).detach();
+  }
+  g_stop = true;
+  g_cv.notify_all();
+  bt.join();
+  AX_WHISPER_Uninit(model);
+  return 0;
+}
