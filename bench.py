@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X Whisper hot path (BASELINE.json: RTF on a 30 s clip + clips/s).
+
+A "step" is one pass of the whole hot path over one batch of synthetic 30 s clips that are already
+resident in HBM: log-mel front-end -> encoder -> greedy decode (4 SOT steps + up to 444 tokens; with
+synthetic weights eot practically never wins, so every clip runs the full 448-step context) -> ids.
+Default workload = BASELINE.json configs[1]: Whisper-small bf16, 1 GPU, batch 1.
+
+    python bench.py                                  # N=1, batch 1
+    python bench.py --batch 64                       # configs[2]
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8   # one rank per GPU, weak scaling
+
+Prints ONE JSON line (rank 0). `roofline` is for the dominant kernel family of the decode loop,
+`cpu_baseline` is the CPU oracle ("port") timed on this box's host cores on one clip of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "whisper.axera_amd", "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def decode_step_bytes(dims, batch, step, s=2):
+    """weights once per step + cross-KV + self-KV per clip, element size s (bf16)."""
+    d, L, nv = dims["d"], dims["dec_layers"], dims["n_vocab"]
+    weights = s * (L * 14 * d * d + nv * d)
+    cross = batch * s * 2 * L * 1500 * d
+    self_kv = batch * s * 2 * L * (step + 1) * d
+    return weights, cross, self_kv
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1, help="clips per GPU (weak scaling)")
+    ap.add_argument("--model", default="small")
+    ap.add_argument("--max-new", type=int, default=0, help="0 = until eot or context (444 ids)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model-dir", default=os.environ.get("AXW_BENCH_MODEL_DIR", "/tmp/axw_bench_models"))
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import modelgen
+    import whisper_axera_amd as wa
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    # ---- synthetic-weight model directory (no weights exist in the reference or this image)
+    dims = modelgen.DIMS[args.model]
+    mdir = os.path.join(args.model_dir, args.model)
+    if local_rank == 0 and not os.path.exists(os.path.join(mdir, f"{args.model}.safetensors")):
+        modelgen.write_model_dir(args.model_dir, args.model, dims, seed=0,
+                                 tiktoken_path=os.path.join(ROOT, "tests", "golden", "multilingual.tiktoken"))
+    barrier()
+
+    B = args.batch
+    eng = wa.Whisper(args.model, args.model_dir, "zh", device=local_rank, max_batch=B)
+    stream = torch.cuda.current_stream(dev)
+    eng.set_stream(stream.cuda_stream)
+
+    n_samp = 480000
+    clips = np.stack([modelgen.synth_clip(rank * B + i, n_samp) for i in range(B)])
+    d_pcm = torch.from_numpy(clips).to(dev)
+    torch.cuda.synchronize(dev)
+
+    def one_step():
+        ids = eng.run_device_tokens(d_pcm.data_ptr(), n_samp, [n_samp] * B, max_new=args.max_new)
+        if world > 1:  # result gather over RCCL/xGMI: fixed-shape ids + lengths
+            t = torch.zeros((B, 449), dtype=torch.int32, device=dev)
+            for b, row in enumerate(ids):
+                t[b, 0] = len(row)
+                if row:
+                    t[b, 1 : 1 + len(row)] = torch.tensor(row, dtype=torch.int32)
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+        return ids
+
+    for _ in range(args.warmup):
+        ids = one_step()
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    stage = {"frontend_ms": 0.0, "encoder_ms": 0.0, "decode_ms": 0.0, "steps": 0}
+    for _ in range(args.steps):
+        ids = one_step()
+        tm = eng.timings()
+        for k in stage:
+            stage[k] += tm[k]
+    torch.cuda.synchronize(dev)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    clips_per_s = world * B * args.steps / dt
+    n_tok = float(np.mean([len(r) for r in ids]))
+    dec_steps = stage["steps"] / args.steps
+
+    # ---- roofline of the dominant kernel family: the decode step's weight-streaming GEMV launches
+    # (gemv_kernel<...>): algorithmic bytes per decode step = bf16 decoder weights (each read exactly once
+    # per step) / launches per step; duration measured with hipEvents on the engine's stream.
+    iters = 50
+    w_bytes, c_bytes, s_bytes = decode_step_bytes(dims, B, 224)
+    n_gemv = dims["dec_layers"] * 6 + 1
+    n_tiles = (B + 3) // 4
+    ms_gemv = eng.bench("decode_gemv", B, 224, iters)
+    per_launch_s = ms_gemv * 1e-3 / (iters * n_gemv * n_tiles)
+    gemv_gbs = (w_bytes / n_gemv) / per_launch_s / 1e9 / n_tiles
+    ms_step = eng.bench("decode_step", B, 224, iters) / iters
+    step_gbs = (w_bytes + c_bytes + s_bytes) / (ms_step * 1e-3) / 1e9
+    roofline = {"kernel": "gemv_kernel (decode weight GEMV, all shapes)", "bound": "hbm", "achieved": round(gemv_gbs, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gemv_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "launches_per_decode_step": n_gemv * n_tiles, "avg_launch_us": round(per_launch_s * 1e6, 3),
+                "bytes_per_launch": int(w_bytes / n_gemv),
+                "decode_step": {"ms": round(ms_step, 4), "algorithmic_GBs": round(step_gbs, 1),
+                                "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4)}}
+
+    out = {
+        "metric": "clips_per_sec (30 s clips, greedy decode, whisper-%s)" % args.model,
+        "value": round(clips_per_s, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"whisper-{args.model} bf16, batch {B}/GPU, 30 s synthetic 16 kHz clips resident in HBM, "
+                               f"greedy decode {n_tok:.0f} ids/clip ({dec_steps:.0f} decoder steps)",
+                   "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}", "weights": "seeded synthetic"},
+        "rtf": round(dt / args.steps / (B * 30.0), 6),
+        "stage_ms": {k: round(v / args.steps, 3) for k, v in stage.items() if k != "steps"},
+        "roofline": roofline,
+    }
+
+    # ---- CPU baseline: the oracle ("port") on this box's host cores, one clip of the same workload
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle
+
+        threads = min(os.cpu_count() or 1, 32)
+        weights = modelgen.read_safetensors(os.path.join(mdir, f"{args.model}.safetensors"))
+        orc = oracle.Oracle(modelgen.make_config(args.model, dims), weights, bf16_policy=True, threads=threads)
+        max_new = args.max_new if args.max_new > 0 else 444
+        cpu_new = min(max_new, 96)  # bounded sample: full front-end + encoder, 4 + 96 decoder steps
+        t1 = time.perf_counter()
+        cpu_ids = orc.transcribe(clips[0], "zh", max_new=cpu_new)
+        t_cpu = time.perf_counter() - t1
+        # scale the decode part to the GPU's step count: measure encoder and decode separately
+        t2 = time.perf_counter()
+        mel, _, _ = oracle.log_mel(clips[0], dims["n_mels"])
+        ck, cv = orc.encoder(mel)
+        t_enc = time.perf_counter() - t2
+        t_dec_step = max(t_cpu - t_enc, 1e-9) / (4 + len(cpu_ids))
+        t_full = t_enc + t_dec_step * dec_steps
+        agree = 0
+        for a, b in zip(cpu_ids, ids[0]):
+            if a != b:
+                break
+            agree += 1
+        out["cpu_baseline"] = {"value": round(1.0 / t_full, 5), "unit": "clips/s", "cores": threads, "kind": "port",
+                               "sample": f"clip 0: front-end + encoder measured ({t_enc:.2f} s) + {4 + len(cpu_ids)} decoder "
+                                         f"steps measured ({t_dec_step * 1e3:.1f} ms/step) scaled to {dec_steps:.0f} steps; "
+                                         f"CPU oracle (bf16 policy), {threads} OpenMP threads of {os.cpu_count()}",
+                               "ids_agree_prefix": f"{agree}/{len(cpu_ids)}"}
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,6 +70,8 @@ def lib():
         L.orc_argmax.argtypes = [fp, C.c_int]
         L.orc_set_threads.argtypes = [C.c_int]
         L.orc_clear_cache.argtypes = []
+        # libgomp with hundreds of threads makes the many tiny parallel regions of the decoder crawl
+        L.orc_set_threads(min(os.cpu_count() or 1, 16))
         _LIB = L
     return _LIB
 

@@ -12,6 +12,7 @@ import os
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (imported before libax_whisper.so so both share torch's HIP runtime in this process)
 
 from conftest import GOLDEN, ModelCase, load_demo_pcm
 

@@ -156,6 +156,7 @@ struct AdvanceParams {
   const int* sot;             // device [4]
   const int* forced; int n_forced;   // teacher forcing (device [B][n_forced]) or nullptr
   int* argmax_dump;           // optional [B][n_forced+1]
+  const bf16* tok_emb; const float* pos; float* x; int d_model;  // fused embedding of the next step
 };
 void launch_advance(const AdvanceParams& p, hipStream_t s);
 

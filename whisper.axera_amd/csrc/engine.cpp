@@ -53,8 +53,7 @@ Engine::Engine(const std::string& model_type, const std::string& model_path, con
 Engine::~Engine() {
   (void)hipSetDevice(device_);
   (void)hipDeviceSynchronize();
-  for (auto& g : graphs_) (void)hipGraphExecDestroy(g.second);
-  free_slot_buffers();
+  free_slot_buffers();  // also destroys the captured step graphs
   for (void* p : allocs_) (void)hipFree(p);
   if (h_poll_) (void)hipHostFree(h_poll_);
   for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
@@ -456,6 +455,8 @@ void Engine::reset_decode_state(int batch) {
   HIP_CHECK(hipMemsetAsync(d_nout_, 0, (size_t)batch * 4, s));
   std::vector<int> t0(batch, sot_seq_[0]);
   HIP_CHECK(hipMemcpyAsync(d_tok_, t0.data(), (size_t)batch * 4, hipMemcpyHostToDevice, s));
+  // x of step 0; every later step's embedding is produced by the previous step's advance kernel
+  launch_embed(tok_emb_, dec_pos_, d_tok_, d_state_, d_xdec_, batch, cfg_.n_text_state, s);
   HIP_CHECK(hipStreamSynchronize(s));
 }
 
@@ -464,7 +465,6 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
                                  long logits_stride, int* d_argmax) {
   const int d = cfg_.n_text_state, H = cfg_.n_text_head, L = cfg_.n_text_layer, Tc = cfg_.n_text_ctx;
   hipStream_t s = stream();
-  launch_embed(tok_emb_, dec_pos_, d_tok_, d_state_, d_xdec_, batch, d, s);
 
   // the VALU GEMV handles <= 4 clips per launch; tile the batch
   auto gemv = [&](GemvParams p, auto&& offset) {
@@ -472,19 +472,20 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
       GemvParams q = p;
       q.batch = std::min(4, batch - b0);
       offset(q, b0);
-      launch_gemv(q, s);
+      if (step_mask_ & 1) launch_gemv(q, s);
     }
   };
   auto attn = [&](const bf16* kc, const bf16* vc, long stride, int n_keys, int cap_blocks, float* part, int n_split) {
     DecAttnParams a{};
     a.q = d_qdec_; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = part; a.n_split = n_split;
     a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
-    launch_decode_attention(a, s);
+    if (step_mask_ & 2) launch_decode_attention(a, s);
   };
 
   const long self_stride = (long)H * Tc * 64, cross_stride = (long)H * t_pad_ * 64;
   for (int l = 0; l < L; ++l) {
-    const DecLayerW& w = dec_[l];
+    static const bool dbg_same = getenv("AXW_DEBUG_SAME_LAYER_WEIGHTS") != nullptr;  // timing experiment only
+    const DecLayerW& w = dec_[dbg_same ? 0 : l];
     bf16* sk = d_self_k_ + (size_t)l * cap_ * self_stride;
     bf16* sv = d_self_v_ + (size_t)l * cap_ * self_stride;
     const bf16* ck = d_cross_k_ + (size_t)l * cap_ * cross_stride;
@@ -542,11 +543,12 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
   a.state = d_state_; a.tok = d_tok_; a.done = d_done_; a.n_out = d_nout_; a.out_ids = d_out_ids_; a.batch = batch;
   a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.sot = d_sot_;
   a.forced = d_forced; a.n_forced = n_forced; a.argmax_dump = d_argmax;
-  launch_advance(a, s);
+  a.tok_emb = tok_emb_; a.pos = dec_pos_; a.x = d_xdec_; a.d_model = d;
+  if (step_mask_ & 4) launch_advance(a, s);
 }
 
 hipGraphExec_t Engine::step_graph(int batch, int max_new) {
-  const long key = (long)batch * 1024 + max_new;
+  const long key = ((long)batch * 1024 + max_new) * 8 + step_mask_;
   auto it = graphs_.find(key);
   if (it != graphs_.end()) return it->second;
   hipStream_t s = stream();
@@ -724,7 +726,10 @@ float Engine::bench(const std::string& what, int batch, int arg, int iters) {
   HIP_CHECK(hipEventCreate(&a));
   HIP_CHECK(hipEventCreate(&b));
   float ms = 0.f;
-  if (what == "decode_step") {
+  if (what == "decode_step" || what == "decode_gemv" || what == "decode_attn") {
+    // decode_gemv / decode_attn: the same captured step with only the GEMV / only the attention launches
+    step_mask_ = what == "decode_step" ? 7 : (what == "decode_gemv" ? 1 : 2);
+    struct Restore { int& m; ~Restore() { m = 7; } } restore{step_mask_};
     const int Tc = cfg_.n_text_ctx;
     reset_decode_state(batch);
     hipGraphExec_t g = step_graph(batch, Tc - 4);

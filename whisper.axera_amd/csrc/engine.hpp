@@ -109,6 +109,7 @@ class Engine {
   DecState* d_state_ = nullptr;
   int* h_poll_ = nullptr;  // pinned
   int split_self_ = 2, split_cross_ = 6;
+  int step_mask_ = 7;  // bench only: 1 GEMV launches, 2 attention launches, 4 embed + advance
   std::map<long, hipGraphExec_t> graphs_;  // key: batch * 1024 + max_new
   hipEvent_t ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
