@@ -87,16 +87,12 @@ def main():
     d_pcm = torch.from_numpy(clips).to(dev)
     torch.cuda.synchronize(dev)
 
+    from whisper_axera_amd import dp
+
     def one_step():
         ids = eng.run_device_tokens(d_pcm.data_ptr(), n_samp, [n_samp] * B, max_new=args.max_new)
-        if world > 1:  # result gather over RCCL/xGMI: fixed-shape ids + lengths
-            t = torch.zeros((B, 449), dtype=torch.int32, device=dev)
-            for b, row in enumerate(ids):
-                t[b, 0] = len(row)
-                if row:
-                    t[b, 1 : 1 + len(row)] = torch.tensor(row, dtype=torch.int32)
-            out = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(out, t)
+        if world > 1:  # the ONE collective of the path: result gather over RCCL/xGMI
+            dp.gather_ids(ids, B, device=dev)
         return ids
 
     for _ in range(args.warmup):
@@ -123,24 +119,38 @@ def main():
     n_tok = float(np.mean([len(r) for r in ids]))
     dec_steps = stage["steps"] / args.steps
 
-    # ---- roofline of the dominant kernel family: the decode step's weight-streaming GEMV launches
-    # (gemv_kernel<...>): algorithmic bytes per decode step = bf16 decoder weights (each read exactly once
-    # per step) / launches per step; duration measured with hipEvents on the engine's stream.
+    # ---- roofline of the dominant kernel family of the timed region: the decode loop's weight-streaming
+    # linear layers (gemv_kernel<..> for <= 4 clips, decode_gemm_kernel<..> beyond; ~2/3 of the GPU time in
+    # profiles/). Algorithmic bytes per decode step for that family = the bf16 decoder weights, each read exactly
+    # once per step for the whole batch (s*[L*14*d^2 + n_vocab*d]); per launch = that / launches per
+    # step. Duration: hipEvents on the engine's stream around `iters` replays of a step graph that holds ONLY
+    # that family's launches.
     iters = 50
     w_bytes, c_bytes, s_bytes = decode_step_bytes(dims, B, 224)
-    n_gemv = dims["dec_layers"] * 6 + 1
-    n_tiles = (B + 3) // 4
-    ms_gemv = eng.bench("decode_gemv", B, 224, iters)
-    per_launch_s = ms_gemv * 1e-3 / (iters * n_gemv * n_tiles)
-    gemv_gbs = (w_bytes / n_gemv) / per_launch_s / 1e9 / n_tiles
+    small_batch = B <= 4
+    n_launch = (dims["dec_layers"] * 6 + 1) * ((B + 3) // 4 if small_batch else (B + 63) // 64)
+    ms_fam = eng.bench("decode_gemv", B, 224, iters)
+    per_launch_s = ms_fam * 1e-3 / (iters * n_launch)
+    fam_gbs = (w_bytes / n_launch) / per_launch_s / 1e9
     ms_step = eng.bench("decode_step", B, 224, iters) / iters
+    ms_attn = eng.bench("decode_attn", B, 224, iters) / iters
     step_gbs = (w_bytes + c_bytes + s_bytes) / (ms_step * 1e-3) / 1e9
-    roofline = {"kernel": "gemv_kernel (decode weight GEMV, all shapes)", "bound": "hbm", "achieved": round(gemv_gbs, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gemv_gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                "launches_per_decode_step": n_gemv * n_tiles, "avg_launch_us": round(per_launch_s * 1e6, 3),
-                "bytes_per_launch": int(w_bytes / n_gemv),
+    attn_gbs = (c_bytes + s_bytes) / (ms_attn * 1e-3) / 1e9
+    fam = "gemv_kernel" if small_batch else "decode_gemm_kernel"
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc_path):  # HBM bytes per launch from rocprofv3 --pmc passes (recipe in profiles/README.md)
+        rec = json.load(open(pmc_path)).get(f"{args.model}_b{B}", {}).get(fam)
+        if rec:
+            traffic = rec["hbm_bytes_per_launch"]
+    roofline = {"kernel": f"{fam} (decode linear layers, all shapes)", "bound": "hbm", "achieved": round(fam_gbs, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fam_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "launches_per_decode_step": n_launch, "avg_launch_us": round(per_launch_s * 1e6, 3),
+                "bytes_per_launch": int(w_bytes / n_launch),
                 "decode_step": {"ms": round(ms_step, 4), "algorithmic_GBs": round(step_gbs, 1),
-                                "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4)}}
+                                "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
+                "decode_attention": {"ms_per_step": round(ms_attn, 4), "algorithmic_GBs": round(attn_gbs, 1),
+                                     "frac_of_hbm_peak": round(attn_gbs / HBM_PEAK_GBS, 4)}}
 
     out = {
         "metric": "clips_per_sec (30 s clips, greedy decode, whisper-%s)" % args.model,

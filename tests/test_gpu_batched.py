@@ -1,0 +1,90 @@
+"""GPU: the batched decode path (5+ clips: bf16-pair activations on the matrix cores, one attention workgroup per
+(clip, head)) against the oracle and against the small-batch path, at batch sizes that exercise 1, 2 and 4
+clip blocks of 16 and a ragged last block."""
+import numpy as np
+import pytest
+import torch  # noqa: F401  (before libax_whisper.so: one HIP runtime per process)
+
+from conftest import load_demo_pcm
+
+pytestmark = pytest.mark.gpu
+
+
+def _mels(n):
+    from make_model_goldens_inputs import demo_mel, synth_mel
+
+    out = [demo_mel(80)]
+    for i in range(1, n):
+        out.append(synth_mel(100 + i, 80, 3000 if i % 3 else 1000 + 37 * i))
+    return out
+
+
+@pytest.fixture(scope="module")
+def engine(built_lib, micro_case):
+    e = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=50)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("B", [5, 16, 21, 50])
+def test_batched_teacher_forced_logits_vs_oracle(engine, micro_case, B):
+    mels = _mels(B)
+    engine.encode_mel(np.stack(mels))
+    n_forced = 10
+    check = sorted(set([0, 1, B // 2, B - 1]))
+    forced = np.zeros((B, n_forced), dtype=np.int32)
+    refs = {}
+    for b in check:
+        ck, cv = micro_case.oracle_bf16.encoder(mels[b])
+        ids = micro_case.oracle_bf16.greedy(ck, cv, "zh", max_new=n_forced)
+        ids = (ids + [0] * n_forced)[:n_forced]
+        _, lg = micro_case.oracle_bf16.greedy(ck, cv, "zh", max_new=n_forced, forced=ids, want_logits=True)
+        forced[b] = ids
+        refs[b] = lg
+    for b in range(B):
+        if b not in refs:
+            forced[b] = forced[check[0]]
+    logits, am = engine.decode_forced(B, forced)
+    for b in check:
+        err = np.abs(logits[b] - refs[b]).max(axis=1)
+        print(f"B={B} clip {b}: logits err {err.max():.3e}")
+        assert err.max() < 2e-2
+        srt = np.sort(refs[b], axis=1)
+        margin = srt[:, -1] - srt[:, -2]
+        for s in range(refs[b].shape[0]):
+            assert am[b, s] == int(refs[b][s].argmax()) or margin[s] < 2 * err[s]
+
+
+def test_batched_and_single_paths_agree(engine):
+    """The same clip through the 1-clip GEMV path and inside a 7-clip MFMA batch: logits within 1e-3, same ids."""
+    mels = _mels(7)
+    engine.encode_mel(np.stack(mels))
+    forced = np.tile(np.arange(10, 18, dtype=np.int32), (7, 1))
+    lg_b, am_b = engine.decode_forced(7, forced)
+    for b in (0, 3, 6):
+        engine.encode_mel(mels[b])
+        lg_1, am_1 = engine.decode_forced(1, forced[:1])
+        err = np.abs(lg_b[b] - lg_1[0]).max()
+        print("clip", b, "batched vs single logits diff", err)
+        assert err < 1e-3
+        srt = np.sort(lg_1[0], axis=1)
+        for s in range(lg_1.shape[1]):
+            assert am_b[b, s] == am_1[0, s] or srt[s, -1] - srt[s, -2] < 2e-3
+
+
+def test_batched_greedy_end_to_end(engine, micro_case):
+    import modelgen
+
+    clips = [load_demo_pcm()] + [modelgen.synth_clip(i, 480000 if i % 2 else 160000 + 1000 * i) for i in range(1, 9)]
+    got = engine.run_tokens_batch(clips, max_new=12)
+    assert len(got) == 9 and all(len(g) == 12 for g in got)
+    import oracle
+
+    for b in (0, 4, 8):
+        mel, _, _ = oracle.log_mel(clips[b], 80)
+        ck, cv = micro_case.oracle_bf16.encoder(mel)
+        ids, lg = micro_case.oracle_bf16.greedy(ck, cv, "zh", max_new=12, want_logits=True)
+        if got[b] != ids:
+            i = next(i for i in range(12) if ids[i] != got[b][i])
+            srt = np.sort(lg[i])
+            assert srt[-1] - srt[-2] < 4e-2, (b, i, ids, got[b])

@@ -146,8 +146,28 @@ struct DecAttnParams {
   int n_keys;                 // fixed key count (cross) or -1: state->step + 1 (self)
   int cap_blocks;             // allocated 64-key blocks per (slot, head): 24 cross, 7 self
   const DecState* state;
+  bf16* out_hi; bf16* out_lo; // n_split == 1 only: write the normalised output as a bf16 pair [B][d] instead of partials
 };
 void launch_decode_attention(const DecAttnParams& p, hipStream_t s);
+
+// ---- batched decode (5..64 clips per launch): activations as bf16 (hi, lo) pairs, MFMA GEMM (decode_gemm.hip)
+struct DecGemmParams {
+  const bf16* W; const float* bias; int N, K, batch;
+  const bf16* a_hi; const bf16* a_lo;      // [batch][K]
+  int epilogue;                            // GemvEpilogue
+  int rt;                                  // weight-row tiles per wave: 1 (16 rows/WG) or 4 (64 rows/WG, vocabulary)
+  float* out;                              // fp32 [batch][N] (STORE / RESID / q of QKV_CACHE)
+  bf16* out_hi; bf16* out_lo;              // GEPI_GELU: bf16 pair [batch][N]
+  bf16* k_cache; bf16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;
+  const DecState* state;
+  float* amax_val; int* amax_idx; int amax_stride;
+  float* logits_dump; long logits_dump_stride;
+  int skip_before_step;
+};
+void launch_decode_gemm(const DecGemmParams& p, hipStream_t s);
+int decode_gemm_grid(int N, int rt);
+void launch_act_prep(const float* x, const float* g, const float* be, bf16* hi, bf16* lo, int batch, int K, bool do_ln,
+                     hipStream_t s);
 
 struct AdvanceParams {
   const float* amax_val; const int* amax_idx; int n_part; int amax_stride;

@@ -320,57 +320,69 @@ void launch_gemv(const GemvParams& p, hipStream_t s) {
 // ------------------------------------------------------------------------------- advance
 // Whisper.cpp:207-222: steps 0..2 feed the next SOT token and drop the logits; from step 3 on the
 // argmax is either the stop condition (eot / context full) or the next recorded + fed token.
-// One wave per clip merges the per-workgroup argmax partials (first max wins).
+// One wave per clip merges the per-workgroup argmax partials (first max wins); 16 clips per workgroup. The step
+// counter is advanced by whichever workgroup finishes last (ticket in state->pad0), i.e. after every
+// workgroup has read it.
 __global__ __launch_bounds__(1024) void advance_kernel(AdvanceParams p) {
   const int s = p.state->step;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int b = wave; b < p.batch; b += 16) {
+  const int b = blockIdx.x * 16 + wave;
+  if (b < p.batch) {
+    int tok = 0;
     if (s < 3) {
-      if (lane == 0) p.tok[b] = p.sot[s + 1];
-      continue;
-    }
-    float v = -INFINITY;
-    int idx = 0x7fffffff;
-    for (int i = lane; i < p.n_part; i += 64) {
-      const float ov = p.amax_val[(long)i * p.amax_stride + b];
-      const int oi = p.amax_idx[(long)i * p.amax_stride + b];
-      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+      tok = p.sot[s + 1];
+      if (lane == 0) p.tok[b] = tok;
+    } else {
+      float v = -INFINITY;
+      int idx = 0x7fffffff;
+#pragma unroll 4
+      for (int i = lane; i < p.n_part; i += 64) {
+        const float ov = p.amax_val[(long)i * p.amax_stride + b];
+        const int oi = p.amax_idx[(long)i * p.amax_stride + b];
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+      }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(v, o, 64);
-      const int oi = __shfl_xor(idx, o, 64);
-      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
-    if (lane != 0) continue;
-    const int gi = s - 3;
-    if (p.argmax_dump && gi <= p.n_forced) p.argmax_dump[(long)b * (p.n_forced + 1) + gi] = idx;
-    if (p.forced) {
-      if (gi < p.n_forced) p.tok[b] = p.forced[(long)b * p.n_forced + gi];
-    } else if (!p.done[b]) {
-      if (idx == p.eot || s + 1 >= p.n_ctx || p.n_out[b] >= p.max_new) {
-        p.done[b] = 1;
-        atomicAdd(&p.state->n_done, 1);
-      } else {
-        p.out_ids[(long)b * p.n_ctx + p.n_out[b]] = idx;
-        p.n_out[b] += 1;
-        p.tok[b] = idx;
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+      }
+      tok = p.tok[b];
+      const int gi = s - 3;
+      if (p.forced) {
+        if (gi < p.n_forced) tok = p.forced[(long)b * p.n_forced + gi];
+      } else if (!p.done[b]) {
+        const int n_out = p.n_out[b];
+        if (idx == p.eot || s + 1 >= p.n_ctx || n_out >= p.max_new) {
+          if (lane == 0) { p.done[b] = 1; atomicAdd(&p.state->n_done, 1); }
+        } else {
+          if (lane == 0) { p.out_ids[(long)b * p.n_ctx + n_out] = idx; p.n_out[b] = n_out + 1; }
+          tok = idx;
+        }
+      }
+      if (lane == 0) {
+        if (p.argmax_dump && gi <= p.n_forced) p.argmax_dump[(long)b * (p.n_forced + 1) + gi] = idx;
+        p.tok[b] = tok;
       }
     }
-  }
-  // fused embedding of the NEXT step: x = tok_emb[token] + pos[step + 1]   (export_onnx.py:334-336);
-  // each wave only re-reads the tokens it wrote itself
-  __syncthreads();
-  if (s + 1 < p.n_ctx) {
-    for (int b = wave; b < p.batch; b += 16) {
-      const int t = p.tok[b];
+    // fused embedding of the NEXT step: x = tok_emb[token] + pos[step + 1]   (export_onnx.py:334-336)
+    if (s + 1 < p.n_ctx) {
       for (int c = lane; c < p.d_model; c += 64)
-        p.x[(long)b * p.d_model + c] = (float)p.tok_emb[(long)t * p.d_model + c] + p.pos[(long)(s + 1) * p.d_model + c];
+        p.x[(long)b * p.d_model + c] = (float)p.tok_emb[(long)tok * p.d_model + c] + p.pos[(long)(s + 1) * p.d_model + c];
     }
   }
-  if (threadIdx.x == 0) p.state->step = s + 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int ticket = atomicAdd(&p.state->pad0, 1);
+    if (ticket == (int)gridDim.x - 1) {
+      p.state->pad0 = 0;
+      p.state->step = s + 1;
+    }
+  }
 }
 
-void launch_advance(const AdvanceParams& p, hipStream_t s) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1024), 0, s, p); }
+void launch_advance(const AdvanceParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(advance_kernel, dim3((p.batch + 15) / 16), dim3(1024), 0, s, p);
+}
 
 }  // namespace axw

@@ -144,9 +144,16 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
         ov += f * s_part[w][2 + tid];
       }
     }
-    float* out = p.part + (((long)b * p.n_head + head) * p.n_split + split) * kPartStride;
-    if (tid == 0) { out[0] = m; out[1] = l; }
-    out[2 + tid] = ov;
+    if (p.out_hi) {  // single split: this IS the attention output (batched decode path)
+      const float y = ov / l;
+      const bf16 yh = (bf16)y;
+      p.out_hi[(long)b * p.d_model + head * 64 + tid] = yh;
+      p.out_lo[(long)b * p.d_model + head * 64 + tid] = (bf16)(y - (float)yh);
+    } else {
+      float* out = p.part + (((long)b * p.n_head + head) * p.n_split + split) * kPartStride;
+      if (tid == 0) { out[0] = m; out[1] = l; }
+      out[2 + tid] = ov;
+    }
   }
 }
 

@@ -347,13 +347,18 @@ void Engine::ensure_capacity(int batch) {
   d_xdec_ = (float*)A((size_t)B * d * 4, true);
   d_qdec_ = (float*)A((size_t)B * d * 4, true);
   d_hid_ = (float*)A((size_t)B * 4 * d * 4, true);
-  split_cross_ = B <= 2 ? 6 : (B <= 8 ? 3 : 2);
-  split_self_ = B <= 8 ? 2 : 1;
+  for (int i = 0; i < 2; ++i) {  // bf16 (hi, lo) activation pairs of the batched (MFMA) decode path
+    d_act_[i] = (bf16*)A((size_t)B * d * 2, true);
+    d_att_[i] = (bf16*)A((size_t)B * d * 2, true);
+    d_hidp_[i] = (bf16*)A((size_t)B * 4 * d * 2, true);
+  }
+  split_cross_ = B <= 2 ? 6 : 3;  // the VALU path serves <= 4 clips; larger batches use one split per (clip, head)
+  split_self_ = 2;
   d_part_self_ = (float*)A((size_t)B * H * split_self_ * 66 * 4, true);
   d_part_cross_ = (float*)A((size_t)B * H * split_cross_ * 66 * 4, true);
   GemvParams lp{};
   lp.N = cfg_.n_vocab; lp.K = d;
-  n_amax_part_ = gemv_grid(lp);
+  n_amax_part_ = std::max(gemv_grid(lp), decode_gemm_grid(cfg_.n_vocab, 4));
   d_amax_val_ = (float*)A((size_t)n_amax_part_ * B * 4, true);
   d_amax_idx_ = (int*)A((size_t)n_amax_part_ * B * 4, true);
   d_tok_ = (int*)A((size_t)B * 4, true);
@@ -465,6 +470,10 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
                                  long logits_stride, int* d_argmax) {
   const int d = cfg_.n_text_state, H = cfg_.n_text_head, L = cfg_.n_text_layer, Tc = cfg_.n_text_ctx;
   hipStream_t s = stream();
+  if (batch > 4) {
+    enqueue_decode_step_batched(batch, max_new, d_forced, n_forced, d_logits, logits_stride, d_argmax);
+    return;
+  }
 
   // the VALU GEMV handles <= 4 clips per launch; tile the batch
   auto gemv = [&](GemvParams p, auto&& offset) {
@@ -539,7 +548,90 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
     if (q.logits_dump) q.logits_dump += (long)b0 * logits_stride;
   });
   AdvanceParams a{};
-  a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = n_amax_part_; a.amax_stride = cap_;
+  a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = gemv_grid(p); a.amax_stride = cap_;
+  a.state = d_state_; a.tok = d_tok_; a.done = d_done_; a.n_out = d_nout_; a.out_ids = d_out_ids_; a.batch = batch;
+  a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.sot = d_sot_;
+  a.forced = d_forced; a.n_forced = n_forced; a.argmax_dump = d_argmax;
+  a.tok_emb = tok_emb_; a.pos = dec_pos_; a.x = d_xdec_; a.d_model = d;
+  if (step_mask_ & 4) launch_advance(a, s);
+}
+
+// Batched variant (5+ clips): LayerNorm -> bf16 pairs (act_prep), MFMA GEMMs that read the weights once for the
+// whole batch, one attention workgroup per (clip, head) writing its output directly (no split partials).
+void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits,
+                                         long logits_stride, int* d_argmax) {
+  const int d = cfg_.n_text_state, H = cfg_.n_text_head, L = cfg_.n_text_layer, Tc = cfg_.n_text_ctx;
+  hipStream_t s = stream();
+  const long self_stride = (long)H * Tc * 64, cross_stride = (long)H * t_pad_ * 64;
+
+  auto gemm = [&](DecGemmParams p, auto&& offset) {
+    for (int b0 = 0; b0 < batch; b0 += 64) {
+      DecGemmParams q = p;
+      q.batch = std::min(64, batch - b0);
+      q.a_hi += (long)b0 * p.K;
+      q.a_lo += (long)b0 * p.K;
+      offset(q, b0);
+      if (step_mask_ & 1) launch_decode_gemm(q, s);
+    }
+  };
+  auto ln = [&](const float* g, const float* be) {
+    if (step_mask_ & 8) launch_act_prep(d_xdec_, g, be, d_act_[0], d_act_[1], batch, d, true, s);
+  };
+  auto attn = [&](const bf16* kc, const bf16* vc, long stride, int n_keys, int cap_blocks) {
+    DecAttnParams a{};
+    a.q = d_qdec_; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = nullptr; a.n_split = 1;
+    a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
+    a.out_hi = d_att_[0]; a.out_lo = d_att_[1];
+    if (step_mask_ & 2) launch_decode_attention(a, s);
+  };
+  auto base = [&](const bf16* W, const float* bias, int N, int K, const bf16* ahi, const bf16* alo, int epi) {
+    DecGemmParams p{};
+    p.W = W; p.bias = bias; p.N = N; p.K = K; p.a_hi = ahi; p.a_lo = alo; p.epilogue = epi; p.rt = 1;
+    p.d_model = d; p.n_ctx_pad = Tc; p.state = d_state_;
+    return p;
+  };
+
+  for (int l = 0; l < L; ++l) {
+    const DecLayerW& w = dec_[l];
+    bf16* sk = d_self_k_ + (size_t)l * cap_ * self_stride;
+    bf16* sv = d_self_v_ + (size_t)l * cap_ * self_stride;
+    const bf16* ck = d_cross_k_ + (size_t)l * cap_ * cross_stride;
+    const bf16* cv = d_cross_v_ + (size_t)l * cap_ * cross_stride;
+    ln(w.attn_ln_w, w.attn_ln_b);
+    DecGemmParams p = base(w.w_qkv, w.b_qkv, 3 * d, d, d_act_[0], d_act_[1], GEPI_QKV_CACHE);
+    p.out = d_qdec_; p.k_cache = sk; p.v_cache = sv; p.kv_batch_stride = self_stride;
+    gemm(p, [&](DecGemmParams& q, int b0) { q.out += (long)b0 * d; q.k_cache += b0 * self_stride; q.v_cache += b0 * self_stride; });
+    attn(sk, sv, self_stride, -1, Tc / 64);
+    p = base(w.w_o, w.b_o, d, d, d_att_[0], d_att_[1], GEPI_RESID);
+    p.out = d_xdec_;
+    gemm(p, [&](DecGemmParams& q, int b0) { q.out += (long)b0 * d; });
+    ln(w.cross_ln_w, w.cross_ln_b);
+    p = base(w.w_cq, w.b_cq, d, d, d_act_[0], d_act_[1], GEPI_STORE);
+    p.out = d_qdec_;
+    gemm(p, [&](DecGemmParams& q, int b0) { q.out += (long)b0 * d; });
+    attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64);
+    p = base(w.w_co, w.b_co, d, d, d_att_[0], d_att_[1], GEPI_RESID);
+    p.out = d_xdec_;
+    gemm(p, [&](DecGemmParams& q, int b0) { q.out += (long)b0 * d; });
+    ln(w.mlp_ln_w, w.mlp_ln_b);
+    p = base(w.w_fc1, w.b_fc1, 4 * d, d, d_act_[0], d_act_[1], GEPI_GELU);
+    p.out_hi = d_hidp_[0]; p.out_lo = d_hidp_[1];
+    gemm(p, [&](DecGemmParams& q, int b0) { q.out_hi += (long)b0 * 4 * d; q.out_lo += (long)b0 * 4 * d; });
+    p = base(w.w_fc2, w.b_fc2, d, 4 * d, d_hidp_[0], d_hidp_[1], GEPI_RESID);
+    p.out = d_xdec_;
+    gemm(p, [&](DecGemmParams& q, int b0) { q.out += (long)b0 * d; });
+  }
+  ln(dec_ln_w_, dec_ln_b_);
+  DecGemmParams p = base(tok_emb_, nullptr, cfg_.n_vocab, d, d_act_[0], d_act_[1], GEPI_LOGITS);
+  p.rt = 4;
+  p.amax_val = d_amax_val_; p.amax_idx = d_amax_idx_; p.amax_stride = cap_;
+  p.skip_before_step = 3; p.logits_dump = d_logits; p.logits_dump_stride = logits_stride;
+  gemm(p, [&](DecGemmParams& q, int b0) {
+    q.amax_val += b0; q.amax_idx += b0;
+    if (q.logits_dump) q.logits_dump += (long)b0 * logits_stride;
+  });
+  AdvanceParams a{};
+  a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = decode_gemm_grid(cfg_.n_vocab, 4); a.amax_stride = cap_;
   a.state = d_state_; a.tok = d_tok_; a.done = d_done_; a.n_out = d_nout_; a.out_ids = d_out_ids_; a.batch = batch;
   a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.sot = d_sot_;
   a.forced = d_forced; a.n_forced = n_forced; a.argmax_dump = d_argmax;
@@ -548,7 +640,7 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
 }
 
 hipGraphExec_t Engine::step_graph(int batch, int max_new) {
-  const long key = ((long)batch * 1024 + max_new) * 8 + step_mask_;
+  const long key = ((long)batch * 1024 + max_new) * 16 + step_mask_;
   auto it = graphs_.find(key);
   if (it != graphs_.end()) return it->second;
   hipStream_t s = stream();
@@ -728,8 +820,8 @@ float Engine::bench(const std::string& what, int batch, int arg, int iters) {
   float ms = 0.f;
   if (what == "decode_step" || what == "decode_gemv" || what == "decode_attn") {
     // decode_gemv / decode_attn: the same captured step with only the GEMV / only the attention launches
-    step_mask_ = what == "decode_step" ? 7 : (what == "decode_gemv" ? 1 : 2);
-    struct Restore { int& m; ~Restore() { m = 7; } } restore{step_mask_};
+    step_mask_ = what == "decode_step" ? 15 : (what == "decode_gemv" ? 1 : 2);
+    struct Restore { int& m; ~Restore() { m = 15; } } restore{step_mask_};
     const int Tc = cfg_.n_text_ctx;
     reset_decode_state(batch);
     hipGraphExec_t g = step_graph(batch, Tc - 4);

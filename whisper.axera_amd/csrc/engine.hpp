@@ -70,6 +70,8 @@ class Engine {
   void reset_decode_state(int batch);
   void enqueue_decode_step(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits, long logits_stride,
                            int* d_argmax);
+  void enqueue_decode_step_batched(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits,
+                                   long logits_stride, int* d_argmax);
   hipGraphExec_t step_graph(int batch, int max_new);
   int greedy_loop(int batch, int max_new);
   void fetch_ids(int batch, int32_t* ids, int* n_ids);
@@ -104,12 +106,13 @@ class Engine {
   float* d_x_ = nullptr;
   bf16 *d_cross_k_ = nullptr, *d_cross_v_ = nullptr, *d_self_k_ = nullptr, *d_self_v_ = nullptr;
   float *d_xdec_ = nullptr, *d_qdec_ = nullptr, *d_hid_ = nullptr, *d_part_self_ = nullptr, *d_part_cross_ = nullptr;
+  bf16 *d_act_[2] = {nullptr, nullptr}, *d_att_[2] = {nullptr, nullptr}, *d_hidp_[2] = {nullptr, nullptr};
   float* d_amax_val_ = nullptr; int* d_amax_idx_ = nullptr; int n_amax_part_ = 0;
   int *d_tok_ = nullptr, *d_done_ = nullptr, *d_nout_ = nullptr, *d_out_ids_ = nullptr;
   DecState* d_state_ = nullptr;
   int* h_poll_ = nullptr;  // pinned
   int split_self_ = 2, split_cross_ = 6;
-  int step_mask_ = 7;  // bench only: 1 GEMV launches, 2 attention launches, 4 embed + advance
+  int step_mask_ = 15;  // bench only: 1 GEMV/GEMM launches, 2 attention launches, 4 advance, 8 act_prep
   std::map<long, hipGraphExec_t> graphs_;  // key: batch * 1024 + max_new
   hipEvent_t ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
