@@ -1,0 +1,32 @@
+"""CPU: every HIP kernel compiles for gfx950 without scratch memory or register spills.
+
+A staging register array that lands in scratch (private_segment_fixed_size != 0) silently serialises every
+prefetch load behind a scratch store — this cost the encoder GEMM 2x before it was caught — so it is a test."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "whisper.axera_amd", "csrc")
+KERNEL_FILES = ["frontend", "gemm", "encoder_attn", "decoder", "decode_gemv", "decode_gemm"]
+
+
+@pytest.mark.parametrize("name", KERNEL_FILES)
+def test_no_scratch_no_spills(name, tmp_path):
+    out = tmp_path / f"{name}.s"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                        "--cuda-device-only", "-S", "-o", str(out), os.path.join(CSRC, name + ".hip")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    names = re.findall(r"^\s+\.name:\s+(\S+)", text, re.M)
+    priv = [int(x) for x in re.findall(r"^\s+\.private_segment_fixed_size:\s+(\d+)", text, re.M)]
+    spills = [int(x) for x in re.findall(r"^\s+\.vgpr_spill_count:\s+(\d+)", text, re.M)]
+    vgprs = [int(x) for x in re.findall(r"^\s+\.vgpr_count:\s+(\d+)", text, re.M)]
+    assert names and len(priv) == len(names)
+    bad = [(n, p) for n, p in zip(names, priv) if p != 0]
+    assert not bad, f"kernels using scratch memory: {bad}"
+    assert all(s == 0 for s in spills)
+    assert max(vgprs) <= 256

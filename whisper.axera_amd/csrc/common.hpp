@@ -10,6 +10,7 @@ typedef __bf16 bf16;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-byte staging register (HIP's uint4 struct can end up in scratch)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kNFFT = 400;
@@ -60,6 +61,7 @@ struct GemmParams {
   int n_batch_total;                 // EPI_CROSS_KV: slot count B in [l][B][h]...
   int n_layer;                       // EPI_CROSS_KV: decoder layers (weight rows: all K, then all V)
   int n_begin;                       // set by launch_gemm: first output column of this launch
+  int n_tiles;                       // set by launch_gemm: 128-column tiles of this launch
   int epilogue;
 };
 void launch_gemm(const GemmParams& p, hipStream_t s);
@@ -111,6 +113,7 @@ enum GemvEpilogue : int {
   GEPI_RESID = 2,      // out[b][n] += y + bias
   GEPI_QKV_CACHE = 3,  // n<d: q; then self-K (blocked) / self-V cache rows at `step`
   GEPI_LOGITS = 4,     // per-WG argmax partials (+ optional full logits dump)
+  GEPI_PARTIAL = 5,    // batched path only: split-K partial sums [ksplit][part_batch][N], folded by the consumer
 };
 
 struct GemvParams {
@@ -146,14 +149,16 @@ struct DecAttnParams {
   int n_keys;                 // fixed key count (cross) or -1: state->step + 1 (self)
   int cap_blocks;             // allocated 64-key blocks per (slot, head): 24 cross, 7 self
   const DecState* state;
-  bf16* out_hi; bf16* out_lo; // n_split == 1 only: write the normalised output as a bf16 pair [B][d] instead of partials
+  bf16* out_hi; bf16* out_lo; int nbs; // n_split == 1 only: normalised output as a fragment-major bf16 pair instead of partials
 };
 void launch_decode_attention(const DecAttnParams& p, hipStream_t s);
 
 // ---- batched decode (5..64 clips per launch): activations as bf16 (hi, lo) pairs, MFMA GEMM (decode_gemm.hip)
 struct DecGemmParams {
-  const bf16* W; const float* bias; int N, K, batch;
-  const bf16* a_hi; const bf16* a_lo;      // [batch][K]
+  const bf16* W;                           // fragment-major packed weights
+  const float* bias; int N, K, batch;
+  const bf16* a_hi; const bf16* a_lo;      // fragment-major bf16 pair (decode_gemm.hip), this launch's first clip block
+  int nbs;                                 // allocated clip blocks (stride of the activation layout)
   int epilogue;                            // GemvEpilogue
   int rt;                                  // weight-row tiles per wave: 1 (16 rows/WG) or 4 (64 rows/WG, vocabulary)
   float* out;                              // fp32 [batch][N] (STORE / RESID / q of QKV_CACHE)
@@ -163,11 +168,14 @@ struct DecGemmParams {
   float* amax_val; int* amax_idx; int amax_stride;
   float* logits_dump; long logits_dump_stride;
   int skip_before_step;
+  int ksplit; int part_batch;              // GEPI_PARTIAL: K slices (grid.y) and the clip stride of the partial buffer
+  int debug;                               // timing experiments only
 };
 void launch_decode_gemm(const DecGemmParams& p, hipStream_t s);
 int decode_gemm_grid(int N, int rt);
-void launch_act_prep(const float* x, const float* g, const float* be, bf16* hi, bf16* lo, int batch, int K, bool do_ln,
-                     hipStream_t s);
+void launch_act_prep(float* x, const float* g, const float* be, bf16* hi, bf16* lo, int batch, int K, bool do_ln, int nbs,
+                     const float* part, int n_part, int part_batch, const float* part_bias, hipStream_t s);
+void launch_pack_weight_frag(const bf16* w, bf16* wp, int N, int K, hipStream_t s);
 
 struct AdvanceParams {
   const float* amax_val; const int* amax_idx; int n_part; int amax_stride;

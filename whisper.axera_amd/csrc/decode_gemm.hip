@@ -8,7 +8,7 @@
 // line with the fp32-FMA GEMV used for 1..4 clips (decode_gemv.hip).
 //
 // Mapping (wave64): C[n][b] = W[n][:] . a[b][:], A operand = 16 weight rows, B operand = 16 clips.
-//   workgroup = 4 waves = 16*RT weight rows; the 4 waves split K (each wave K/4), then reduce through LDS;
+//   workgroup = 8 waves = 16*RT weight rows; the 8 waves split K (k-steps round-robin), then reduce through LDS;
 //   a wave keeps RT x NB accumulator tiles (NB = ceil(batch/16) <= 4) so one activation fragment feeds RT MFMAs;
 //   weights: 16-byte loads, 4 lanes cover 64 contiguous bytes of a row per k-step, k-steps unrolled so the
 //   whole 128-byte line is requested back to back; activations come from L2 (bf16 pairs written by the
@@ -24,16 +24,41 @@ __device__ __forceinline__ void split_bf16(float x, bf16& hi, bf16& lo) {
   lo = (bf16)(x - (float)hi);
 }
 
+// Fragment-major layouts: both MFMA operands are stored in the order the 16x16x32 instruction consumes them, so
+// every operand load of a wave is ONE contiguous 1 KiB access (lane*16 bytes):
+//   activations  ap[((ks * nbs + c) * 64 + lane) * 8 + j] = a[clip = c*16 + (lane&15)][k = ks*32 + (lane>>4)*8 + j]
+//   weights      wp[((nb * KS + ks) * 64 + lane) * 8 + j] = W[row = nb*16 + (lane&15)][k = ks*32 + (lane>>4)*8 + j]
+__device__ __forceinline__ long frag_index(int row, int k, int row_blocks_stride /* nbs or unused */, int ks_count, bool weight) {
+  const int ks = k >> 5, q = (k >> 3) & 3, j = k & 7, blk = row >> 4, r = row & 15;
+  const long tile = weight ? ((long)blk * ks_count + ks) : ((long)ks * row_blocks_stride + blk);
+  return (tile * 64 + q * 16 + r) * 8 + j;
+}
+__device__ __forceinline__ void store_pair_frag(float x, bf16* hi, bf16* lo, int clip, int k, int nbs) {
+  bf16 h, l;
+  split_bf16(x, h, l);
+  const long i = frag_index(clip, k, nbs, 0, false);
+  hi[i] = h; lo[i] = l;
+}
+
 // LayerNorm (or plain copy) of the residual stream -> bf16 (hi, lo) rows; one workgroup per clip.
-__global__ __launch_bounds__(256) void act_prep_kernel(const float* __restrict__ x, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void act_prep_kernel(float* x, const float* __restrict__ g,
                                                        const float* __restrict__ be, bf16* __restrict__ hi, bf16* __restrict__ lo,
-                                                       int K, int do_ln) {
+                                                       int K, int do_ln, int nbs, const float* __restrict__ part, int n_part,
+                                                       int part_batch, const float* __restrict__ part_bias) {
   __shared__ float red[8];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* xr = x + (long)b * K;
+  float* xr = x + (long)b * K;
+  if (n_part > 0) {  // x += bias + sum of the previous GEMM's split-K partial outputs (fixed order: deterministic)
+    for (int c = tid; c < K; c += 256) {
+      float v = xr[c] + part_bias[c];
+      for (int s = 0; s < n_part; ++s) v += part[((long)s * part_batch + b) * K + c];
+      xr[c] = v;
+    }
+    __syncthreads();
+  }
   constexpr int MAXE = 8;  // K <= 2048 for LayerNorm rows
   if (!do_ln) {
-    for (int c = tid; c < K; c += 256) split_bf16(xr[c], hi[(long)b * K + c], lo[(long)b * K + c]);
+    for (int c = tid; c < K; c += 256) store_pair_frag(xr[c], hi, lo, b, c, nbs);
     return;
   }
   float v[MAXE], gg[MAXE], bb[MAXE];
@@ -57,39 +82,52 @@ __global__ __launch_bounds__(256) void act_prep_kernel(const float* __restrict__
 #pragma unroll
   for (int e = 0; e < MAXE; ++e) {
     const int c = tid + 256 * e;
-    if (c < K) split_bf16((v[e] - mean) * rstd * gg[e] + bb[e], hi[(long)b * K + c], lo[(long)b * K + c]);
+    if (c < K) store_pair_frag((v[e] - mean) * rstd * gg[e] + bb[e], hi, lo, b, c, nbs);
   }
 }
 
-void launch_act_prep(const float* x, const float* g, const float* be, bf16* hi, bf16* lo, int batch, int K, bool do_ln,
-                     hipStream_t s) {
-  hipLaunchKernelGGL(act_prep_kernel, dim3(batch), dim3(256), 0, s, x, g, be, hi, lo, K, do_ln ? 1 : 0);
+void launch_act_prep(float* x, const float* g, const float* be, bf16* hi, bf16* lo, int batch, int K, bool do_ln, int nbs,
+                     const float* part, int n_part, int part_batch, const float* part_bias, hipStream_t s) {
+  hipLaunchKernelGGL(act_prep_kernel, dim3(batch), dim3(256), 0, s, x, g, be, hi, lo, K, do_ln ? 1 : 0, nbs, part, n_part,
+                     part_batch, part_bias);
+}
+
+// row-major bf16 [N][K] -> fragment-major (rows padded to a multiple of 16 with zeros)
+__global__ void pack_weight_frag_kernel(const bf16* __restrict__ w, bf16* __restrict__ wp, int N, int K) {
+  const int KS = K / 32;
+  const long total = (long)((N + 15) / 16) * KS * 512;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long tile = i >> 9;
+    const int ks = (int)(tile % KS), nb = (int)(tile / KS);
+    const int row = nb * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + j;
+    wp[i] = row < N ? w[(long)row * K + k] : (bf16)0.f;
+  }
+}
+void launch_pack_weight_frag(const bf16* w, bf16* wp, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(2048), dim3(256), 0, s, w, wp, N, K);
 }
 
 template <int RT, int NB>
-__global__ __launch_bounds__(256) void decode_gemm_kernel(DecGemmParams p) {
+__global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);  // [4 waves][RT][NB][16 n][16 b]
+  float* red = reinterpret_cast<float*>(smem);  // [8 waves][RT][NB][16 clips][16 rows]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // 8 waves
   const int r = lane & 15, q = lane >> 4;
-  const int K = p.K;
   const int n0 = blockIdx.x * (16 * RT);
-  const int kw = K / 4;            // this wave's K range
-  const int k_begin = wave * kw;
-  const int nks = kw / 32;
+  const int KS_all = p.K / 32;     // k-steps in total
+  const int KS = KS_all / (int)gridDim.y;  // k-steps of this workgroup's K slice (blockIdx.y); wave w takes w, w+8, ...
+  const int ks_base = blockIdx.y * KS;
+  const int nb0 = blockIdx.x * RT; // first 16-row block of this workgroup
+  const int n_rb = (p.N + 15) / 16;
 
   const bf16* wrow[RT];
 #pragma unroll
-  for (int t = 0; t < RT; ++t) wrow[t] = p.W + (long)min(n0 + t * 16 + r, p.N - 1) * K + k_begin + 8 * q;
-  const bf16* ahi[NB];
-  const bf16* alo[NB];
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    const int b = min(c * 16 + r, p.batch - 1);  // clips beyond the batch: duplicate loads, results discarded
-    ahi[c] = p.a_hi + (long)b * K + k_begin + 8 * q;
-    alo[c] = p.a_lo + (long)b * K + k_begin + 8 * q;
-  }
+  for (int t = 0; t < RT; ++t) wrow[t] = p.W + ((long)min(nb0 + t, n_rb - 1) * KS_all + ks_base) * 512 + lane * 8;
+  const bf16* ahi = p.a_hi + ks_base * ((long)p.nbs * 512) + lane * 8;
+  const bf16* alo = p.a_lo + ks_base * ((long)p.nbs * 512) + lane * 8;
+  const long a_step = (long)p.nbs * 512;  // elements between consecutive k-steps of the activations
 
   f32x4 acc[RT][NB];
 #pragma unroll
@@ -99,52 +137,83 @@ __global__ __launch_bounds__(256) void decode_gemm_kernel(DecGemmParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[t][c][e] = 0.f;
 
-  const int step = (p.epilogue == GEPI_LOGITS || p.epilogue == GEPI_QKV_CACHE) ? p.state->step : 0;
-  if (p.epilogue == GEPI_LOGITS && step < p.skip_before_step) return;
-
-#pragma unroll 2
-  for (int ks = 0; ks < nks; ++ks) {
-    bf16x8 wf[RT], hf[NB], lf[NB];
+  // Three register sets of operand fragments: with 8 waves splitting K, Whisper-small's K = 768 is 3 k-steps
+  // per wave, i.e. every operand byte of the workgroup is requested before the first MFMA (one memory round
+  // trip); longer K rotates the sets. Every load is one contiguous 1 KiB wave access.
+  struct Frag { bf16x8 w[RT], h[NB], l[NB]; };
+  auto load = [&](Frag& f, int ks) {
+    if (p.debug & 4) return;
 #pragma unroll
-    for (int t = 0; t < RT; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(wrow[t] + ks * 32);
+    for (int t = 0; t < RT; ++t) f.w[t] = *reinterpret_cast<const bf16x8*>(wrow[t] + (long)ks * 512);
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-      hf[c] = *reinterpret_cast<const bf16x8*>(ahi[c] + ks * 32);
-      lf[c] = *reinterpret_cast<const bf16x8*>(alo[c] + ks * 32);
+      f.h[c] = *reinterpret_cast<const bf16x8*>(ahi + ks * a_step + c * 512);
+      f.l[c] = *reinterpret_cast<const bf16x8*>(alo + ks * a_step + c * 512);
     }
+  };
+  auto mma = [&](const Frag& f) {
+    if (p.debug & 2) return;
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
       for (int c = 0; c < NB; ++c) {
-        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], hf[c], acc[t][c], 0, 0, 0);
-        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], lf[c], acc[t][c], 0, 0, 0);
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t], f.h[c], acc[t][c], 0, 0, 0);
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t], f.l[c], acc[t][c], 0, 0, 0);
       }
+  };
+  const int dbg = p.debug;  // timing experiments only (AXW_DEBUG_GEMM): 1 no epilogue stores, 2 no MFMA, 4 no loads
+  Frag f0, f1, f2;
+  if (dbg & 4) { f0 = Frag{}; f1 = Frag{}; f2 = Frag{}; }
+  if (wave < KS) load(f0, wave);
+  if (wave + 8 < KS) load(f1, wave + 8);
+  if (wave + 16 < KS) load(f2, wave + 16);
+
+  // the step counter is read after the operand loads are in flight
+  const int step = (p.epilogue == GEPI_LOGITS || p.epilogue == GEPI_QKV_CACHE) ? p.state->step : 0;
+  if (p.epilogue == GEPI_LOGITS && step < p.skip_before_step) return;
+
+  for (int ks = wave; ks < KS; ks += 24) {
+    mma(f0);
+    if (ks + 24 < KS) load(f0, ks + 24);
+    if (ks + 8 < KS) {
+      mma(f1);
+      if (ks + 32 < KS) load(f1, ks + 32);
+    }
+    if (ks + 16 < KS) {
+      mma(f2);
+      if (ks + 40 < KS) load(f2, ks + 40);
+    }
   }
 
-  // split-K reduction across the 4 waves: acc[t][c][e] = C[n = t*16 + 4q + e][b = c*16 + r]
+  // split-K reduction across the 8 waves through LDS: red[wave][t][c][clip r][row 4q+e], rows fastest, so a
+  // lane's 4 accumulator values are one 16-byte LDS store and the epilogue reads consecutive rows.
 #pragma unroll
   for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int c = 0; c < NB; ++c)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) red[(((wave * RT + t) * NB + c) * 16 + 4 * q + e) * 16 + r] = acc[t][c][e];
+      *reinterpret_cast<f32x4*>(red + (((wave * RT + t) * NB + c) * 16 + r) * 16 + 4 * q) = acc[t][c];
   __syncthreads();
 
   constexpr int OUT = RT * NB * 256;  // outputs of this workgroup
-  float best_v = -INFINITY;
-  int best_i = 0x7fffffff;
-  for (int o = tid; o < OUT; o += 256) {
-    // o -> (t, c, nn, bb) with bb fastest: consecutive threads = consecutive clips of one weight row
-    const int bb = o & 15, nn = (o >> 4) & 15, c = (o >> 8) % NB, t = (o >> 8) / NB;
-    const int n = n0 + t * 16 + nn, b = c * 16 + bb;
+  for (int o = tid; o < OUT; o += 512) {
+    // o -> (clip, row) with the weight row fastest: consecutive threads write consecutive n of one clip
+    // (out[b][n], the V cache rows and the fragment-major pair are all contiguous in n)
+    const int nl = o % (16 * RT), bl = o / (16 * RT);
+    const int t = nl >> 4, nn = nl & 15, c = bl >> 4, bb = bl & 15;
+    const int n = n0 + nl, b = bl;
     float y = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) y += red[(((w * RT + t) * NB + c) * 16 + nn) * 16 + bb];
+    for (int w = 0; w < 8; ++w) y += red[(((w * RT + t) * NB + c) * 16 + bb) * 16 + nn];
     if (n >= p.N || b >= p.batch) continue;
+    if ((p.debug & 1) && y != 12345.f) continue;
+    if (p.epilogue == GEPI_PARTIAL) {  // split-K slice: plain partial sums, folded (with the bias) by the consumer
+      p.out[((long)blockIdx.y * p.part_batch + b) * p.N + n] = y;
+      continue;
+    }
     y += p.bias ? p.bias[n] : 0.f;
     switch (p.epilogue) {
       case GEPI_STORE: p.out[(long)b * p.N + n] = y; break;
-      case GEPI_GELU: split_bf16(gelu_erf(y), p.out_hi[(long)b * p.N + n], p.out_lo[(long)b * p.N + n]); break;
+      case GEPI_GELU: store_pair_frag(gelu_erf(y), p.out_hi, p.out_lo, b, n, p.nbs); break;
       case GEPI_RESID: p.out[(long)b * p.N + n] += y; break;
       case GEPI_QKV_CACHE: {
         const int d = p.d_model;
@@ -161,17 +230,19 @@ __global__ __launch_bounds__(256) void decode_gemm_kernel(DecGemmParams p) {
       }
       case GEPI_LOGITS:
         if (p.logits_dump) p.logits_dump[(long)b * p.logits_dump_stride + n] = y;
-        red[4 * RT * NB * 256 + (t * 16 + nn) * (NB * 16) + b] = y;  // [16*RT rows][NB*16 clips] for the argmax below
+        red[8 * RT * NB * 256 + nl * (NB * 16) + b] = y;  // [16*RT rows][NB*16 clips] for the argmax below
         break;
     }
   }
   if (p.epilogue == GEPI_LOGITS) {  // per-clip argmax over this workgroup's rows, first max wins
     __syncthreads();
     if (tid < NB * 16 && tid < p.batch) {
+      float best_v = -INFINITY;
+      int best_i = 0x7fffffff;
       for (int i = 0; i < 16 * RT; ++i) {
         const int n = n0 + i;
         if (n >= p.N) break;
-        const float y = red[4 * RT * NB * 256 + i * (NB * 16) + tid];
+        const float y = red[8 * RT * NB * 256 + i * (NB * 16) + tid];
         if (y > best_v) { best_v = y; best_i = n; }
       }
       p.amax_val[(long)blockIdx.x * p.amax_stride + tid] = best_v;
@@ -185,21 +256,28 @@ int decode_gemm_grid(int N, int rt) { return (N + 16 * rt - 1) / (16 * rt); }
 template <int RT>
 static void launch_nb(const DecGemmParams& p, hipStream_t s) {
   const int nb = (p.batch + 15) / 16;
-  const int grid = decode_gemm_grid(p.N, RT);
-  const size_t lds = (size_t)(4 * RT * nb * 256 + (p.epilogue == GEPI_LOGITS ? 16 * RT * nb * 16 : 0)) * 4;
+  const dim3 grid(decode_gemm_grid(p.N, RT), p.epilogue == GEPI_PARTIAL ? p.ksplit : 1);
+  const size_t lds = (size_t)(8 * RT * nb * 256 + (p.epilogue == GEPI_LOGITS ? 16 * RT * nb * 16 : 0)) * 4;
   switch (nb) {
-    case 1: hipLaunchKernelGGL((decode_gemm_kernel<RT, 1>), dim3(grid), dim3(256), lds, s, p); break;
-    case 2: hipLaunchKernelGGL((decode_gemm_kernel<RT, 2>), dim3(grid), dim3(256), lds, s, p); break;
-    case 3: hipLaunchKernelGGL((decode_gemm_kernel<RT, 3>), dim3(grid), dim3(256), lds, s, p); break;
-    case 4: hipLaunchKernelGGL((decode_gemm_kernel<RT, 4>), dim3(grid), dim3(256), lds, s, p); break;
+    case 1: hipLaunchKernelGGL((decode_gemm_kernel<RT, 1>), grid, dim3(512), lds, s, p); break;
+    case 2: hipLaunchKernelGGL((decode_gemm_kernel<RT, 2>), grid, dim3(512), lds, s, p); break;
+    case 3: hipLaunchKernelGGL((decode_gemm_kernel<RT, 3>), grid, dim3(512), lds, s, p); break;
+    case 4: hipLaunchKernelGGL((decode_gemm_kernel<RT, 4>), grid, dim3(512), lds, s, p); break;
     default: fprintf(stderr, "[ax_whisper] launch_decode_gemm: batch %d > 64 per launch\n", p.batch); abort();
   }
 }
 
 // p.batch <= 64 per launch (the engine tiles larger batches); K % 128 == 0.
-void launch_decode_gemm(const DecGemmParams& p, hipStream_t s) {
+void launch_decode_gemm(const DecGemmParams& p0, hipStream_t s) {
+  static const int dbg = getenv("AXW_DEBUG_GEMM") ? atoi(getenv("AXW_DEBUG_GEMM")) : 0;
+  DecGemmParams p = p0;
+  p.debug = dbg;
   if (p.K % 128 != 0) { fprintf(stderr, "[ax_whisper] launch_decode_gemm: unsupported K=%d\n", p.K); abort(); }
-  if (p.rt == 4) launch_nb<4>(p, s);
+  static const int dbg_rt = getenv("AXW_DEBUG_RT") ? atoi(getenv("AXW_DEBUG_RT")) : 0;  // tuning aid
+  int rt = p.rt;
+  if (dbg_rt && rt == 4 && p.epilogue != GEPI_LOGITS) rt = dbg_rt;
+  if (rt == 4) launch_nb<4>(p, s);
+  else if (rt == 2) launch_nb<2>(p, s);
   else launch_nb<1>(p, s);
 }
 

@@ -147,8 +147,10 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
     if (p.out_hi) {  // single split: this IS the attention output (batched decode path)
       const float y = ov / l;
       const bf16 yh = (bf16)y;
-      p.out_hi[(long)b * p.d_model + head * 64 + tid] = yh;
-      p.out_lo[(long)b * p.d_model + head * 64 + tid] = (bf16)(y - (float)yh);
+      const int k = head * 64 + tid;  // fragment-major pair (layout: decode_gemm.hip)
+      const long i = ((((long)(k >> 5) * p.nbs + (b >> 4)) * 64) + ((k >> 3) & 3) * 16 + (b & 15)) * 8 + (k & 7);
+      p.out_hi[i] = yh;
+      p.out_lo[i] = (bf16)(y - (float)yh);
     } else {
       float* out = p.part + (((long)b * p.n_head + head) * p.n_split + split) * kPartStride;
       if (tid == 0) { out[0] = m; out[1] = l; }

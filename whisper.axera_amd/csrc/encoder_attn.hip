@@ -52,20 +52,20 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const bf16* __re
 
   const int ld_row = tid >> 3, ld_c = tid & 7;
   const int nkt = t_pad / 64;
-  uint4 rk[2], rv[2];
+  u32x4 rk[2], rv[2];
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int key = min(kt * 64 + ld_row + 32 * i, T - 1);
-      rk[i] = *reinterpret_cast<const uint4*>(Kb + (long)key * d_model + ld_c * 8);
-      rv[i] = *reinterpret_cast<const uint4*>(Vb + (long)(ld_row + 32 * i) * t_pad + kt * 64 + ld_c * 8);
+      rk[i] = *reinterpret_cast<const u32x4*>(Kb + (long)key * d_model + ld_c * 8);
+      rv[i] = *reinterpret_cast<const u32x4*>(Vb + (long)(ld_row + 32 * i) * t_pad + kt * 64 + ld_c * 8);
     }
   };
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<uint4*>(Ks + swz128(ld_row + 32 * i, ld_c)) = rk[i];
-      *reinterpret_cast<uint4*>(Vs + swz128(ld_row + 32 * i, ld_c)) = rv[i];
+      *reinterpret_cast<u32x4*>(Ks + swz128(ld_row + 32 * i, ld_c)) = rk[i];
+      *reinterpret_cast<u32x4*>(Vs + swz128(ld_row + 32 * i, ld_c)) = rv[i];
     }
   };
 
@@ -75,9 +75,8 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const bf16* __re
 
   const float sc = 0.125f * 1.44269504088896340736f;  // (64^-0.25)^2 * log2(e)
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) load_tile(kt + 1);
-
+  // One 64-key tile out of LDS: scores, online softmax, P.V  (kt only selects the tail mask)
+  auto process_tile = [&](int kt) {
     // ---- S^T = K Q^T : sacc[kb][e] = score(key = kt*64 + kb*32 + (e&3) + 8*(e>>2) + 4h, query = lane r)
     f32x16 sacc[2];
 #pragma unroll
@@ -141,12 +140,17 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const bf16* __re
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], oacc[db], 0, 0, 0);
         }
 
+  };
+  // Peeled so the staging registers are assigned unconditionally inside the loop (a conditional prefetch makes
+  // hipcc keep them in scratch memory and serialise every load).
+  for (int kt = 0; kt + 1 < nkt; ++kt) {
+    load_tile(kt + 1);
+    process_tile(kt);
     __syncthreads();
-    if (kt + 1 < nkt) {
-      store_tile();
-      __syncthreads();
-    }
+    store_tile();
+    __syncthreads();
   }
+  process_tile(nkt - 1);
 
   const float l = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l;

@@ -18,6 +18,8 @@ namespace axw {
       throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);       \
   } while (0)
 
+constexpr int kLogitsRT = 2;  // weight-row tiles per wave of the batched vocabulary projection (32 rows / workgroup)
+
 static int dtype_code(const std::string& d) { return d == "F32" ? 0 : d == "BF16" ? 1 : 2; }
 
 // ------------------------------------------------------------------------------ construction
@@ -63,7 +65,12 @@ Engine::~Engine() {
 void* Engine::dalloc(size_t bytes, bool zero) {
   void* p = nullptr;
   HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 256)));
-  if (zero) HIP_CHECK(hipMemset(p, 0, std::max<size_t>(bytes, 256)));
+  if (zero) {
+    // the engine's streams are non-blocking (not ordered against the null stream): finish the fill before any
+    // kernel on them can touch the buffer
+    HIP_CHECK(hipMemset(p, 0, std::max<size_t>(bytes, 256)));
+    HIP_CHECK(hipDeviceSynchronize());
+  }
   return p;
 }
 
@@ -285,6 +292,22 @@ void Engine::load_weights(const std::string& path) {
   dec_pos_ = to_f32("decoder.positional_embedding", {cfg_.n_text_ctx, d});
   dec_ln_w_ = to_f32("decoder.ln.weight", {d});
   dec_ln_b_ = to_f32("decoder.ln.bias", {d});
+  // fragment-major copies of the decoder weights for the batched (MFMA) decode path (decode_gemm.hip)
+  auto pack = [&](const bf16* w, int N, int K) {
+    bf16* wp = new_bf16((size_t)((N + 15) / 16) * 16 * K);
+    launch_pack_weight_frag(w, wp, N, K, s);
+    return (const bf16*)wp;
+  };
+  dec_packed_.resize(L);
+  for (int i = 0; i < L; ++i) {
+    dec_packed_[i].w_qkv = pack(dec_[i].w_qkv, 3 * d, d);
+    dec_packed_[i].w_o = pack(dec_[i].w_o, d, d);
+    dec_packed_[i].w_cq = pack(dec_[i].w_cq, d, d);
+    dec_packed_[i].w_co = pack(dec_[i].w_co, d, d);
+    dec_packed_[i].w_fc1 = pack(dec_[i].w_fc1, 4 * d, d);
+    dec_packed_[i].w_fc2 = pack(dec_[i].w_fc2, d, 4 * d);
+  }
+  tok_emb_packed_ = pack(tok_emb_, cfg_.n_vocab, d);
   HIP_CHECK(hipStreamSynchronize(s));
   HIP_CHECK(hipFree(stage));
 
@@ -347,18 +370,20 @@ void Engine::ensure_capacity(int batch) {
   d_xdec_ = (float*)A((size_t)B * d * 4, true);
   d_qdec_ = (float*)A((size_t)B * d * 4, true);
   d_hid_ = (float*)A((size_t)B * 4 * d * 4, true);
-  for (int i = 0; i < 2; ++i) {  // bf16 (hi, lo) activation pairs of the batched (MFMA) decode path
-    d_act_[i] = (bf16*)A((size_t)B * d * 2, true);
-    d_att_[i] = (bf16*)A((size_t)B * d * 2, true);
-    d_hidp_[i] = (bf16*)A((size_t)B * 4 * d * 2, true);
+  nbs_ = (B + 15) / 16;
+  for (int i = 0; i < 2; ++i) {  // fragment-major bf16 (hi, lo) activation pairs of the batched (MFMA) decode path
+    d_act_[i] = (bf16*)A((size_t)nbs_ * 16 * d * 2, true);
+    d_att_[i] = (bf16*)A((size_t)nbs_ * 16 * d * 2, true);
+    d_hidp_[i] = (bf16*)A((size_t)nbs_ * 16 * 4 * d * 2, true);
   }
   split_cross_ = B <= 2 ? 6 : 3;  // the VALU path serves <= 4 clips; larger batches use one split per (clip, head)
   split_self_ = 2;
+  d_part_ = (float*)A((size_t)4 * B * d * 4, true);  // split-K partials of the batched residual GEMMs
   d_part_self_ = (float*)A((size_t)B * H * split_self_ * 66 * 4, true);
   d_part_cross_ = (float*)A((size_t)B * H * split_cross_ * 66 * 4, true);
   GemvParams lp{};
   lp.N = cfg_.n_vocab; lp.K = d;
-  n_amax_part_ = std::max(gemv_grid(lp), decode_gemm_grid(cfg_.n_vocab, 4));
+  n_amax_part_ = std::max(gemv_grid(lp), decode_gemm_grid(cfg_.n_vocab, kLogitsRT));
   d_amax_val_ = (float*)A((size_t)n_amax_part_ * B * 4, true);
   d_amax_idx_ = (int*)A((size_t)n_amax_part_ * B * 4, true);
   d_tok_ = (int*)A((size_t)B * 4, true);
@@ -568,20 +593,40 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     for (int b0 = 0; b0 < batch; b0 += 64) {
       DecGemmParams q = p;
       q.batch = std::min(64, batch - b0);
-      q.a_hi += (long)b0 * p.K;
-      q.a_lo += (long)b0 * p.K;
+      q.a_hi += (long)(b0 / 16) * 512;  // fragment-major: clip blocks are 512 elements apart within a k-step
+      q.a_lo += (long)(b0 / 16) * 512;
+      q.nbs = nbs_;
       offset(q, b0);
       if (step_mask_ & 1) launch_decode_gemm(q, s);
     }
   };
+  // residual GEMMs write split-K partial sums; the next LayerNorm prep folds them (+ bias) into x, in fixed order
+  int pend_n = 0;
+  const float* pend_bias = nullptr;
   auto ln = [&](const float* g, const float* be) {
-    if (step_mask_ & 8) launch_act_prep(d_xdec_, g, be, d_act_[0], d_act_[1], batch, d, true, s);
+    if (step_mask_ & 8)
+      launch_act_prep(d_xdec_, g, be, d_act_[0], d_act_[1], batch, d, true, nbs_, d_part_, pend_n, cap_, pend_bias, s);
+    pend_n = 0;
+  };
+  auto ksplit_for = [&](int K) {
+    const int KS = K / 32;
+    for (int k = 4; k > 1; --k)
+      if (KS % k == 0 && KS / k >= 8) return k;
+    return 1;
+  };
+  auto resid = [&](const bf16* W, const float* bias, int K, const bf16* ahi, const bf16* alo) {
+    DecGemmParams p{};
+    p.W = W; p.bias = nullptr; p.N = d; p.K = K; p.a_hi = ahi; p.a_lo = alo; p.epilogue = GEPI_PARTIAL; p.rt = 1;
+    p.d_model = d; p.n_ctx_pad = Tc; p.state = d_state_; p.out = d_part_; p.ksplit = ksplit_for(K); p.part_batch = cap_;
+    gemm(p, [&](DecGemmParams& q, int b0) { q.out += (long)b0 * d; });
+    pend_n = p.ksplit;
+    pend_bias = bias;
   };
   auto attn = [&](const bf16* kc, const bf16* vc, long stride, int n_keys, int cap_blocks) {
     DecAttnParams a{};
     a.q = d_qdec_; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = nullptr; a.n_split = 1;
     a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
-    a.out_hi = d_att_[0]; a.out_lo = d_att_[1];
+    a.out_hi = d_att_[0]; a.out_lo = d_att_[1]; a.nbs = nbs_;
     if (step_mask_ & 2) launch_decode_attention(a, s);
   };
   auto base = [&](const bf16* W, const float* bias, int N, int K, const bf16* ahi, const bf16* alo, int epi) {
@@ -598,32 +643,27 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     const bf16* ck = d_cross_k_ + (size_t)l * cap_ * cross_stride;
     const bf16* cv = d_cross_v_ + (size_t)l * cap_ * cross_stride;
     ln(w.attn_ln_w, w.attn_ln_b);
-    DecGemmParams p = base(w.w_qkv, w.b_qkv, 3 * d, d, d_act_[0], d_act_[1], GEPI_QKV_CACHE);
+    const DecLayerWP& wp = dec_packed_[l];
+    DecGemmParams p = base(wp.w_qkv, w.b_qkv, 3 * d, d, d_act_[0], d_act_[1], GEPI_QKV_CACHE);
     p.out = d_qdec_; p.k_cache = sk; p.v_cache = sv; p.kv_batch_stride = self_stride;
     gemm(p, [&](DecGemmParams& q, int b0) { q.out += (long)b0 * d; q.k_cache += b0 * self_stride; q.v_cache += b0 * self_stride; });
     attn(sk, sv, self_stride, -1, Tc / 64);
-    p = base(w.w_o, w.b_o, d, d, d_att_[0], d_att_[1], GEPI_RESID);
-    p.out = d_xdec_;
-    gemm(p, [&](DecGemmParams& q, int b0) { q.out += (long)b0 * d; });
+    resid(wp.w_o, w.b_o, d, d_att_[0], d_att_[1]);
     ln(w.cross_ln_w, w.cross_ln_b);
-    p = base(w.w_cq, w.b_cq, d, d, d_act_[0], d_act_[1], GEPI_STORE);
+    p = base(wp.w_cq, w.b_cq, d, d, d_act_[0], d_act_[1], GEPI_STORE);
     p.out = d_qdec_;
     gemm(p, [&](DecGemmParams& q, int b0) { q.out += (long)b0 * d; });
     attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64);
-    p = base(w.w_co, w.b_co, d, d, d_att_[0], d_att_[1], GEPI_RESID);
-    p.out = d_xdec_;
-    gemm(p, [&](DecGemmParams& q, int b0) { q.out += (long)b0 * d; });
+    resid(wp.w_co, w.b_co, d, d_att_[0], d_att_[1]);
     ln(w.mlp_ln_w, w.mlp_ln_b);
-    p = base(w.w_fc1, w.b_fc1, 4 * d, d, d_act_[0], d_act_[1], GEPI_GELU);
+    p = base(wp.w_fc1, w.b_fc1, 4 * d, d, d_act_[0], d_act_[1], GEPI_GELU);
     p.out_hi = d_hidp_[0]; p.out_lo = d_hidp_[1];
-    gemm(p, [&](DecGemmParams& q, int b0) { q.out_hi += (long)b0 * 4 * d; q.out_lo += (long)b0 * 4 * d; });
-    p = base(w.w_fc2, w.b_fc2, d, 4 * d, d_hidp_[0], d_hidp_[1], GEPI_RESID);
-    p.out = d_xdec_;
-    gemm(p, [&](DecGemmParams& q, int b0) { q.out += (long)b0 * d; });
+    gemm(p, [&](DecGemmParams& q, int b0) { q.out_hi += (long)(b0 / 16) * 512; q.out_lo += (long)(b0 / 16) * 512; });
+    resid(wp.w_fc2, w.b_fc2, 4 * d, d_hidp_[0], d_hidp_[1]);
   }
   ln(dec_ln_w_, dec_ln_b_);
-  DecGemmParams p = base(tok_emb_, nullptr, cfg_.n_vocab, d, d_act_[0], d_act_[1], GEPI_LOGITS);
-  p.rt = 4;
+  DecGemmParams p = base(tok_emb_packed_, nullptr, cfg_.n_vocab, d, d_act_[0], d_act_[1], GEPI_LOGITS);
+  p.rt = kLogitsRT;
   p.amax_val = d_amax_val_; p.amax_idx = d_amax_idx_; p.amax_stride = cap_;
   p.skip_before_step = 3; p.logits_dump = d_logits; p.logits_dump_stride = logits_stride;
   gemm(p, [&](DecGemmParams& q, int b0) {
@@ -631,7 +671,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     if (q.logits_dump) q.logits_dump += (long)b0 * logits_stride;
   });
   AdvanceParams a{};
-  a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = decode_gemm_grid(cfg_.n_vocab, 4); a.amax_stride = cap_;
+  a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = decode_gemm_grid(cfg_.n_vocab, kLogitsRT); a.amax_stride = cap_;
   a.state = d_state_; a.tok = d_tok_; a.done = d_done_; a.n_out = d_nout_; a.out_ids = d_out_ids_; a.batch = batch;
   a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.sot = d_sot_;
   a.forced = d_forced; a.n_forced = n_forced; a.argmax_dump = d_argmax;

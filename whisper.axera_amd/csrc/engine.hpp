@@ -92,6 +92,10 @@ class Engine {
   int conv1_k_ = 0;
   std::vector<EncLayer> enc_;
   std::vector<DecLayerW> dec_;
+  struct DecLayerWP { const bf16 *w_qkv, *w_o, *w_cq, *w_co, *w_fc1, *w_fc2; };
+  std::vector<DecLayerWP> dec_packed_;  // fragment-major copies for the batched decode path
+  const bf16* tok_emb_packed_ = nullptr;
+  int nbs_ = 1;                         // allocated clip blocks of 16
   // front-end constants
   float *twiddle_ = nullptr, *window_ = nullptr, *mel_basis_t_ = nullptr;
   int* d_sot_ = nullptr;
@@ -107,6 +111,7 @@ class Engine {
   bf16 *d_cross_k_ = nullptr, *d_cross_v_ = nullptr, *d_self_k_ = nullptr, *d_self_v_ = nullptr;
   float *d_xdec_ = nullptr, *d_qdec_ = nullptr, *d_hid_ = nullptr, *d_part_self_ = nullptr, *d_part_cross_ = nullptr;
   bf16 *d_act_[2] = {nullptr, nullptr}, *d_att_[2] = {nullptr, nullptr}, *d_hidp_[2] = {nullptr, nullptr};
+  float* d_part_ = nullptr;
   float* d_amax_val_ = nullptr; int* d_amax_idx_ = nullptr; int n_amax_part_ = 0;
   int *d_tok_ = nullptr, *d_done_ = nullptr, *d_nout_ = nullptr, *d_out_ids_ = nullptr;
   DecState* d_state_ = nullptr;

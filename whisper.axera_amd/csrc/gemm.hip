@@ -34,7 +34,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
-  const int n0 = p.n_begin + blockIdx.x * BN, m0 = blockIdx.y * BM, bz = blockIdx.z;
+  // XCD-aware tile order (1-D grid): workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so
+  // give every XCD a CONTIGUOUS chunk of the (clip, row-tile, column-tile) space with the column tile fastest: the
+  // N/128 workgroups that share one 128-row A panel then run on one XCD and hit its L2 (bijective for any grid size).
+  int n0, m0, bz;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+    const int nt = p.n_tiles, mt = (p.M + BM - 1) / BM;
+    n0 = p.n_begin + (wg % nt) * BN;
+    const int rest = wg / nt;
+    m0 = (rest % mt) * BM;
+    bz = rest / mt;
+  }
 
   const bf16* A = p.A + (long)bz * p.a_batch_stride;
   const bf16* W = p.W;
@@ -61,29 +74,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   // SWAPPED: MFMA operands exchanged so that lanes run along M (the consumer wants M contiguous)
   constexpr bool swapped = SWAPPED;
 
-  uint4 ra[4], rw[4];
+  u32x4 ra[4], rw[4];
   const int nk = p.K / BK;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    ra[i] = *reinterpret_cast<const uint4*>(a_src[i]);
-    rw[i] = *reinterpret_cast<const uint4*>(w_src[i]);
+    ra[i] = *reinterpret_cast<const u32x4*>(a_src[i]);
+    rw[i] = *reinterpret_cast<const u32x4*>(w_src[i]);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<uint4*>(As + swz(ld_row + 32 * i, ld_c)) = ra[i];
-    *reinterpret_cast<uint4*>(Ws + swz(ld_row + 32 * i, ld_c)) = rw[i];
+    *reinterpret_cast<u32x4*>(As + swz(ld_row + 32 * i, ld_c)) = ra[i];
+    *reinterpret_cast<u32x4*>(Ws + swz(ld_row + 32 * i, ld_c)) = rw[i];
   }
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const uint4*>(a_src[i] + (kt + 1) * BK);
-        rw[i] = *reinterpret_cast<const uint4*>(w_src[i] + (kt + 1) * BK);
-      }
-    }
+  // One k-tile of MFMAs out of LDS buffer `cur`.
+  auto compute = [&](int cur) {
     const char* Ab = As + cur * TILE_BYTES;
     const char* Wb = Ws + cur * TILE_BYTES;
 #pragma unroll
@@ -100,17 +106,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
           acc[i][j] = SWAPPED ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0)
                               : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) {
-      char* An = As + (cur ^ 1) * TILE_BYTES;
-      char* Wn = Ws + (cur ^ 1) * TILE_BYTES;
+  };
+  // Steady state: the loads of k-tile kt+1 are issued before the MFMAs of k-tile kt and written to the other LDS
+  // buffer afterwards. The loop is peeled so the staging registers are assigned UNCONDITIONALLY in the body —
+  // a conditional prefetch makes hipcc keep them in scratch memory and wait on every load right after issuing it.
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    const int cur = kt & 1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<uint4*>(An + swz(ld_row + 32 * i, ld_c)) = ra[i];
-        *reinterpret_cast<uint4*>(Wn + swz(ld_row + 32 * i, ld_c)) = rw[i];
-      }
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const u32x4*>(a_src[i] + (kt + 1) * BK);
+      rw[i] = *reinterpret_cast<const u32x4*>(w_src[i] + (kt + 1) * BK);
+    }
+    compute(cur);
+    char* An = As + (cur ^ 1) * TILE_BYTES;
+    char* Wn = Ws + (cur ^ 1) * TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(An + swz(ld_row + 32 * i, ld_c)) = ra[i];
+      *reinterpret_cast<u32x4*>(Wn + swz(ld_row + 32 * i, ld_c)) = rw[i];
     }
     __syncthreads();
   }
+  compute((nk - 1) & 1);
 
   // ------------------------------------------------------------------ epilogue
   // normal:  acc[i][j][e] = C[m = mb + i*32 + row(e,h)][n = nb + j*32 + r]
@@ -191,7 +208,8 @@ template <int EPI, bool SW>
 static void launch_one(GemmParams p, int n_begin, int n_end, hipStream_t s) {
   if (n_end <= n_begin) return;
   p.n_begin = n_begin;
-  dim3 grid((n_end - n_begin) / BN, (p.M + BM - 1) / BM, p.batch);
+  p.n_tiles = (n_end - n_begin) / BN;
+  dim3 grid(p.n_tiles * ((p.M + BM - 1) / BM) * p.batch);
   hipLaunchKernelGGL((gemm_bf16_kernel<EPI, SW>), grid, dim3(256), 4 * TILE_BYTES, s, p);
 }
 
