@@ -29,4 +29,4 @@ def test_no_scratch_no_spills(name, tmp_path):
     bad = [(n, p) for n, p in zip(names, priv) if p != 0]
     assert not bad, f"kernels using scratch memory: {bad}"
     assert all(s == 0 for s in spills)
-    assert max(vgprs) <= 256
+    assert max(vgprs) <= 512  # unified VGPR+AGPR file on gfx950
