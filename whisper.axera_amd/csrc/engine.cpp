@@ -376,8 +376,10 @@ void Engine::ensure_capacity(int batch) {
     d_att_[i] = (bf16*)A((size_t)nbs_ * 16 * d * 2, true);
     d_hidp_[i] = (bf16*)A((size_t)nbs_ * 16 * 4 * d * 2, true);
   }
-  split_cross_ = B <= 2 ? 6 : 3;  // the VALU path serves <= 4 clips; larger batches use one split per (clip, head)
+  split_cross_ = B <= 2 ? 8 : 3;  // the VALU path serves <= 4 clips; larger batches use one split per (clip, head)
   split_self_ = 2;
+  if (const char* v = getenv("AXW_SPLIT_CROSS")) split_cross_ = std::max(1, std::min(8, atoi(v)));  // tuning aid
+  if (const char* v = getenv("AXW_SPLIT_SELF")) split_self_ = std::max(1, std::min(7, atoi(v)));
   d_part_ = (float*)A((size_t)4 * B * d * 4, true);  // split-K partials of the batched residual GEMMs
   d_part_self_ = (float*)A((size_t)B * H * split_self_ * 66 * 4, true);
   d_part_cross_ = (float*)A((size_t)B * H * split_cross_ * 66 * 4, true);
@@ -566,14 +568,14 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
   GemvParams p{};
   p.W = tok_emb_; p.bias = nullptr; p.N = cfg_.n_vocab; p.K = d;
   p.prologue = PRO_LAYERNORM; p.in = d_xdec_; p.ln_w = dec_ln_w_; p.ln_b = dec_ln_b_;
-  p.epilogue = GEPI_LOGITS; p.state = d_state_; p.amax_val = d_amax_val_; p.amax_idx = d_amax_idx_; p.amax_stride = cap_;
+  p.epilogue = GEPI_LOGITS; p.state = d_state_; p.amax_val = d_amax_val_; p.amax_idx = d_amax_idx_; p.amax_stride = n_amax_part_;
   p.skip_before_step = 3; p.logits_dump = d_logits; p.logits_dump_stride = logits_stride;
   gemv(p, [&](GemvParams& q, int b0) {
-    q.in += (long)b0 * d; q.amax_val += b0; q.amax_idx += b0;
+    q.in += (long)b0 * d; q.amax_val += (long)b0 * n_amax_part_; q.amax_idx += (long)b0 * n_amax_part_;
     if (q.logits_dump) q.logits_dump += (long)b0 * logits_stride;
   });
   AdvanceParams a{};
-  a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = gemv_grid(p); a.amax_stride = cap_;
+  a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = gemv_grid(p); a.amax_stride = n_amax_part_;
   a.state = d_state_; a.tok = d_tok_; a.done = d_done_; a.n_out = d_nout_; a.out_ids = d_out_ids_; a.batch = batch;
   a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.sot = d_sot_;
   a.forced = d_forced; a.n_forced = n_forced; a.argmax_dump = d_argmax;
@@ -664,14 +666,14 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
   ln(dec_ln_w_, dec_ln_b_);
   DecGemmParams p = base(tok_emb_packed_, nullptr, cfg_.n_vocab, d, d_act_[0], d_act_[1], GEPI_LOGITS);
   p.rt = kLogitsRT;
-  p.amax_val = d_amax_val_; p.amax_idx = d_amax_idx_; p.amax_stride = cap_;
+  p.amax_val = d_amax_val_; p.amax_idx = d_amax_idx_; p.amax_stride = n_amax_part_;
   p.skip_before_step = 3; p.logits_dump = d_logits; p.logits_dump_stride = logits_stride;
   gemm(p, [&](DecGemmParams& q, int b0) {
-    q.amax_val += b0; q.amax_idx += b0;
+    q.amax_val += (long)b0 * n_amax_part_; q.amax_idx += (long)b0 * n_amax_part_;
     if (q.logits_dump) q.logits_dump += (long)b0 * logits_stride;
   });
   AdvanceParams a{};
-  a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = decode_gemm_grid(cfg_.n_vocab, kLogitsRT); a.amax_stride = cap_;
+  a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = decode_gemm_grid(cfg_.n_vocab, kLogitsRT); a.amax_stride = n_amax_part_;
   a.state = d_state_; a.tok = d_tok_; a.done = d_done_; a.n_out = d_nout_; a.out_ids = d_out_ids_; a.batch = batch;
   a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.sot = d_sot_;
   a.forced = d_forced; a.n_forced = n_forced; a.argmax_dump = d_argmax;

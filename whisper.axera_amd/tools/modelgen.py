@@ -29,6 +29,8 @@ DIMS = {
     # reduced dims for fast parity tests (same graph, head_dim 64)
     "micro":  dict(n_mels=80,  d=128,  heads=2,  enc_layers=2,  dec_layers=2,  n_vocab=51865, n_langs=99),
     "mini":   dict(n_mels=80,  d=256,  heads=4,  enc_layers=2,  dec_layers=3,  n_vocab=51865, n_langs=99),
+    # turbo-shaped front half at reduced width: 128 mels, 100 languages (adds yue), n_vocab 51866, shallow decoder
+    "miniturbo": dict(n_mels=128, d=256, heads=4, enc_layers=3, dec_layers=2, n_vocab=51866, n_langs=100),
 }
 
 N_AUDIO_CTX = 1500
