@@ -9,11 +9,10 @@
 // every nn.Linear of the encoder blocks and the per-decoder-layer cross K/V projections.
 //
 // Tiling (wave64): 128x128 output tile, BK = 64, 256 threads = 4 waves in 2x2, each wave a
-// 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs). A and W tiles are staged
-// global -> registers -> LDS with an XOR swizzle of the 16-byte chunks (chunk ^ ((row>>1)&7))
-// which makes every ds_read_b128 fragment read conflict-free; the loads of k-tile t+1 are issued
-// before the MFMAs of k-tile t and written to the other LDS buffer afterwards (one barrier per
-// k-tile). Epilogues write the layouts the consumers want (V^T for the encoder attention, the
+// 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs). A and W tiles are staged by LDS-DMA
+// (global_load_lds, no VGPR round trip) with an XOR swizzle of the 16-byte chunks (chunk ^ ((row>>1)&7)),
+// applied on the source address, which makes every ds_read_b128 fragment read conflict-free; k-tile t+1
+// streams into the other LDS buffer while k-tile t is multiplied (one drain + barrier per k-tile). Epilogues write the layouts the consumers want (V^T for the encoder attention, the
 // blocked K / row-major V of the decoder's cross-attention) so no transposition kernel exists;
 // where the consumer wants M contiguous the MFMA operands are swapped so lanes run along M.
 #include "common.hpp"
@@ -24,6 +23,8 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KB per operand tile
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * (BK * 2) + 16 * (chunk ^ ((row >> 1) & 7)); }
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
 
 template <int EPI, bool SWAPPED>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
@@ -52,16 +53,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   const bf16* A = p.A + (long)bz * p.a_batch_stride;
   const bf16* W = p.W;
 
-  // per-thread staging coordinates: chunk t + 256*i -> row = t/8 + 32*i, col chunk = t%8
-  const int ld_row = tid >> 3, ld_c = tid & 7;
+  // Staging: LDS-DMA (global_load_lds, 16 B per lane). One wave-instruction lands 1 KiB = 8 tile rows x 128 B
+  // LINEARLY in LDS (hardware: wave-uniform base + lane*16), so the bank-conflict swizzle is applied on the SOURCE
+  // side: LDS chunk position c of row `row` receives global chunk c ^ ((row>>1)&7), and fragment reads look for
+  // global chunk g at position g ^ ((row>>1)&7) (the same involution; swz()). No VGPR staging, no ds_write.
+  const int ld_row = tid >> 3, ld_c = tid & 7;   // lane l of wave w: row 8w + l/8 (+32 i), position l%8
   const bf16* a_src[4];
   const bf16* w_src[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int ra = min(m0 + ld_row + 32 * i, p.M - 1);
-    a_src[i] = A + (long)ra * p.lda + ld_c * 8;
-    w_src[i] = W + (long)(n0 + ld_row + 32 * i) * p.K + ld_c * 8;
+    const int row = ld_row + 32 * i;
+    const int gc = ld_c ^ ((row >> 1) & 7);
+    const int ra = min(m0 + row, p.M - 1);
+    a_src[i] = A + (long)ra * p.lda + gc * 8;
+    w_src[i] = W + (long)(n0 + row) * p.K + gc * 8;
   }
+  auto stage = [&](int buf, int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = buf * TILE_BYTES + (32 * i + 8 * wave) * (BK * 2);  // wave-uniform LDS base of this 1 KiB piece
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + kt * BK), (lds_ptr_t)(As + off), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + kt * BK), (lds_ptr_t)(Ws + off), 16, 0, 0);
+    }
+  };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -71,60 +85,41 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // SWAPPED: MFMA operands exchanged so that lanes run along M (the consumer wants M contiguous)
-  constexpr bool swapped = SWAPPED;
-
-  u32x4 ra[4], rw[4];
   const int nk = p.K / BK;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ra[i] = *reinterpret_cast<const u32x4*>(a_src[i]);
-    rw[i] = *reinterpret_cast<const u32x4*>(w_src[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<u32x4*>(As + swz(ld_row + 32 * i, ld_c)) = ra[i];
-    *reinterpret_cast<u32x4*>(Ws + swz(ld_row + 32 * i, ld_c)) = rw[i];
-  }
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // One k-tile of MFMAs out of LDS buffer `cur`.
+  // One k-tile of MFMAs out of LDS buffer `cur`: the fragment reads of k-step s+1 are issued before the MFMAs of
+  // k-step s (two fragment register sets), so LDS latency hides under the matrix pipe.
   auto compute = [&](int cur) {
     const char* Ab = As + cur * TILE_BYTES;
     const char* Wb = Ws + cur * TILE_BYTES;
+    bf16x8 af[2][2], wf[2][2];
+    auto frags = [&](int s, int set) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[set][i] = *reinterpret_cast<const bf16x8*>(Ab + swz(wm * 64 + i * 32 + r, 2 * s + h));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[set][j] = *reinterpret_cast<const bf16x8*>(Wb + swz(wn * 64 + j * 32 + r, 2 * s + h));
+    };
+    frags(0, 0);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      bf16x8 af[2], wf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + swz(wm * 64 + i * 32 + r, 2 * s + h));
-#pragma unroll
-      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(Wb + swz(wn * 64 + j * 32 + r, 2 * s + h));
+      if (s < 3) frags(s + 1, (s + 1) & 1);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = SWAPPED ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0)
-                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = SWAPPED ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], wf[s & 1][j], acc[i][j], 0, 0, 0);
     }
   };
-  // Steady state: the loads of k-tile kt+1 are issued before the MFMAs of k-tile kt and written to the other LDS
-  // buffer afterwards. The loop is peeled so the staging registers are assigned UNCONDITIONALLY in the body —
-  // a conditional prefetch makes hipcc keep them in scratch memory and wait on every load right after issuing it.
+  // k-tile kt+1 streams into the other LDS buffer while k-tile kt is multiplied; one drain + barrier per k-tile.
   for (int kt = 0; kt + 1 < nk; ++kt) {
     const int cur = kt & 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const u32x4*>(a_src[i] + (kt + 1) * BK);
-      rw[i] = *reinterpret_cast<const u32x4*>(w_src[i] + (kt + 1) * BK);
-    }
+    stage(cur ^ 1, kt + 1);
     compute(cur);
-    char* An = As + (cur ^ 1) * TILE_BYTES;
-    char* Wn = Ws + (cur ^ 1) * TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4*>(An + swz(ld_row + 32 * i, ld_c)) = ra[i];
-      *reinterpret_cast<u32x4*>(Wn + swz(ld_row + 32 * i, ld_c)) = rw[i];
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   compute((nk - 1) & 1);
@@ -150,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
           if constexpr (EPI == EPI_BIAS_BF16) {
             reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] = (bf16)v;
           } else if constexpr (EPI == EPI_BIAS_GELU_BF16) {
-            reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] = (bf16)gelu_erf(v);
+            reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] = (bf16)gelu_erf_fast(v);
           } else if constexpr (EPI == EPI_GELU_POS_F32) {
             reinterpret_cast<float*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] =
                 gelu_erf(v) + p.aux[(long)m * p.N + n];
