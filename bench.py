@@ -27,6 +27,7 @@ for p in (ROOT, os.path.join(ROOT, "whisper.axera_amd", "tools")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
 
 
 def decode_step_bytes(dims, batch, step, s=2):
@@ -143,7 +144,7 @@ def main():
         rec = json.load(open(pmc_path)).get(f"{args.model}_b{B}", {}).get(fam)
         if rec:
             traffic = rec["hbm_bytes_per_launch"]
-    roofline = {"kernel": f"{fam} (decode linear layers, all shapes)", "bound": "hbm", "achieved": round(fam_gbs, 1),
+    roofline = {"kernel": f"{fam}{'/gemv1_kernel' if small_batch else ''} (decode linear layers, all shapes)", "bound": "hbm", "achieved": round(fam_gbs, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fam_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches_per_decode_step": n_launch, "avg_launch_us": round(per_launch_s * 1e6, 3),
                 "bytes_per_launch": int(w_bytes / n_launch),
@@ -151,6 +152,17 @@ def main():
                                 "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
                 "decode_attention": {"ms_per_step": round(ms_attn, 4), "algorithmic_GBs": round(attn_gbs, 1),
                                      "frac_of_hbm_peak": round(attn_gbs / HBM_PEAK_GBS, 4)}}
+
+    # ---- the other two stages against their own rooflines: encoder = MFMA-bound, front-end = HBM-bound
+    enc_flop = {"tiny": 40.48e9, "small": 386.63e9, "turbo": 2313.09e9}.get(args.model)
+    ms_enc = eng.bench("encoder", B, 0, 5) / 5
+    ms_fe = eng.bench("frontend", B, 0, 10) / 10
+    stages = {"frontend": {"ms": round(ms_fe, 4), "GBs": round(B * (4 * n_samp + 2 * dims["n_mels"] * 3000) / (ms_fe * 1e-3) / 1e9, 1),
+                           "bound": "hbm"}}
+    if enc_flop:
+        tf = enc_flop * B / (ms_enc * 1e-3) / 1e12
+        stages["encoder"] = {"ms": round(ms_enc, 3), "TFLOPs": round(tf, 1), "bound": "mfma", "peak": MFMA_BF16_PEAK_TF,
+                             "frac": round(tf / MFMA_BF16_PEAK_TF, 4)}
 
     out = {
         "metric": "clips_per_sec (30 s clips, greedy decode, whisper-%s)" % args.model,
@@ -163,6 +175,7 @@ def main():
         "rtf": round(dt / args.steps / (B * 30.0), 6),
         "stage_ms": {k: round(v / args.steps, 3) for k, v in stage.items() if k != "steps"},
         "roofline": roofline,
+        "stage_rooflines": stages,
     }
 
     # ---- CPU baseline: the oracle ("port") on this box's host cores, one clip of the same workload

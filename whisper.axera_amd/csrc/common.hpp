@@ -141,7 +141,6 @@ struct GemvParams {
   float* logits_dump;              // optional logits row of this step for clip b at logits_dump + b*logits_dump_stride
   long logits_dump_stride;
   int skip_before_step;            // GEPI_LOGITS: do nothing while state->step < this (SOT steps)
-  int debug;                       // timing experiments only
 };
 void launch_gemv(const GemvParams& p, hipStream_t s);
 int gemv_grid(const GemvParams& p);  // number of workgroups launch_gemv will use
@@ -179,7 +178,6 @@ struct DecGemmParams {
   float* logits_dump; long logits_dump_stride;
   int skip_before_step;
   int ksplit; int part_batch;              // GEPI_PARTIAL: K slices (grid.y) and the clip stride of the partial buffer
-  int debug;                               // timing experiments only
 };
 void launch_decode_gemm(const DecGemmParams& p, hipStream_t s);
 int decode_gemm_grid(int N, int rt);

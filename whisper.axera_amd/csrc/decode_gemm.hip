@@ -154,7 +154,6 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
   // trip); longer K rotates the sets. Every load is one contiguous 1 KiB wave access.
   struct Frag { bf16x8 w[RT], h[NB], l[NB]; };
   auto load = [&](Frag& f, int ks) {
-    if (p.debug & 4) return;
 #pragma unroll
     for (int t = 0; t < RT; ++t) f.w[t] = *reinterpret_cast<const bf16x8*>(wrow[t] + (long)ks * 512);
 #pragma unroll
@@ -164,7 +163,6 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
     }
   };
   auto mma = [&](const Frag& f) {
-    if (p.debug & 2) return;
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -173,9 +171,7 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
         acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t], f.l[c], acc[t][c], 0, 0, 0);
       }
   };
-  const int dbg = p.debug;  // timing experiments only (AXW_DEBUG_GEMM): 1 no epilogue stores, 2 no MFMA, 4 no loads
   Frag f0, f1, f2;
-  if (dbg & 4) { f0 = Frag{}; f1 = Frag{}; f2 = Frag{}; }
   if (wave < KS) load(f0, wave);
   if (wave + 8 < KS) load(f1, wave + 8);
   if (wave + 16 < KS) load(f2, wave + 16);
@@ -217,7 +213,6 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
 #pragma unroll
     for (int w = 0; w < 8; ++w) y += red[(((w * RT + t) * NB + c) * 16 + bb) * 16 + nn];
     if (n >= p.N || b >= p.batch) continue;
-    if ((p.debug & 1) && y != 12345.f) continue;
     if (p.epilogue == GEPI_PARTIAL) {  // split-K slice: plain partial sums, folded (with the bias) by the consumer
       p.out[((long)blockIdx.y * p.part_batch + b) * p.N + n] = y;
       continue;
@@ -280,14 +275,9 @@ static void launch_nb(const DecGemmParams& p, hipStream_t s) {
 }
 
 // p.batch <= 64 per launch (the engine tiles larger batches); K % 128 == 0.
-void launch_decode_gemm(const DecGemmParams& p0, hipStream_t s) {
-  static const int dbg = getenv("AXW_DEBUG_GEMM") ? atoi(getenv("AXW_DEBUG_GEMM")) : 0;
-  DecGemmParams p = p0;
-  p.debug = dbg;
+void launch_decode_gemm(const DecGemmParams& p, hipStream_t s) {
   if (p.K % 128 != 0) { fprintf(stderr, "[ax_whisper] launch_decode_gemm: unsupported K=%d\n", p.K); abort(); }
-  static const int dbg_rt = getenv("AXW_DEBUG_RT") ? atoi(getenv("AXW_DEBUG_RT")) : 0;  // tuning aid
-  int rt = p.rt;
-  if (dbg_rt && rt == 4 && p.epilogue != GEPI_LOGITS) rt = dbg_rt;
+  const int rt = p.rt;
   if (rt == 4) launch_nb<4>(p, s);
   else if (rt == 2) launch_nb<2>(p, s);
   else launch_nb<1>(p, s);

@@ -118,10 +118,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p, int rows_per_wg
 
   // ---- 1. first row's weights: issued before anything that depends on the activations
   uint4 wnext[CH];
-  if (p.debug & 4) {
-#pragma unroll
-    for (int i = 0; i < CH; ++i) wnext[i] = make_uint4(0, 0, 0, 0);
-  } else {
+  {
     const int n = min(row_begin + rsub, row_end - 1);
     const bf16* wrow = p.W + (long)n * K;
 #pragma unroll
@@ -144,9 +141,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p, int rows_per_wg
   }
 
   // ---- 2. prologue: activation rows -> LDS
-  if (p.debug & 2) {
-    for (int i = tid; i < BT * K; i += 256) act[i] = 1.f;
-  } else if (p.prologue == PRO_LAYERNORM) {
+  if (p.prologue == PRO_LAYERNORM) {
     prologue_layernorm<BT>(p, act, s_red);
   } else if (p.prologue == PRO_ATTN_COMBINE) {
     prologue_attn_combine<BT>(p, act);
@@ -201,7 +196,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p, int rows_per_wg
 #pragma unroll
       for (int o = LPR / 2; o > 0; o >>= 1) acc[b] += __shfl_xor(acc[b], o, 64);
 
-    if (j == 0 && valid && !((p.debug & 1) && acc[0] != 12345.f)) {
+    if (j == 0 && valid) {
       const bool first = row0 == row_begin;
       const float bias = first ? bias0 : (p.bias ? p.bias[n] : 0.f);
 #pragma unroll
@@ -462,10 +457,7 @@ static bool launch_gemv_ch(const GemvParams& p, int rpw, int grid, hipStream_t s
 
 // Handles p.batch <= 4 per launch; the engine tiles larger batches. K must be one of the supported
 // widths (multiples of 128 with <= 10 chunks per lane): every Whisper size is.
-void launch_gemv(const GemvParams& p0, hipStream_t s) {
-  static const int dbg = getenv("AXW_DEBUG_GEMV") ? atoi(getenv("AXW_DEBUG_GEMV")) : 0;  // timing experiments only
-  GemvParams p = p0;
-  p.debug = dbg;
+void launch_gemv(const GemvParams& p, hipStream_t s) {
   const int lpr = pick_lpr(p.K);
   bool ok = lpr != 0;
   if (ok) {

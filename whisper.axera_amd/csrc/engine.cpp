@@ -378,8 +378,6 @@ void Engine::ensure_capacity(int batch) {
   }
   split_cross_ = B <= 2 ? 8 : 3;  // the VALU path serves <= 4 clips; larger batches use one split per (clip, head)
   split_self_ = 2;
-  if (const char* v = getenv("AXW_SPLIT_CROSS")) split_cross_ = std::max(1, std::min(8, atoi(v)));  // tuning aid
-  if (const char* v = getenv("AXW_SPLIT_SELF")) split_self_ = std::max(1, std::min(7, atoi(v)));
   d_part_ = (float*)A((size_t)4 * B * d * 4, true);  // split-K partials of the batched residual GEMMs
   d_part_self_ = (float*)A((size_t)B * H * split_self_ * 66 * 4, true);
   d_part_cross_ = (float*)A((size_t)B * H * split_cross_ * 66 * 4, true);
@@ -520,8 +518,7 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
 
   const long self_stride = (long)H * Tc * 64, cross_stride = (long)H * t_pad_ * 64;
   for (int l = 0; l < L; ++l) {
-    static const bool dbg_same = getenv("AXW_DEBUG_SAME_LAYER_WEIGHTS") != nullptr;  // timing experiment only
-    const DecLayerW& w = dec_[dbg_same ? 0 : l];
+    const DecLayerW& w = dec_[l];
     bf16* sk = d_self_k_ + (size_t)l * cap_ * self_stride;
     bf16* sv = d_self_v_ + (size_t)l * cap_ * self_stride;
     const bf16* ck = d_cross_k_ + (size_t)l * cap_ * cross_stride;
