@@ -84,3 +84,50 @@ def test_corrupt_model_directories_fail_with_a_message(built_lib, micro_case, tm
     modelgen.write_model_dir(str(d3), "micro", micro_case.dims, weights=w)
     assert L.AX_WHISPER_Init(b"micro", str(d3).encode(), b"zh") is None
     assert b"decoder.ln.weight" in L.AX_WHISPER_LastError(None)
+
+
+def _write_wav(path, data, rate=16000, fmt="int16"):
+    """data: float array [n] or [n, ch] in [-1, 1)."""
+    import struct
+
+    a = np.atleast_2d(np.asarray(data, dtype=np.float64).T).T  # [n, ch]
+    n, ch = a.shape
+    if fmt == "int16":
+        raw, bits, tag = (np.round(a * 32768).clip(-32768, 32767).astype("<i2")).tobytes(), 16, 1
+    elif fmt == "int24":
+        v = np.round(a * 8388608).clip(-8388608, 8388607).astype(np.int32).reshape(-1)
+        raw, bits, tag = b"".join(int(x).to_bytes(3, "little", signed=True) for x in v), 24, 1
+    elif fmt == "int32":
+        raw, bits, tag = (np.round(a * 2147483648).clip(-2147483648, 2147483647).astype("<i4")).tobytes(), 32, 1
+    elif fmt == "float32":
+        raw, bits, tag = a.astype("<f4").tobytes(), 32, 3
+    else:
+        raise ValueError(fmt)
+    blk = ch * bits // 8
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, tag, ch, rate, rate * blk, blk, bits)
+    # an extra chunk before "data" must be skipped by the reader
+    hdr += b"LIST" + struct.pack("<I", 4) + b"abcd"
+    with open(path, "wb") as f:
+        f.write(hdr + b"data" + struct.pack("<I", len(raw)) + raw)
+
+
+def test_wav_ingest_formats(built_lib, micro_case, tmp_path):
+    """AX_WHISPER_RunFile: int16 -> /32768 (AudioFile.h:1241-1243), stereo -> (L+R)/2 (ax_whisper_api.cpp:105-113); plus the
+    int24 / int32 / float32 encodings AudioFile also reads."""
+    e = built_lib.Whisper("micro", micro_case.root, "zh", device=0)
+    pcm = load_demo_pcm()[:40000].astype(np.float64)
+    q16 = np.round(pcm * 32768) / 32768  # exactly representable in every format below
+    want = e.run(q16.astype(np.float32))
+    for fmt in ("int16", "int24", "int32", "float32"):
+        p = str(tmp_path / f"mono_{fmt}.wav")
+        _write_wav(p, q16, fmt=fmt)
+        assert e.run(p) == want, fmt
+    # stereo: L = x + d, R = x - d  -> (L+R)/2 == x
+    d = 0.25 * np.sin(np.arange(len(q16)) * 0.01)
+    d = np.round(d * 32768) / 32768
+    st = np.stack([np.clip(q16 + d, -1, 1 - 2 ** -15), np.clip(q16 - d, -1, 1 - 2 ** -15)], axis=1)
+    mono = ((st[:, 0].astype(np.float32) + st[:, 1].astype(np.float32)) / 2).astype(np.float32)
+    p = str(tmp_path / "stereo.wav")
+    _write_wav(p, st, fmt="int16")
+    assert e.run(p) == e.run(mono)
+    e.close()

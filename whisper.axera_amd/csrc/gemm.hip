@@ -26,6 +26,83 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * (BK * 2) +
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 
+// Epilogue of one wave's 64x64 sub-tile (2x2 accumulator tiles), shared by both tile shapes.
+template <int EPI, bool SWAPPED>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][2], int mb, int nb, int bz, int r, int h) {
+  // ------------------------------------------------------------------ epilogue
+  // normal:  acc[i][j][e] = C[m = mb + i*32 + row(e,h)][n = nb + j*32 + r]
+  // swapped: acc[i][j][e] = C[m = mb + i*32 + r][n = nb + j*32 + row(e,h)],  row(e,h) = (e&3) + 8*(e>>2) + 4*h
+  const int d = p.d_model;
+
+  if constexpr (!SWAPPED) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = nb + j * 32 + r;
+      const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = mb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (m >= p.M) continue;
+          float v = acc[i][j][e] + bias;
+          if constexpr (EPI == EPI_BIAS_BF16) {
+            reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] = (bf16)v;
+          } else if constexpr (EPI == EPI_BIAS_GELU_BF16) {
+            reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] = (bf16)gelu_erf_fast(v);
+          } else if constexpr (EPI == EPI_GELU_POS_F32) {
+            reinterpret_cast<float*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] =
+                gelu_erf(v) + p.aux[(long)m * p.N + n];
+          } else if constexpr (EPI == EPI_RESID_F32) {
+            float* c = reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n;
+            *c += v;
+          } else if constexpr (EPI == EPI_QKV) {  // Q (n < d) or K (d <= n < 2d), both bf16 [m][d]
+            if (n < d) reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * d + n] = (bf16)v;
+            else reinterpret_cast<bf16*>(p.C2)[(long)bz * p.c2_batch_stride + (long)m * d + (n - d)] = (bf16)v;
+          } else {  // EPI_CROSS_KV, V rows [n_layer*d, 2*n_layer*d): [l][slot][head][t_pad][64]
+            const int nv = n - p.n_layer * d;
+            const int l = nv / d, c = nv - l * d;
+            const int head = c >> 6, dd = c & 63;
+            const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + head;
+            reinterpret_cast<bf16*>(p.C2)[(slot * p.t_pad + m) * 64 + dd] = (bf16)v;
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mb + i * 32 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (EPI == EPI_QKV) {  // V^T [head][64][t_pad], lanes run along m (coalesced)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int n = nb + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float v = acc[i][j][e] + (p.bias ? p.bias[n] : 0.f);
+            const int c = n - 2 * d;
+            reinterpret_cast<bf16*>(p.C3)[(long)bz * p.c3_batch_stride + (long)c * p.t_pad + m] = (bf16)v;
+          }
+        } else {  // EPI_CROSS_KV K rows [0, n_layer*d): blocked [l][slot][head][m/64][dd/8][m%64][8]; 4 consecutive dd per quad
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = nb + j * 32 + 8 * q + 4 * h;
+            const int l = n / d, c = n - l * d;
+            const int head = c >> 6, dd = c & 63;
+            bf16x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = (bf16)(acc[i][j][4 * q + e] + (p.bias ? p.bias[n + e] : 0.f));
+            const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + head;
+            bf16* dst = reinterpret_cast<bf16*>(p.C) + slot * p.t_pad * 64 + (long)(m >> 6) * 4096 + (dd >> 3) * 512 + (m & 63) * 8 + (dd & 7);
+            *reinterpret_cast<bf16x4*>(dst) = pk;
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int EPI, bool SWAPPED>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -124,79 +201,109 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   }
   compute((nk - 1) & 1);
 
-  // ------------------------------------------------------------------ epilogue
-  // normal:  acc[i][j][e] = C[m = mb + i*32 + row(e,h)][n = nb + j*32 + r]
-  // swapped: acc[i][j][e] = C[m = mb + i*32 + r][n = nb + j*32 + row(e,h)],  row(e,h) = (e&3) + 8*(e>>2) + 4*h
-  const int mb = m0 + wm * 64, nb = n0 + wn * 64;
-  const int d = p.d_model;
+  gemm_epilogue<EPI, SWAPPED>(p, acc, m0 + wm * 64, n0 + wn * 64, bz, r, h);
+}
 
-  if constexpr (!SWAPPED) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = nb + j * 32 + r;
-      const float bias = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = mb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (m >= p.M) continue;
-          float v = acc[i][j][e] + bias;
-          if constexpr (EPI == EPI_BIAS_BF16) {
-            reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] = (bf16)v;
-          } else if constexpr (EPI == EPI_BIAS_GELU_BF16) {
-            reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] = (bf16)gelu_erf_fast(v);
-          } else if constexpr (EPI == EPI_GELU_POS_F32) {
-            reinterpret_cast<float*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] =
-                gelu_erf(v) + p.aux[(long)m * p.N + n];
-          } else if constexpr (EPI == EPI_RESID_F32) {
-            float* c = reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n;
-            *c += v;
-          } else if constexpr (EPI == EPI_QKV) {  // Q (n < d) or K (d <= n < 2d), both bf16 [m][d]
-            if (n < d) reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * d + n] = (bf16)v;
-            else reinterpret_cast<bf16*>(p.C2)[(long)bz * p.c2_batch_stride + (long)m * d + (n - d)] = (bf16)v;
-          } else {  // EPI_CROSS_KV, V rows [n_layer*d, 2*n_layer*d): [l][slot][head][t_pad][64]
-            const int nv = n - p.n_layer * d;
-            const int l = nv / d, c = nv - l * d;
-            const int head = c >> 6, dd = c & 63;
-            const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + head;
-            reinterpret_cast<bf16*>(p.C2)[(slot * p.t_pad + m) * 64 + dd] = (bf16)v;
-          }
-        }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = mb + i * 32 + r;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if constexpr (EPI == EPI_QKV) {  // V^T [head][64][t_pad], lanes run along m (coalesced)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int n = nb + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const float v = acc[i][j][e] + (p.bias ? p.bias[n] : 0.f);
-            const int c = n - 2 * d;
-            reinterpret_cast<bf16*>(p.C3)[(long)bz * p.c3_batch_stride + (long)c * p.t_pad + m] = (bf16)v;
-          }
-        } else {  // EPI_CROSS_KV K rows [0, n_layer*d): blocked [l][slot][head][m/64][dd/8][m%64][8]; 4 consecutive dd per quad
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int n = nb + j * 32 + 8 * q + 4 * h;
-            const int l = n / d, c = n - l * d;
-            const int head = c >> 6, dd = c & 63;
-            bf16x4 pk;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = (bf16)(acc[i][j][4 * q + e] + (p.bias ? p.bias[n + e] : 0.f));
-            const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + head;
-            bf16* dst = reinterpret_cast<bf16*>(p.C) + slot * p.t_pad * 64 + (long)(m >> 6) * 4096 + (dd >> 3) * 512 + (m & 63) * 8 + (dd & 7);
-            *reinterpret_cast<bf16x4*>(dst) = pk;
-          }
-        }
-      }
-    }
+// ---------------------------------------------------------------------------- 256 x 128 tile, 3-stage LDS-DMA ring
+// Used when the launch has enough tiles to fill the chip (batched encoder). Same per-wave 64x64 sub-tile and the
+// same swizzled LDS image as above, but 8 waves (4 along M x 2 along N) share a 256x128 output tile, so a k-tile
+// costs 48 KB of staging for twice the MFMAs (1.33x the arithmetic intensity), and the ring is three k-tiles deep:
+// two k-tiles (96 KB) are in flight while one is multiplied. The waits are COUNTED (`s_waitcnt vmcnt(6)` leaves the
+// youngest k-tile's 6 LDS-DMA pieces per wave in flight) and the barrier is a raw `s_barrier`: `__syncthreads()`
+// would drain the LDS-DMA queue. A staged buffer is read only after [own vmcnt wait -> barrier], and refilled only
+// after the barrier that follows its last read (cdna guide: "read a staged buffer one phase after the wait").
+constexpr int BM2 = 256;
+constexpr int A2_BYTES = BM2 * BK * 2;   // 32 KB
+constexpr int W2_BYTES = BN * BK * 2;    // 16 KB
+constexpr int STAGE2_BYTES = A2_BYTES + W2_BYTES;
+
+template <int EPI, bool SWAPPED>
+__global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][A 32 KB | W 16 KB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  int n0, m0, bz;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+    const int nt = p.n_tiles, mt = (p.M + BM2 - 1) / BM2;
+    n0 = p.n_begin + (wg % nt) * BN;
+    const int rest = wg / nt;
+    m0 = (rest % mt) * BM2;
+    bz = rest / mt;
   }
+  const bf16* A = p.A + (long)bz * p.a_batch_stride;
+  const bf16* W = p.W;
+
+  const int ld_row = tid >> 3, ld_c = tid & 7;  // lane l of wave w: tile row 8w + l/8 (+64 i), chunk position l%8
+  const bf16* a_src[4];
+  const bf16* w_src[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = ld_row + 64 * i;
+    a_src[i] = A + (long)min(m0 + row, p.M - 1) * p.lda + (ld_c ^ ((row >> 1) & 7)) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = ld_row + 64 * i;
+    w_src[i] = W + (long)(n0 + row) * p.K + (ld_c ^ ((row >> 1) & 7)) * 8;
+  }
+  auto stage = [&](int buf, int kt) {  // 6 LDS-DMA pieces (1 KiB each) per wave
+    char* base = smem + buf * STAGE2_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + kt * BK), (lds_ptr_t)(base + (64 * i + 8 * wave) * (BK * 2)), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + kt * BK), (lds_ptr_t)(base + A2_BYTES + (64 * i + 8 * wave) * (BK * 2)), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto compute = [&](int buf) {
+    const char* Ab = smem + buf * STAGE2_BYTES;
+    const char* Wb = Ab + A2_BYTES;
+    bf16x8 af[2][2], wf[2][2];
+    auto frags = [&](int s, int set) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[set][i] = *reinterpret_cast<const bf16x8*>(Ab + swz(wm * 64 + i * 32 + r, 2 * s + h));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[set][j] = *reinterpret_cast<const bf16x8*>(Wb + swz(wn * 64 + j * 32 + r, 2 * s + h));
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < 3) frags(s + 1, (s + 1) & 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = SWAPPED ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], wf[s & 1][j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  if (nk > 1) stage(1, 1);
+  for (int kt = 0; kt < nk; ++kt) {
+    // k-tile kt has landed once at most the younger k-tile's 6 pieces are still outstanding
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's pieces of k-tile kt are in LDS; every wave is done reading k-tile kt-1
+    if (kt + 2 < nk) stage((kt + 2) % 3, kt + 2);  // refills the buffer k-tile kt-1 was read from
+    compute(kt % 3);
+  }
+  gemm_epilogue<EPI, SWAPPED>(p, acc, m0 + wm * 64, n0 + wn * 64, bz, r, h);
 }
 
 template <int EPI, bool SW>
@@ -204,6 +311,11 @@ static void launch_one(GemmParams p, int n_begin, int n_end, hipStream_t s) {
   if (n_end <= n_begin) return;
   p.n_begin = n_begin;
   p.n_tiles = (n_end - n_begin) / BN;
+  const int tiles256 = p.n_tiles * ((p.M + BM2 - 1) / BM2) * p.batch;
+  if (tiles256 >= 256 && p.K >= 2 * BK) {  // enough 256-row tiles for every CU: deep-ring kernel
+    hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SW>), dim3(tiles256), dim3(512), 3 * STAGE2_BYTES, s, p);
+    return;
+  }
   dim3 grid(p.n_tiles * ((p.M + BM - 1) / BM) * p.batch);
   hipLaunchKernelGGL((gemm_bf16_kernel<EPI, SW>), grid, dim3(256), 4 * TILE_BYTES, s, p);
 }
