@@ -196,6 +196,24 @@ struct AdvanceParams {
 };
 void launch_advance(const AdvanceParams& p, hipStream_t s);
 
+// ---- persistent batch-1 decode (decode_persistent.hip): the whole greedy loop of one clip in ONE launch
+typedef unsigned long long u64;
+struct PersistParams {
+  const DecLayerW* layers;      // device array [n_layer]
+  const bf16* tok_emb; const float* pos; const float* ln_w; const float* ln_b;
+  const bf16* cross_k; const bf16* cross_v; long cross_layer_stride;  // this clip's slot, layer 0
+  int n_layer, n_vocab, n_ctx, n_audio_ctx;
+  int eot, max_new, total_steps;
+  const int* sot;               // device [4]
+  const int* forced; int n_forced; float* logits_dump; int* argmax_dump;   // teacher forcing (tests)
+  u64* gran; unsigned* err;     // granule area + error word, zeroed before every launch
+  int* out_ids; int* n_out; DecState* state;
+};
+bool decode_persistent_supported(int d_model, int n_head, int n_layer, int n_cu);
+int decode_persistent_grid(int d_model, int n_cu);
+size_t decode_persistent_gran_bytes(int d_model, int grid);   // granule area; the error word sits in its last 8 bytes
+hipError_t launch_decode_persistent(const PersistParams& p, int d_model, int grid, hipStream_t s);
+
 // weight preparation (device): raw file dtype -> bf16 / fp32, with the layout changes the kernels want
 void launch_convert_to_bf16(const void* src, int src_dtype /*0 f32,1 bf16,2 f16*/, bf16* dst, long n, hipStream_t s);
 void launch_convert_to_f32(const void* src, int src_dtype, float* dst, long n, hipStream_t s);

@@ -48,6 +48,22 @@ Engine::Engine(const std::string& model_type, const std::string& model_path, con
     max_batch = e ? atoi(e) : 1;
   }
   HIP_CHECK(hipHostMalloc((void**)&h_poll_, 64 * sizeof(int), hipHostMallocDefault));
+  {  // persistent batch-1 decode: one workgroup per CU for the whole utterance (decode_persistent.hip)
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device_));
+    const char* mode = getenv("AX_WHISPER_DECODE");
+    const bool want = !(mode && std::string(mode) == "graph");
+    persistent_ok_ = want && decode_persistent_supported(cfg_.n_text_state, cfg_.n_text_head, cfg_.n_text_layer, prop.multiProcessorCount);
+    if (persistent_ok_) {
+      persist_grid_ = decode_persistent_grid(cfg_.n_text_state, prop.multiProcessorCount);
+      gran_bytes_ = decode_persistent_gran_bytes(cfg_.n_text_state, persist_grid_);
+      d_gran_ = (u64*)dalloc(gran_bytes_, true);
+      allocs_.push_back(d_gran_);
+      d_layers_ = (DecLayerW*)dalloc(dec_.size() * sizeof(DecLayerW));
+      allocs_.push_back(d_layers_);
+      HIP_CHECK(hipMemcpy(d_layers_, dec_.data(), dec_.size() * sizeof(DecLayerW), hipMemcpyHostToDevice));
+    }
+  }
   ensure_capacity(std::max(1, max_batch));
   HIP_CHECK(hipStreamSynchronize(own_stream_));
 }
@@ -703,6 +719,12 @@ hipGraphExec_t Engine::step_graph(int batch, int max_new) {
 int Engine::greedy_loop(int batch, int max_new) {
   const int Tc = cfg_.n_text_ctx;
   if (max_new <= 0 || max_new > Tc - 4) max_new = Tc - 4;
+  if (batch == 1 && persistent_ok_) {
+    const int steps = run_persistent(max_new, nullptr, 0, nullptr, nullptr);
+    if (steps >= 0) return steps;
+    // the persistent launch gave up (it needs every workgroup resident at once): use the launch-per-phase path from now on
+    persistent_ok_ = false;
+  }
   reset_decode_state(batch);
   hipGraphExec_t g = step_graph(batch, max_new);
   hipStream_t s = stream();
@@ -724,6 +746,36 @@ int Engine::greedy_loop(int batch, int max_new) {
     }
   }
   return steps;
+}
+
+int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float* d_logits, int* d_argmax) {
+  hipStream_t s = stream();
+  const int Tc = cfg_.n_text_ctx, H = cfg_.n_text_head;
+  PersistParams p{};
+  p.layers = d_layers_;
+  p.tok_emb = tok_emb_; p.pos = dec_pos_; p.ln_w = dec_ln_w_; p.ln_b = dec_ln_b_;
+  p.cross_k = d_cross_k_; p.cross_v = d_cross_v_;  // slot 0
+  p.cross_layer_stride = (long)cap_ * H * t_pad_ * 64;
+  p.n_layer = cfg_.n_text_layer; p.n_vocab = cfg_.n_vocab; p.n_ctx = Tc; p.n_audio_ctx = cfg_.n_audio_ctx;
+  p.eot = cfg_.eot; p.max_new = max_new;
+  p.total_steps = d_forced || d_logits || d_argmax ? 4 + n_forced : std::min(Tc, 4 + max_new);
+  p.sot = d_sot_;
+  p.forced = d_forced; p.n_forced = n_forced; p.logits_dump = d_logits; p.argmax_dump = d_argmax;
+  p.gran = d_gran_;
+  p.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(d_gran_) + gran_bytes_ - 8);
+  p.out_ids = d_out_ids_; p.n_out = d_nout_; p.state = d_state_;
+  HIP_CHECK(hipMemsetAsync(d_gran_, 0, gran_bytes_, s));
+  HIP_CHECK(hipMemsetAsync(d_state_, 0, sizeof(DecState), s));
+  HIP_CHECK(hipMemsetAsync(d_nout_, 0, 4, s));
+  HIP_CHECK(launch_decode_persistent(p, cfg_.n_text_state, persist_grid_, s));
+  HIP_CHECK(hipMemcpyAsync(&h_poll_[8], p.err, 4, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipMemcpyAsync(&h_poll_[9], &d_state_->step, 4, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  if (h_poll_[8] != 0) {
+    fprintf(stderr, "[ax_whisper] persistent decode gave up (code 0x%x); falling back to the launch-per-phase path\n", (unsigned)h_poll_[8]);
+    return -1;
+  }
+  return h_poll_[9];
 }
 
 void Engine::fetch_ids(int batch, int32_t* ids, int* n_ids) {
@@ -828,8 +880,13 @@ void Engine::decode_forced(int batch, const int32_t* forced, int n_forced, float
   HIP_CHECK(hipMalloc((void**)&d_arg, (size_t)batch * rows * 4));
   if (logits) HIP_CHECK(hipMalloc((void**)&d_logits, (size_t)batch * rows * nv * 4));
   if (n_forced) HIP_CHECK(hipMemcpy(d_forced, forced, (size_t)batch * n_forced * 4, hipMemcpyHostToDevice));
-  reset_decode_state(batch);
-  for (int st = 0; st < 4 + n_forced; ++st) {
+  bool done = false;
+  if (batch == 1 && persistent_ok_) {
+    if (run_persistent(cfg_.n_text_ctx, d_forced, n_forced, d_logits, d_arg) >= 0) done = true;
+    else persistent_ok_ = false;
+  }
+  if (!done) reset_decode_state(batch);
+  for (int st = 0; !done && st < 4 + n_forced; ++st) {
     const int gi = st - 3;
     float* lrow = (d_logits && gi >= 0) ? d_logits + (size_t)gi * nv : nullptr;
     enqueue_decode_step(batch, cfg_.n_text_ctx, d_forced, n_forced, lrow, (long)rows * nv, d_arg);

@@ -74,6 +74,8 @@ class Engine {
                                    long logits_stride, int* d_argmax);
   hipGraphExec_t step_graph(int batch, int max_new);
   int greedy_loop(int batch, int max_new);
+  // batch 1: the whole loop as one persistent launch (decode_persistent.hip); returns steps run, -1 if it gave up
+  int run_persistent(int max_new, const int* d_forced, int n_forced, float* d_logits, int* d_argmax);
   void fetch_ids(int batch, int32_t* ids, int* n_ids);
 
   ModelConfig cfg_;
@@ -118,6 +120,11 @@ class Engine {
   int* h_poll_ = nullptr;  // pinned
   int split_self_ = 2, split_cross_ = 6;
   int step_mask_ = 15;  // bench only: 1 GEMV/GEMM launches, 2 attention launches, 4 advance, 8 act_prep
+  // persistent batch-1 decode
+  bool persistent_ok_ = false;      // model shape supported and not disabled (AX_WHISPER_DECODE=graph)
+  int persist_grid_ = 0;
+  DecLayerW* d_layers_ = nullptr;   // device copy of dec_
+  u64* d_gran_ = nullptr; size_t gran_bytes_ = 0;
   std::map<long, hipGraphExec_t> graphs_;  // key: batch * 1024 + max_new
   hipEvent_t ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
