@@ -26,7 +26,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // phases alternate between (Din=a -> Dout=b) and (Din=b -> Dout=a)
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void chain(u64* bufs, int bufstride, const unsigned short* W, long wstride, int nw,
-                                                    int a, int b, int nphase, unsigned* tmo, int sleep_n, long long* stamps) {
+                                                    int a, int b, int nphase, unsigned* tmo, int sleep_n, long long* stamps, int late_w, int R, long rep_stride) {
   extern __shared__ float vec[];  // [max(a,b)]
   __shared__ float red[WAVES * 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -50,10 +50,10 @@ __global__ __launch_bounds__(WAVES * 64) void chain(u64* bufs, int bufstride, co
       const int r = r0 + wave + rr * WAVES;
 #pragma unroll
       for (int c = 0; c < MAXC; ++c)
-        if (r < r1 && c < nch) wreg[rr][c] = *reinterpret_cast<const uint2*>(Wp + (long)r * din + c * 256 + lane * 4);
+        if (!late_w && r < r1 && c < nch) wreg[rr][c] = *reinterpret_cast<const uint2*>(Wp + (long)r * din + c * 256 + lane * 4);
     }
     // ---- gather
-    gu64* in = (gu64*)(bufs + (long)(p & 1) * bufstride);
+    gu64* in = (gu64*)(bufs + (long)(wg % R) * rep_stride + (long)(p & 1) * bufstride);
     int failed = 0;
     {
       const int per = (din + WAVES * 64 - 1) / (WAVES * 64);
@@ -73,6 +73,15 @@ __global__ __launch_bounds__(WAVES * 64) void chain(u64* bufs, int bufstride, co
       }
     }
     if (__syncthreads_or(failed)) return;  // uniform give-up
+    if (late_w) {
+#pragma unroll
+      for (int rr = 0; rr < MAXR; ++rr) {
+        const int r = r0 + wave + rr * WAVES;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+          if (r < r1 && c < nch) wreg[rr][c] = *reinterpret_cast<const uint2*>(Wp + (long)r * din + c * 256 + lane * 4);
+      }
+    }
     const long long t1 = wall_clock64();
     // ---- LayerNorm statistics (every wave redundantly) + rows
     float s1 = 0.f, s2 = 0.f;
@@ -99,8 +108,8 @@ __global__ __launch_bounds__(WAVES * 64) void chain(u64* bufs, int bufstride, co
             acc = fmaf(__uint_as_float(u1 & 0xffff0000u), (v.w - mean) * rstd, acc);
           }
         acc = wave_sum(acc);
-        if (lane == 0)
-          __hip_atomic_store(out + r, ((u64)(epoch + 1) << 32) | __float_as_uint(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < R)
+          __hip_atomic_store(out + (long)lane * rep_stride + r, ((u64)(epoch + 1) << 32) | __float_as_uint(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     const long long t3 = wall_clock64();
@@ -114,18 +123,19 @@ static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (uns
 
 static long long* stamps;
 template <int WAVES>
-static void run(int P, int a, int b, int nphase, int nw, int sleep_n, const unsigned short* dW, long wstride, u64* bufs, int bufstride, unsigned* tmo) {
+static void run(int P, int a, int b, int nphase, int nw, int sleep_n, int late_w, int R, const unsigned short* dW, long wstride, u64* bufs, int bufstride, unsigned* tmo) {
   hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  std::vector<u64> init(bufstride * 2, 0);
-  for (int i = 0; i < a; ++i) { float v = sinf(0.37f * i); unsigned u; memcpy(&u, &v, 4); init[i] = (1ull << 32) | u; }
+  const long rep_stride = 2 * bufstride + 512 + 64;  // odd number of 512-byte units apart
+  std::vector<u64> init(rep_stride * 32, 0);
+  for (int r = 0; r < 32; ++r) for (int i = 0; i < a; ++i) { float v = sinf(0.37f * i); unsigned u; memcpy(&u, &v, 4); init[r * rep_stride + i] = (1ull << 32) | u; }
   float best = 1e30f;
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipMemcpy(bufs, init.data(), init.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemset(tmo, 0, 16));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, s));
-    hipLaunchKernelGGL((chain<WAVES>), dim3(P), dim3(WAVES * 64), (size_t)std::max(a, b) * 4, s, bufs, bufstride, dW, wstride, nw, a, b, nphase, tmo, sleep_n, stamps);
+    hipLaunchKernelGGL((chain<WAVES>), dim3(P), dim3(WAVES * 64), (size_t)std::max(a, b) * 4, s, bufs, bufstride, dW, wstride, nw, a, b, nphase, tmo, sleep_n, stamps, late_w, R, rep_stride);
     CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     best = std::min(best, ms);
@@ -134,33 +144,31 @@ static void run(int P, int a, int b, int nphase, int nw, int sleep_n, const unsi
   printf("   wg0: gather %.2f ln %.2f rows %.2f tail %.2f | wgLast: gather %.2f ln %.2f rows %.2f tail %.2f  (us/phase, 100 MHz clock)\n",
          hs[0] * 0.01 / nphase, hs[1] * 0.01 / nphase, hs[2] * 0.01 / nphase, hs[3] * 0.01 / nphase, hs[4] * 0.01 / nphase, hs[5] * 0.01 / nphase, hs[6] * 0.01 / nphase, hs[7] * 0.01 / nphase);
   unsigned h_tmo; CK(hipMemcpy(&h_tmo, tmo, 4, hipMemcpyDeviceToHost));
-  std::vector<u64> fin(bufstride * 2);
+  std::vector<u64> fin(rep_stride * 32);
   CK(hipMemcpy(fin.data(), bufs, fin.size() * 8, hipMemcpyDeviceToHost));
   const u64 g = fin[(size_t)(nphase & 1) * bufstride];
   float v0; unsigned u = (unsigned)g; memcpy(&v0, &u, 4);
-  printf("P=%3d waves=%2d %4d->%4d nw=%2d sleep=%d: %.3f us/phase  (timeout=%u, final tag %u, v0 %.5f)\n", P, WAVES, a, b, nw, sleep_n,
+  printf("P=%3d waves=%2d %4d->%4d nw=%2d late_w=%d R=%2d sleep=%d: %.3f us/phase  (timeout=%u, final tag %u, v0 %.5f)\n", P, WAVES, a, b, nw, late_w, R, sleep_n,
          best * 1e3 / nphase, h_tmo, (unsigned)(g >> 32), v0);
   CK(hipStreamDestroy(s));
 }
 
 int main() {
-  const int DMAX = 3072, NW = 24;
+  const int DMAX = 3072, NW = 72;
   const long wstride = (long)DMAX * 768;
   std::vector<unsigned short> hW((size_t)NW * wstride);
   srand(1);
   for (auto& w : hW) w = f2bf(((rand() & 0xffff) / 65536.f - 0.5f) * 0.12f);
   unsigned short* dW; CK(hipMalloc(&dW, hW.size() * 2)); CK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
-  u64* bufs; CK(hipMalloc(&bufs, (size_t)2 * DMAX * 8));
+  u64* bufs; CK(hipMalloc(&bufs, (size_t)(2 * DMAX + 576) * 32 * 8));
   unsigned* tmo; CK(hipMalloc(&tmo, 16));
   CK(hipMalloc(&stamps, 64));
   const int nphase = 2000;
-  for (int P : {32, 64, 128, 256}) {
-    run<16>(P, 768, 768, nphase, NW, 0, dW, wstride, bufs, DMAX, tmo);
-    run<16>(P, 768, 768, nphase, NW, 1, dW, wstride, bufs, DMAX, tmo);
-    run<4>(P, 768, 768, nphase, NW, 0, dW, wstride, bufs, DMAX, tmo);
-    run<16>(P, 768, 3072, nphase, NW, 0, dW, wstride, bufs, DMAX, tmo);
+  for (int R : {1, 2, 4, 8, 16, 32}) {
+    run<8>(256, 768, 768, nphase, 72, 0, 0, R, dW, wstride, bufs, DMAX, tmo);
+    run<8>(256, 768, 3072, nphase, 72, 0, 0, R, dW, wstride, bufs, DMAX, tmo);
   }
-  run<16>(256, 768, 768, nphase, 1, 0, dW, wstride, bufs, DMAX, tmo);
-  run<8>(256, 768, 768, nphase, NW, 0, dW, wstride, bufs, DMAX, tmo);
+  run<16>(256, 768, 768, nphase, 72, 0, 0, 16, dW, wstride, bufs, DMAX, tmo);
+  run<16>(256, 768, 3072, nphase, 72, 0, 0, 16, dW, wstride, bufs, DMAX, tmo);
   return 0;
 }

@@ -115,6 +115,16 @@ struct DecLayerW {
   const float *b_qkv, *b_o, *b_cq, *b_co, *b_fc1, *b_fc2;
 };
 
+// Layout of the decoder-layer weight arenas (engine.cpp load_weights): layer l's bf16 matrices start at
+// w_base + l * w_stride(d), in units of d*d elements; its fp32 vectors at f_base + l * f_stride(d), in units of d.
+struct DecArena {
+  enum : int { W_QKV = 0, W_O = 3, W_CQ = 4, W_CO = 5, W_FC1 = 6, W_FC2 = 10, W_UNITS = 14 };
+  enum : int { F_ATTN_LN_W = 0, F_ATTN_LN_B = 1, F_B_QKV = 2, F_B_O = 5, F_CROSS_LN_W = 6, F_CROSS_LN_B = 7, F_B_CQ = 8, F_B_CO = 9,
+               F_MLP_LN_W = 10, F_MLP_LN_B = 11, F_B_FC1 = 12, F_B_FC2 = 16, F_UNITS = 17 };
+  static constexpr __host__ __device__ long w_stride(int d) { return (long)W_UNITS * d * d; }
+  static constexpr __host__ __device__ long f_stride(int d) { return (long)F_UNITS * d; }
+};
+
 enum GemvPrologue : int { PRO_PLAIN = 0, PRO_LAYERNORM = 1, PRO_ATTN_COMBINE = 2 };
 enum GemvEpilogue : int {
   GEPI_STORE = 0,      // out[b][n] = y + bias
@@ -199,7 +209,7 @@ void launch_advance(const AdvanceParams& p, hipStream_t s);
 // ---- persistent batch-1 decode (decode_persistent.hip): the whole greedy loop of one clip in ONE launch
 typedef unsigned long long u64;
 struct PersistParams {
-  const DecLayerW* layers;      // device array [n_layer]
+  const bf16* wl; const float* fl;   // decoder-layer weight arenas (DecArena layout)
   const bf16* tok_emb; const float* pos; const float* ln_w; const float* ln_b;
   const bf16* cross_k; const bf16* cross_v; long cross_layer_stride;  // this clip's slot, layer 0
   int n_layer, n_vocab, n_ctx, n_audio_ctx;
@@ -208,6 +218,7 @@ struct PersistParams {
   const int* forced; int n_forced; float* logits_dump; int* argmax_dump;   // teacher forcing (tests)
   u64* gran; unsigned* err;     // granule area + error word, zeroed before every launch
   int* out_ids; int* n_out; DecState* state;
+  long long* prof;              // optional [grid][64]: per-phase 100 MHz tick sums + one layer's absolute timeline (AX_WHISPER_PERSIST_PROF), else nullptr
 };
 bool decode_persistent_supported(int d_model, int n_head, int n_layer, int n_cu);
 int decode_persistent_grid(int d_model, int n_cu);

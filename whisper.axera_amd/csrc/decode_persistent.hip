@@ -7,22 +7,25 @@
 //
 // Why: at batch 1 a decoder step is a chain of ~100 dependent phases that each move only a few MB, so the chain is
 // bound by per-phase latency, not by HBM. As separate graph nodes a phase costs ~4.4 us (kernel
-// boundary + wave start + activation round trip + drain). Here one workgroup per CU stays resident for the whole
-// utterance and the phases hand their outputs over INSIDE the launch:
+// boundary + wave start + activation round trip + drain). Here one 1024-thread workgroup per CU stays resident for
+// the whole utterance and the phases hand their outputs over INSIDE the launch:
 //   * every output element travels as one 8-byte {tag, value} granule written by ONE sc1 (write-through) store and
 //     polled with sc1 loads — the data is the flag, no fence, no separate barrier
 //     (cdna_hip_programming.md §6 Guideline 16 form R2; tags = step * n_layer + layer + 1, never 0, buffers zeroed
 //     before every launch);
-//   * each workgroup issues the weight loads of its rows BEFORE it starts polling, so the HBM round trip of the
-//     weights hides behind the hand-off; cross-attention K/V tiles (constant during the utterance) are prefetched
-//     into registers two phases ahead;
+//   * the waves of a workgroup have fixed ROLES: waves 0-7 ("pollers") gather granules, keep the residual stream in
+//     registers and do LayerNorm; waves 8-15 ("compute") own the weight rows, the attention blocks and every
+//     bulk load. Vector-memory results return to a wave in issue order, so a wave that polls must have no long load
+//     in flight — with the roles split, a poll never queues behind a weight or K/V load, and the compute waves request
+//     the rows of the NEXT phase right after publishing the current one, a whole hand-off ahead of their use;
 //   * the self-attention K/V cache of one (layer, head) lives in the LDS of the workgroup that owns that head for
-//     the whole utterance (448 keys x 64 x 2 x bf16 = 112 KB): it never touches HBM;
+//     the whole utterance (448 keys x 64 x 2 x bf16 = 112 KB): it never touches HBM. Workgroups that own no head
+//     use the same LDS region to stage cross-attention K/V tiles by LDS-DMA two phases before their use;
 //   * every workgroup keeps its own copy of the residual stream, so a LayerNorm needs no extra hand-off;
 //   * the token feedback (argmax merge, SOT forcing, eot / context stop, embedding of the next token) is computed
 //     redundantly by every workgroup from the gathered argmax partials: the loop never returns to the host.
-// Every spin is bounded: a workgroup that waits too long sets an error word and leaves; the others see the word
-// (or time out themselves) and leave too, so the grid always drains. The host then throws.
+// Every spin is bounded: a lane that waits too long raises a flag, its workgroup sets an error word and leaves; the
+// others see the word (or time out themselves) and leave too, so the grid always drains. The host then falls back.
 #include "common.hpp"
 
 namespace axw {
@@ -30,13 +33,17 @@ namespace axw {
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
 
-constexpr int PT = 512;            // threads per workgroup (8 waves, one workgroup per CU: 256 VGPRs per lane)
-constexpr int PW = PT / 64;
+constexpr int PT = 1024;           // threads per workgroup, one workgroup per CU
+constexpr int NPW = 8, NCW = 8;    // poller waves, compute waves
+constexpr int PL = NPW * 64;       // poller lanes
+constexpr int CT = NCW * 64;       // compute threads
 constexpr int kSpinMax = 1 << 21;  // polls before a lane gives up (~1 s; a real wait is microseconds)
 constexpr int kPS = 66;            // attention partial record: m, l, o[64]
-constexpr int kCrossSplit = 3;     // cross-attention key ranges per head (8 blocks of 64 keys each = 8 waves)
-constexpr int kSelfBlocks = 7;     // 448 / 64
+constexpr int kCrossSplit = 3;     // cross-attention key ranges per head (8 blocks of 64 keys each = 8 compute waves)
+constexpr int kKvBytes = 2 * NCW * 8192;  // LDS K/V region: K [8 blk][8][64][8] bf16 + V [512 keys][64] bf16
 
 // ---------------------------------------------------------------------------------------- lane-group reductions
 template <int CTRL>
@@ -94,7 +101,7 @@ __device__ __forceinline__ unsigned eget(const unsigned* e) {
 
 // Lane `tid` collects granules idx(k) for k < MAXG (idx < 0: none) of epoch `tag`; returns true on give-up.
 template <int MAXG, typename IDX>
-__device__ __forceinline__ bool gather(const u64* buf, unsigned tag, unsigned (&v)[MAXG], const unsigned* err, IDX idx) {
+__device__ __forceinline__ bool gather(const u64* buf, unsigned tag, unsigned (&v)[MAXG], const unsigned* err, const int* ctl, IDX idx) {
   bool ok[MAXG];
   int ix[MAXG];
 #pragma unroll
@@ -110,7 +117,8 @@ __device__ __forceinline__ bool gather(const u64* buf, unsigned tag, unsigned (&
         if ((unsigned)(x[k] >> 32) == tag) { v[k] = (unsigned)x[k]; ok[k] = true; } else all = false;
       }
     if (all) return false;
-    if ((spins & 1023) == 1023 && eget(err)) return true;  // somebody gave up: leave as well
+    if ((spins & 63) == 63 && *(volatile const int*)ctl) return true;  // a wave of this workgroup gave up
+    if ((spins & 1023) == 1023 && eget(err)) return true;             // another workgroup gave up: leave as well
   }
   return true;
 }
@@ -118,8 +126,8 @@ __device__ __forceinline__ bool gather(const u64* buf, unsigned tag, unsigned (&
 
 // ---------------------------------------------------------------------------------------- weight rows
 template <int LPR, int CH>
-__device__ __forceinline__ void rows_load(u32x4 (&w)[CH], const bf16* W, int K, int row) {
-  const int j = threadIdx.x % LPR;
+__device__ __forceinline__ void rows_load(u32x4 (&w)[CH], const bf16* W, int K, int row, int tid) {
+  const int j = tid % LPR;
   const bf16* wr = W + (long)row * K;
 #pragma unroll
   for (int i = 0; i < CH; ++i) w[i] = *reinterpret_cast<const u32x4*>(wr + (j + LPR * i) * 8);
@@ -135,8 +143,8 @@ __device__ __forceinline__ void rows_load(u32x4 (&w)[CH], const bf16* W, int K, 
   ACC1 = fmaf(__uint_as_float(U[3] & 0xffff0000u), X1.w, ACC1);
 // dot product of one weight row (registers) with the activation vector in LDS; LPR lanes share the row
 template <int LPR, int CH>
-__device__ __forceinline__ float rows_dot(const u32x4 (&w)[CH], const float* act) {
-  const int j = threadIdx.x % LPR;
+__device__ __forceinline__ float rows_dot(const u32x4 (&w)[CH], const float* act, int tid) {
+  const int j = tid % LPR;
   float a0 = 0.f, a1 = 0.f;
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
@@ -154,493 +162,677 @@ __device__ __forceinline__ float rows_dot_reg(const u32x4 (&w)[CH], const float4
   return group_sum<LPR>(a0 + a1);
 }
 
+// ---------------------------------------------------------------------------------------- workgroup barrier
+// s_barrier with only the LDS counter drained. HIP's __syncthreads() also drains vmcnt, which would make every
+// barrier wait for the weight rows that were just requested for the NEXT phase.
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---------------------------------------------------------------------------------------- row sets
+// The rows of one linear layer that this workgroup computes: slot = ctid / LPR handles row r0 + slot (+ k * slots),
+// ctid = thread index among the compute waves. prefetch() issues the loads of the first pass one phase ahead.
+template <int LPR, int CH>
+struct RowSet {
+  u32x4 w[CH];
+  float bias;
+  int r0, r1;
+  __device__ __forceinline__ void prefetch(const bf16* W, const float* b, int K, int N, int wg, int P, int ctid) {
+    r0 = (int)((unsigned)wg * (unsigned)N / (unsigned)P);  // wg * N < 2^31 (256 workgroups x 51866 rows)
+    r1 = (int)((unsigned)(wg + 1) * (unsigned)N / (unsigned)P);
+    const int slot = ctid / LPR, j = ctid % LPR;
+    const int row = r0 + slot;
+    rows_load<LPR, CH>(w, W, K, row < r1 ? row : r0, ctid);
+    bias = (b && row < r1 && j == 0) ? b[row] : 0.f;
+  }
+  // Computes this slot's rows (at most two passes: every supported shape has <= 2 * slots rows per workgroup) into
+  // res[]. The caller requests the NEXT phase's rows before it publishes: a write-through store in front of a load
+  // holds the load back for about a microsecond.
+  __device__ __forceinline__ void run(const bf16* W, const float* b, int K, const float* act, int ctid, float (&res)[2]) {
+    constexpr int SLOTS = CT / LPR;
+    const int slot = ctid / LPR, j = ctid % LPR;
+    res[0] = rows_dot<LPR, CH>(w, act, ctid) + bias;
+    res[1] = 0.f;
+    const int row1 = r0 + slot + SLOTS;
+    if (row1 < r1) {
+      rows_load<LPR, CH>(w, W, K, row1, ctid);
+      const float b1 = (b && j == 0) ? b[row1] : 0.f;
+      res[1] = rows_dot<LPR, CH>(w, act, ctid) + b1;
+    }
+  }
+  template <typename EPI>
+  __device__ __forceinline__ void publish(int ctid, const float (&res)[2], EPI epi) const {
+    constexpr int SLOTS = CT / LPR;
+    const int slot = ctid / LPR, j = ctid % LPR;
+    if (j == 0) {
+      const int row = r0 + slot;
+      if (row < r1) epi(row, res[0]);
+      if (row + SLOTS < r1) epi(row + SLOTS, res[1]);
+    }
+  }
+};
+
+// sum over the lanes that share (lane & 7): lane bits 3, 4, 5
+__device__ __forceinline__ float sum_hi3(float v) {
+  v += dpp_mov<0x128>(v);  // row_ror:8
+  {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  return v;
+}
+
+// One wave, one block of 64 keys in LDS: kblk = [8 (d/8)][64 keys][8] bf16 (lane = key for the scores),
+// vblk = [64 keys][64] bf16. Writes the softmax partial (m, l, o[64]) to part[0..66).
+// pw: 64 floats of wave-private LDS scratch that transposes the probabilities (no cross-lane shuffles).
+__device__ __forceinline__ void attn_block(const bf16* kblk, const bf16* vblk, const float* qs, bool valid, float* pw, float* part, int lane) {
+  float sc0 = 0.f, sc1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const u32x4 kq = *reinterpret_cast<const u32x4*>(kblk + i * 512 + lane * 8);
+    const float4 q0 = *reinterpret_cast<const float4*>(qs + i * 8), q1 = *reinterpret_cast<const float4*>(qs + i * 8 + 4);
+    AXW_FMA8(sc0, sc1, kq, q0, q1)
+  }
+  float sc = (sc0 + sc1) * 0.125f;  // (64^-0.25)^2, export_onnx.py:116,124-126
+  if (!valid) sc = -INFINITY;
+  const float m = wmax(sc);  // -inf only for a block without a single valid key
+  const float pk = m > -INFINITY ? __expf(sc - m) : 0.f;
+  const float lsum = wsum(pk);
+  pw[(lane & 7) * 8 + (lane >> 3)] = pk;  // key k = 8i + r -> pw[r*8 + i]
+  __builtin_amdgcn_wave_barrier();
+  const float4 p0 = *reinterpret_cast<const float4*>(pw + (lane >> 3) * 8), p1 = *reinterpret_cast<const float4*>(pw + (lane >> 3) * 8 + 4);
+  const float pr[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {  // V row of key 8i + (lane>>3), dims (lane&7)*8 .. +8
+    const u32x4 vv = *reinterpret_cast<const u32x4*>(vblk + (8 * i + (lane >> 3)) * 64 + (lane & 7) * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[2 * e] = fmaf(pr[i], __uint_as_float(vv[e] << 16), o[2 * e]);
+      o[2 * e + 1] = fmaf(pr[i], __uint_as_float(vv[e] & 0xffff0000u), o[2 * e + 1]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = sum_hi3(o[e]);
+  if (lane == 0) { part[0] = m; part[1] = lsum; }
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[2 + lane * 8 + e] = o[e];
+  }
+}
+
+// merge nb wave partials (m, l, o[64]) in LDS: returns (l, o[c]) rescaled to the common maximum *m_out
+__device__ __forceinline__ void merge_partials(const float* wpart, int nb, int c, float* m_out, float* l_out, float* o_out) {
+  float m = -INFINITY;
+  for (int b = 0; b < nb; ++b) m = fmaxf(m, wpart[b * kPS]);
+  float lt = 0.f, ov = 0.f;
+  for (int b = 0; b < nb; ++b) {
+    const float mb = wpart[b * kPS];
+    const float f = mb > -INFINITY ? __expf(mb - m) : 0.f;
+    lt += f * wpart[b * kPS + 1];
+    ov += f * wpart[b * kPS + 2 + c];
+  }
+  *m_out = m; *l_out = lt; *o_out = ov;
+}
+
 // ---------------------------------------------------------------------------------------- the kernel
 // d_model = 8*LD*CD (rows with K = d: LD lanes x CD 16-byte chunks), 4*d_model = 8*LF*CF.
 template <int LD, int CD, int LF, int CF>
 __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) {
   constexpr int D = 8 * LD * CD, F = 8 * LF * CF, H = D / 64;
   static_assert(F == 4 * D, "mlp width");
-  constexpr int GD = (D + PT - 1) / PT, GF = (F + PT - 1) / PT, NPART = H * kCrossSplit * kPS, GP = (NPART + PT - 1) / PT;
-  constexpr int SD = PT / LD, SF = PT / LF;  // row slots per pass
+  constexpr int GD = (D + PL - 1) / PL, GF = (F + PL - 1) / PL, NPART = H * kCrossSplit * kPS, GP = (NPART + PL - 1) / PL;
+  constexpr int NU = kCrossSplit * H;  // cross-attention units per layer
   // granule buffers (u64 units)
   constexpr int O_QKV = 0, O_ATT = 3 * D, O_Y1 = 4 * D, O_CQ = 5 * D, O_PART = 6 * D, O_Y2 = 10 * D, O_HID = 11 * D, O_Y3 = 15 * D,
                 O_AMAX = 16 * D;
-  static_assert(NPART <= 4 * D && NPART <= 3 * D + D / 8, "partial buffer");
-  static_assert(kCrossSplit * PW == 24, "cross-attention key blocks");
+  static_assert(NPART <= 3 * D + D / 8, "partial buffer");
+  static_assert(kCrossSplit * NCW == 24, "cross-attention key blocks");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* sK = reinterpret_cast<bf16*>(smem);                  // [7 blk][8][64 keys][8]  (blocked, lane = key)
-  bf16* sV = sK + kSelfBlocks * 4096;                        // [448 keys][64]
-  float* xres = reinterpret_cast<float*>(sV + kSelfBlocks * 4096);  // [D] residual stream (own copy)
-  float* act = xres + D;                                     // [F + D/8] input vector of the current rows phase
-  float* wpart = act + F + D / 8;                            // [PW][kPS] per-wave attention partials
-  float* red = wpart + PW * kPS;                             // [2*PW] LayerNorm partial sums
-  float* qs = red + 2 * PW;                                  // [64] query of the attention phase
-  float* am_v = qs + 64;                                     // [64] argmax scratch
-  int* am_i = reinterpret_cast<int*>(am_v + 64);             // [64]
+  bf16* sK = reinterpret_cast<bf16*>(smem);                  // [8 blk][8][64 keys][8]  (blocked, lane = key)
+  bf16* sV = sK + NCW * 4096;                                // [512 keys][64]
+  float* act = reinterpret_cast<float*>(smem + kKvBytes);    // [F + D/8] input vector of the current rows phase
+  float* wpart = act + F + D / 8;                            // [NCW][kPS] per-wave attention partials
+  float* red = wpart + NCW * kPS;                            // [2*NPW] LayerNorm partial sums
+  float* qs = red + 2 * NPW;                                 // [64] query of the attention phase
+  float* am_v = qs + 64;                                     // [16] argmax scratch
+  int* am_i = reinterpret_cast<int*>(am_v + 16);             // [16]
+  int* ctl = am_i + 16;                                      // [16]: 0 give-up flag, 1 argmax of the step
+  float* pscr = reinterpret_cast<float*>(ctl + 16);          // [NCW][64] probability transpose scratch
+  long long* prof_acc = reinterpret_cast<long long*>(pscr + NCW * 64);  // [64] per-phase time sums + one layer's absolute timeline (profiling runs only)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // tid is re-derived behind an opaque asm at the top of every layer: without it the compiler hoists every
+  // per-thread address of every phase out of the step loop and keeps >100 registers of loop invariants alive
+  int tid = threadIdx.x;
+  const bool poller = tid < PL;  // wave-uniform
   const int P = gridDim.x, wg = blockIdx.x;
   const int L = p.n_layer;
   u64* const G = p.gran;
 
-  // self-attention ownership: unit (l, h) -> workgroup P-1-(l*H+h); cross: unit ((l*H+h)*2+s) -> workgroup unit % P
+  // self-attention ownership: unit (l, h) -> workgroup P-1-(l*H+h). The other NS workgroups take the cross-attention
+  // units: unit u of layer l -> workgroup (l*NU + u) % NS.
   const int sa_unit = P - 1 - wg;
   const int sa_layer = sa_unit < L * H ? sa_unit / H : -1, sa_head = sa_unit % H;
+  const int NS = P - L * H;
 
-  // zero the LDS K/V cache: masked keys must hold finite values
-  for (int i = tid; i < kSelfBlocks * 4096 * 2 / 8; i += PT) reinterpret_cast<u32x4*>(sK)[i] = u32x4{0u, 0u, 0u, 0u};
+  for (int i = tid; i < kKvBytes / 16; i += PT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};  // masked keys must be finite
+  if (tid < 16) ctl[tid] = 0;
+  if (p.prof && tid < 64) prof_acc[tid] = 0;
+  __syncthreads();
+
+  long long t_last = p.prof ? wall_clock64() : 0;
+  // pollers stamp slots 0..15 (thread 0), compute waves 16..31 (thread PL)
+#define AXW_TL(IDX) \
+  if (p.prof && tl_on && (tid == 0 || tid == PL)) prof_acc[32 + (IDX)] = wall_clock64();
+#define AXW_STAMP(IDX) \
+  if (p.prof && (tid == 0 || tid == PL)) { const long long t_now = wall_clock64(); prof_acc[IDX] += t_now - t_last; t_last = t_now; }
+  // first barrier of a phase: everybody learns whether a poller gave up
+#define AXW_BARRIER_CHECK(CODE)                                                                                          \
+  {                                                                                                                      \
+    wg_barrier();                                                                                                        \
+    if (ctl[0]) {                                                                                                        \
+      if (tid == 0) __hip_atomic_store((gu32*)p.err, (unsigned)(CODE) | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+      return;                                                                                                            \
+    }                                                                                                                    \
+  }
 
   int tok = p.sot[0];
   int n_out = 0, n_done = 0, steps_run = 0;
-  float shift = 0.f;  // LayerNorm variance shift (previous mean): sums stay small without a second pass
 
-#define AXW_GIVE_UP(CODE)                                                                    \
-  {                                                                                          \
-    if (tid == 0) __hip_atomic_store((gu32*)p.err, (unsigned)(CODE) | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-    return;                                                                                  \
-  }
-
-  // LayerNorm of (xres += y) into act[0..D): y[k] belongs to element tid + k*PT. Two workgroup barriers.
-  auto ln_stage = [&](const unsigned (&y)[GD], bool add, const float* g, const float* be, bool fail) -> bool {
-    float xs[GD], gg[GD], bb[GD];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < GD; ++k) {
-      const int i = tid + k * PT;
-      if (i < D) {
-        gg[k] = g[i]; bb[k] = be[i];
-        xs[k] = xres[i] + (add ? __uint_as_float(y[k]) : 0.f);
-        xres[i] = xs[k];
-        const float t = xs[k] - shift;
-        s1 += t; s2 += t * t;
-      }
-    }
-    s1 = wsum(s1); s2 = wsum(s2);
-    if (lane == 0) { red[2 * wave] = s1; red[2 * wave + 1] = s2; }
-    if (__syncthreads_or(fail)) return true;
-    float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-    for (int w = 0; w < PW; ++w) { t1 += red[2 * w]; t2 += red[2 * w + 1]; }
-    const float dm = t1 / D, var = fmaxf(t2 / D - dm * dm, 0.f);
-    const float mean = shift + dm, rstd = rsqrtf(var + 1e-5f);
-#pragma unroll
-    for (int k = 0; k < GD; ++k) {
-      const int i = tid + k * PT;
-      if (i < D) act[i] = (xs[k] - mean) * rstd * gg[k] + bb[k];
-    }
-    shift = mean;
-    __syncthreads();
-    return false;
+  auto ca_unit_of = [&](int l) -> int {  // cross-attention unit of this workgroup in layer l, or -1
+    if (wg >= NS) return -1;
+    int r = (wg - l * NU) % NS;
+    if (r < 0) r += NS;
+    return r < NU ? r : -1;
   };
 
-  for (int step = 0; step < p.total_steps; ++step) {
-    // x = token_embedding[tok] + positional_embedding[step]   (export_onnx.py:334-336)
-    __syncthreads();
+  if (poller) {
+    // ======================================================================================= pollers
+    float x[GD];        // residual stream, element tid + k*PL
+    float lg[GD], lb[GD];
+    float shift = 0.f;  // LayerNorm variance shift (previous mean): sums stay small without a second pass
+    auto ln_prefetch = [&](const float* g, const float* be) {
 #pragma unroll
-    for (int k = 0; k < GD; ++k) {
-      const int i = tid + k * PT;
-      if (i < D) xres[i] = (float)p.tok_emb[(long)tok * D + i] + p.pos[(long)step * D + i];
-    }
-    // (made visible by the first barrier of ln_stage)
-
-    for (int l = 0; l < L; ++l) {
-      const DecLayerW& w = p.layers[l];
-      const unsigned tag = (unsigned)(step * L + l + 1);
-
-      // ================================================================= QKV rows (export_onnx.py:245-247)
-      {
-        constexpr int N = 3 * D;
-        const int r0 = (int)((long)wg * N / P), r1 = (int)((long)(wg + 1) * N / P);
-        const int slot = tid / LD, j = tid % LD;
-        u32x4 wr[CD];
-        int row = r0 + slot;
-        rows_load<LD, CD>(wr, w.w_qkv, D, row < r1 ? row : r0);
-        float bias = (row < r1 && j == 0) ? w.b_qkv[row] : 0.f;
-        unsigned y[GD];
-        bool fail = false;
-        if (l > 0) fail = gather<GD>(G + O_Y3, tag - 1, y, p.err, [&](int k) { const int i = tid + k * PT; return i < D ? i : -1; });
-        if (ln_stage(y, l > 0, w.attn_ln_w, w.attn_ln_b, fail)) AXW_GIVE_UP(0x100 + l)
-        for (; row < r1; row += SD) {
-          if (row != r0 + slot) { rows_load<LD, CD>(wr, w.w_qkv, D, row); bias = j == 0 ? w.b_qkv[row] : 0.f; }
-          const float acc = rows_dot<LD, CD>(wr, act);
-          if (j == 0) gput(G + O_QKV + row, tag, acc + bias);
-        }
+      for (int k = 0; k < GD; ++k) {
+        const int i = tid + k * PL;
+        lg[k] = i < D ? g[i] : 0.f;
+        lb[k] = i < D ? be[i] : 0.f;
       }
+    };
+    auto idx_d = [&](int k) { const int i = tid + k * PL; return i < D ? i : -1; };
 
-      // ================================================================= self-attention of one head (export_onnx.py:103-147)
-      // keys 0..step: the -60000 mask + the separate current-token column of the reference equal causal attention.
-      if (l == sa_layer) {
-        const int h = sa_head;
-        unsigned v[1];
-        const bool fail = gather<1>(G + O_QKV, tag, v, p.err, [&](int) { return tid < 192 ? (tid >> 6) * D + h * 64 + (tid & 63) : -1; });
-        if (tid < 64) qs[tid] = __uint_as_float(v[0]);
-        else if (tid < 128) {  // K row `step`, blocked [blk][d/8][key%64][8]
-          const int dd = tid - 64;
-          sK[(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (bf16)__uint_as_float(v[0]);
-        } else if (tid < 192) {
-          sV[step * 64 + (tid - 128)] = (bf16)__uint_as_float(v[0]);
+    // x += y, LayerNorm into act[0..D): two workgroup barriers
+#define AXW_LN_STAGE(Y, ADD, FAIL, CODE)                                                    \
+  {                                                                                          \
+    float s1 = 0.f, s2 = 0.f;                                                                \
+    _Pragma("unroll") for (int k = 0; k < GD; ++k) {                                         \
+      if (tid + k * PL < D) {                                                                \
+        if (ADD) x[k] += __uint_as_float(Y[k]);                                              \
+        const float t = x[k] - shift;                                                        \
+        s1 += t; s2 += t * t;                                                                \
+      }                                                                                      \
+    }                                                                                        \
+    s1 = wsum(s1); s2 = wsum(s2);                                                            \
+    if ((tid & 63) == 0) { red[2 * (tid >> 6)] = s1; red[2 * (tid >> 6) + 1] = s2; }         \
+    if (FAIL) ctl[0] = 1;                                                                    \
+    AXW_BARRIER_CHECK(CODE)                                                                  \
+    float t1 = 0.f, t2 = 0.f;                                                                \
+    _Pragma("unroll") for (int w2 = 0; w2 < NPW; ++w2) { t1 += red[2 * w2]; t2 += red[2 * w2 + 1]; } \
+    const float dm = t1 / D, var = fmaxf(t2 / D - dm * dm, 0.f);                             \
+    const float mean = shift + dm, rstd = rsqrtf(var + 1e-5f);                               \
+    _Pragma("unroll") for (int k = 0; k < GD; ++k) {                                         \
+      const int i = tid + k * PL;                                                            \
+      if (i < D) act[i] = (x[k] - mean) * rstd * lg[k] + lb[k];                              \
+    }                                                                                        \
+    shift = mean;                                                                            \
+    wg_barrier();                                                                            \
+  }
+
+    for (int step = 0; step < p.total_steps; ++step) {
+      // x = token_embedding[tok] + positional_embedding[step]   (export_onnx.py:334-336)
+#pragma unroll
+      for (int k = 0; k < GD; ++k) {
+        const int i = tid + k * PL;
+        x[k] = i < D ? (float)p.tok_emb[(long)tok * D + i] + p.pos[(long)step * D + i] : 0.f;
+      }
+      ln_prefetch(p.fl + DecArena::F_ATTN_LN_W * D, p.fl + DecArena::F_ATTN_LN_B * D);
+
+      for (int l = 0; l < L; ++l) {
+        asm volatile("" : "+v"(tid));
+        const bool tl_on = step == p.total_steps / 2 && l == L / 2;
+        const float* FL = p.fl + (long)l * DecArena::f_stride(D);
+        const unsigned tag = (unsigned)(step * L + l + 1);
+        // ---- QKV
+        {
+          unsigned y[GD];
+          bool fail = false;
+          if (l > 0) fail = gather<GD>(G + O_Y3, tag - 1, y, p.err, ctl, idx_d);
+          AXW_STAMP(0)
+          AXW_TL(0)
+          AXW_LN_STAGE(y, l > 0, fail, 0x100 + l)
+          ln_prefetch(FL + DecArena::F_CROSS_LN_W * D, FL + DecArena::F_CROSS_LN_B * D);
+          AXW_STAMP(1)
+          AXW_TL(1)
         }
-        if (__syncthreads_or(fail)) AXW_GIVE_UP(0x200 + l)
-        const int nblk = (step >> 6) + 1;
-        if (wave < nblk) {
-          float sc0 = 0.f, sc1 = 0.f;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const u32x4 kk = *reinterpret_cast<const u32x4*>(sK + (wave * 8 + i) * 512 + lane * 8);
-            const float4 q0 = *reinterpret_cast<const float4*>(qs + i * 8), q1 = *reinterpret_cast<const float4*>(qs + i * 8 + 4);
-            AXW_FMA8(sc0, sc1, kk, q0, q1)
+        // ---- self-attention owner: collect q, k, v of the head; append k, v to the LDS cache
+        if (l == sa_layer) {
+          unsigned v[1];
+          const bool fail = gather<1>(G + O_QKV, tag, v, p.err, ctl, [&](int) { return tid < 192 ? (tid >> 6) * D + sa_head * 64 + (tid & 63) : -1; });
+          if (tid < 64) qs[tid] = __uint_as_float(v[0]);
+          else if (tid < 128) {  // K row `step`, blocked [blk][d/8][key%64][8]
+            const int dd = tid - 64;
+            sK[(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (bf16)__uint_as_float(v[0]);
+          } else if (tid < 192) {
+            sV[step * 64 + (tid - 128)] = (bf16)__uint_as_float(v[0]);
           }
-          float sc = (sc0 + sc1) * 0.125f;  // (64^-0.25)^2, export_onnx.py:116,124-126
-          if (wave * 64 + lane > step) sc = -INFINITY;
-          const float m = wmax(sc);
-          const float pk = __expf(sc - m);
-          const float lsum = wsum(pk);
-          float o[8];
+          if (fail) ctl[0] = 1;
+          AXW_STAMP(2)
+          AXW_BARRIER_CHECK(0x200 + l)
+          wg_barrier();
+          AXW_STAMP(3)
+        }
+        // ---- attention output projection
+        {
+          unsigned y[GD];
+          const bool fail = gather<GD>(G + O_ATT, tag, y, p.err, ctl, idx_d);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = 0.f;
+          for (int k = 0; k < GD; ++k) { const int i = tid + k * PL; if (i < D) act[i] = __uint_as_float(y[k]); }
+          if (fail) ctl[0] = 1;
+          AXW_STAMP(4)
+          AXW_TL(2)
+          AXW_BARRIER_CHECK(0x300 + l)
+        }
+        // ---- cross-attention query
+        {
+          unsigned y[GD];
+          const bool fail = gather<GD>(G + O_Y1, tag, y, p.err, ctl, idx_d);
+          AXW_STAMP(5)
+          AXW_TL(3)
+          AXW_LN_STAGE(y, true, fail, 0x400 + l)
+          ln_prefetch(FL + DecArena::F_MLP_LN_W * D, FL + DecArena::F_MLP_LN_B * D);
+          AXW_STAMP(6)
+          AXW_TL(4)
+        }
+        // ---- cross-attention unit: collect the head's query
+        const int cu = ca_unit_of(l);
+        if (cu >= 0) {
+          const int ca_head = cu / kCrossSplit;
+          unsigned v[1];
+          const bool fail = gather<1>(G + O_CQ, tag, v, p.err, ctl, [&](int) { return tid < 64 ? ca_head * 64 + tid : -1; });
+          if (tid < 64) qs[tid] = __uint_as_float(v[0]);
+          if (fail) ctl[0] = 1;
+          AXW_STAMP(7)
+          AXW_BARRIER_CHECK(0x500 + l)
+          wg_barrier();
+          AXW_STAMP(8)
+        }
+        // ---- cross-attention output projection: merge the partials of every head
+        {
+          unsigned y[GP];
+          const bool fail = gather<GP>(G + O_PART, tag, y, p.err, ctl, [&](int k) { const int i = tid + k * PL; return i < NPART ? i : -1; });
+          float* pbuf = act + D;  // [H][kCrossSplit][66]
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float wgt = __shfl(pk, 8 * i + (lane >> 3), 64);
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(sV + (wave * 64 + 8 * i + (lane >> 3)) * 64 + (lane & 7) * 8);
+          for (int k = 0; k < GP; ++k) { const int i = tid + k * PL; if (i < NPART) pbuf[i] = __uint_as_float(y[k]); }
+          if (fail) ctl[0] = 1;
+          AXW_STAMP(9)
+          AXW_TL(5)
+          AXW_BARRIER_CHECK(0x600 + l)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              o[2 * e] = fmaf(wgt, __uint_as_float(vv[e] << 16), o[2 * e]);
-              o[2 * e + 1] = fmaf(wgt, __uint_as_float(vv[e] & 0xffff0000u), o[2 * e + 1]);
+          for (int k = 0; k < GD; ++k) {
+            const int i = tid + k * PL;
+            if (i < D) {
+              float m, lt, ov;
+              merge_partials(pbuf + (i >> 6) * kCrossSplit * kPS, kCrossSplit, i & 63, &m, &lt, &ov);
+              act[i] = ov / lt;
             }
           }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            o[e] += __shfl_xor(o[e], 8, 64);
-            o[e] += __shfl_xor(o[e], 16, 64);
-            o[e] += __shfl_xor(o[e], 32, 64);
-          }
-          if (lane == 0) { wpart[wave * kPS] = m; wpart[wave * kPS + 1] = lsum; }
-          if (lane < 8) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) wpart[wave * kPS + 2 + lane * 8 + e] = o[e];
-          }
+          wg_barrier();
+          AXW_STAMP(10)
+          AXW_TL(6)
         }
-        __syncthreads();
-        if (tid < 64) {
-          float m = -INFINITY;
-          for (int b = 0; b < nblk; ++b) m = fmaxf(m, wpart[b * kPS]);
-          float lt = 0.f, ov = 0.f;
-          for (int b = 0; b < nblk; ++b) {
-            const float f = __expf(wpart[b * kPS] - m);
-            lt += f * wpart[b * kPS + 1];
-            ov += f * wpart[b * kPS + 2 + tid];
-          }
-          gput(G + O_ATT + h * 64 + tid, tag, ov / lt);
+        // ---- mlp.0
+        {
+          unsigned y[GD];
+          const bool fail = gather<GD>(G + O_Y2, tag, y, p.err, ctl, idx_d);
+          AXW_STAMP(11)
+          AXW_TL(7)
+          AXW_LN_STAGE(y, true, fail, 0x700 + l)
+          if (l + 1 < L) ln_prefetch(FL + DecArena::f_stride(D) + DecArena::F_ATTN_LN_W * D, FL + DecArena::f_stride(D) + DecArena::F_ATTN_LN_B * D);
+          else ln_prefetch(p.ln_w, p.ln_b);
+          AXW_STAMP(12)
+          AXW_TL(8)
         }
-      }
-
-      // ---- cross-attention unit of this workgroup in this layer (K/V are constant: prefetch now, use two phases later)
-      int ca_head = -1, ca_split = 0;
-      {
-        const int base = kCrossSplit * l * H;
-        const int kk = wg >= base ? 0 : (base - wg + P - 1) / P;
-        const int u = wg + kk * P;
-        if (u >= base && u < base + kCrossSplit * H) { ca_head = (u - base) / kCrossSplit; ca_split = (u - base) % kCrossSplit; }
-      }
-      u32x4 ckr[8], cvr[8];
-      if (ca_head >= 0) {
-        const int kb = ca_split * PW + wave;  // 64-key block of this wave (24 blocks = t_pad 1536)
-        const bf16* kbp = p.cross_k + (long)l * p.cross_layer_stride + (long)ca_head * 24 * 4096 + (long)kb * 4096;
-        const bf16* vbp = p.cross_v + (long)l * p.cross_layer_stride + (long)ca_head * 24 * 4096 + (long)kb * 4096;
+        // ---- mlp.2
+        {
+          unsigned y[GF];
+          const bool fail = gather<GF>(G + O_HID, tag, y, p.err, ctl, [&](int k) { const int i = tid + k * PL; return i < F ? i : -1; });
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ckr[i] = *reinterpret_cast<const u32x4*>(kbp + i * 512 + lane * 8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) cvr[i] = *reinterpret_cast<const u32x4*>(vbp + (8 * i + (lane >> 3)) * 64 + (lane & 7) * 8);
-      }
+          for (int k = 0; k < GF; ++k) { const int i = tid + k * PL; if (i < F) act[i] = __uint_as_float(y[k]); }
+          if (fail) ctl[0] = 1;
+          AXW_STAMP(13)
+          AXW_TL(9)
+          AXW_BARRIER_CHECK(0x800 + l)
+        }
+      }  // layers
 
-      // ================================================================= attention output projection
+      steps_run = step + 1;
+      asm volatile("" : "+v"(tid));
+      if (step < 3) {  // SOT steps: feed the next forced token, logits are discarded (Whisper.cpp:214-217)
+        tok = p.sot[step + 1];
+        continue;
+      }
+      // ---- final LayerNorm for the vocabulary projection, then merge the argmax partials of every workgroup
       {
-        const int r0 = (int)((long)wg * D / P), r1 = (int)((long)(wg + 1) * D / P);
-        const int slot = tid / LD, j = tid % LD;
-        u32x4 wr[CD];
-        int row = r0 + slot;
-        rows_load<LD, CD>(wr, w.w_o, D, row < r1 ? row : r0);
-        float bias = (row < r1 && j == 0) ? w.b_o[row] : 0.f;
         unsigned y[GD];
-        const bool fail = gather<GD>(G + O_ATT, tag, y, p.err, [&](int k) { const int i = tid + k * PT; return i < D ? i : -1; });
-#pragma unroll
-        for (int k = 0; k < GD; ++k) { const int i = tid + k * PT; if (i < D) act[i] = __uint_as_float(y[k]); }
-        if (__syncthreads_or(fail)) AXW_GIVE_UP(0x300 + l)
-        for (; row < r1; row += SD) {
-          if (row != r0 + slot) { rows_load<LD, CD>(wr, w.w_o, D, row); bias = j == 0 ? w.b_o[row] : 0.f; }
-          const float acc = rows_dot<LD, CD>(wr, act);
-          if (j == 0) gput(G + O_Y1 + row, tag, acc + bias);
-        }
-      }
-
-      // ================================================================= cross-attention query (export_onnx.py:221-230)
-      {
-        const int r0 = (int)((long)wg * D / P), r1 = (int)((long)(wg + 1) * D / P);
-        const int slot = tid / LD, j = tid % LD;
-        u32x4 wr[CD];
-        int row = r0 + slot;
-        rows_load<LD, CD>(wr, w.w_cq, D, row < r1 ? row : r0);
-        float bias = (row < r1 && j == 0) ? w.b_cq[row] : 0.f;
-        unsigned y[GD];
-        const bool fail = gather<GD>(G + O_Y1, tag, y, p.err, [&](int k) { const int i = tid + k * PT; return i < D ? i : -1; });
-        if (ln_stage(y, true, w.cross_ln_w, w.cross_ln_b, fail)) AXW_GIVE_UP(0x400 + l)
-        for (; row < r1; row += SD) {
-          if (row != r0 + slot) { rows_load<LD, CD>(wr, w.w_cq, D, row); bias = j == 0 ? w.b_cq[row] : 0.f; }
-          const float acc = rows_dot<LD, CD>(wr, act);
-          if (j == 0) gput(G + O_CQ + row, tag, acc + bias);
-        }
-      }
-
-      // ================================================================= cross-attention over one third of the 1536 padded keys
-      if (ca_head >= 0) {
+        const bool fail = gather<GD>(G + O_Y3, (unsigned)(step * L + L), y, p.err, ctl, idx_d);
+        AXW_LN_STAGE(y, true, fail, 0x900)
+        AXW_STAMP(14)
+        wg_barrier();  // B3: the compute waves have their workgroup argmax
         unsigned v[1];
-        const bool fail = gather<1>(G + O_CQ, tag, v, p.err, [&](int) { return tid < 64 ? ca_head * 64 + tid : -1; });
-        if (tid < 64) qs[tid] = __uint_as_float(v[0]);
-        if (__syncthreads_or(fail)) AXW_GIVE_UP(0x500 + l)
-        float sc0 = 0.f, sc1 = 0.f;
+        const bool fail2 = gather<1>(G + O_AMAX, (unsigned)(step + 1), v, p.err, ctl, [&](int) { return tid < 2 * P ? tid : -1; });
+        // even lane = value of workgroup tid/2, odd lane = its index; first max wins (Whisper.cpp:42-45)
+        float cv = (tid < 2 * P && !(tid & 1)) ? __uint_as_float(v[0]) : -INFINITY;
+        int ci = (int)__shfl_down(v[0], 1, 64);
+        if (tid >= 2 * P || (tid & 1)) { cv = -INFINITY; ci = 0x7fffffff; }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float4 q0 = *reinterpret_cast<const float4*>(qs + i * 8), q1 = *reinterpret_cast<const float4*>(qs + i * 8 + 4);
-          AXW_FMA8(sc0, sc1, ckr[i], q0, q1)
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(cv, o, 64);
+          const int oi = __shfl_xor(ci, o, 64);
+          if (ov > cv || (ov == cv && oi < ci)) { cv = ov; ci = oi; }
         }
-        float sc = (sc0 + sc1) * 0.125f;
-        const int key = (ca_split * PW + wave) * 64 + lane;
-        if (key >= p.n_audio_ctx) sc = -INFINITY;
-        const float m = wmax(sc);  // may be -inf for a fully padded block
-        const float pk = m > -INFINITY ? __expf(sc - m) : 0.f;
-        const float lsum = wsum(pk);
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float wgt = __shfl(pk, 8 * i + (lane >> 3), 64);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[2 * e] = fmaf(wgt, __uint_as_float(cvr[i][e] << 16), o[2 * e]);
-            o[2 * e + 1] = fmaf(wgt, __uint_as_float(cvr[i][e] & 0xffff0000u), o[2 * e + 1]);
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          o[e] += __shfl_xor(o[e], 8, 64);
-          o[e] += __shfl_xor(o[e], 16, 64);
-          o[e] += __shfl_xor(o[e], 32, 64);
-        }
-        if (lane == 0) { wpart[wave * kPS] = m; wpart[wave * kPS + 1] = lsum; }
-        if (lane < 8) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) wpart[wave * kPS + 2 + lane * 8 + e] = o[e];
-        }
-        __syncthreads();
-        if (tid < 64) {
-          float m2 = -INFINITY;
-#pragma unroll
-          for (int b = 0; b < PW; ++b) m2 = fmaxf(m2, wpart[b * kPS]);
-          float lt = 0.f, ov = 0.f;
-#pragma unroll
-          for (int b = 0; b < PW; ++b) {
-            const float mb = wpart[b * kPS];
-            const float f = mb > -INFINITY ? __expf(mb - m2) : 0.f;
-            lt += f * wpart[b * kPS + 1];
-            ov += f * wpart[b * kPS + 2 + tid];
-          }
-          u64* out = G + O_PART + (ca_head * kCrossSplit + ca_split) * kPS;
-          if (tid == 0) { gput(out, tag, m2); gput(out + 1, tag, lt); }
-          gput(out + 2 + tid, tag, ov);
-        }
+        if ((tid & 63) == 0) { am_v[tid >> 6] = cv; am_i[tid >> 6] = ci; }
+        if (fail2) ctl[0] = 1;
+        AXW_STAMP(15)
+        AXW_BARRIER_CHECK(0xA00)  // B4
       }
-
-      // ================================================================= cross-attention output projection
-      {
-        const int r0 = (int)((long)wg * D / P), r1 = (int)((long)(wg + 1) * D / P);
-        const int slot = tid / LD, j = tid % LD;
-        u32x4 wr[CD];
-        int row = r0 + slot;
-        rows_load<LD, CD>(wr, w.w_co, D, row < r1 ? row : r0);
-        float bias = (row < r1 && j == 0) ? w.b_co[row] : 0.f;
-        unsigned y[GP];
-        const bool fail = gather<GP>(G + O_PART, tag, y, p.err, [&](int k) { const int i = tid + k * PT; return i < NPART ? i : -1; });
-        float* pbuf = act + D;  // [H][kCrossSplit][66]  (NPART <= 3.1 D floats behind act[0..D))
-#pragma unroll
-        for (int k = 0; k < GP; ++k) { const int i = tid + k * PT; if (i < NPART) pbuf[i] = __uint_as_float(y[k]); }
-        if (__syncthreads_or(fail)) AXW_GIVE_UP(0x600 + l)
-#pragma unroll
-        for (int k = 0; k < GD; ++k) {
-          const int i = tid + k * PT;
-          if (i < D) {
-            const float* pp = pbuf + (i >> 6) * kCrossSplit * kPS;
-            float m = pp[0];
-#pragma unroll
-            for (int sp = 1; sp < kCrossSplit; ++sp) m = fmaxf(m, pp[sp * kPS]);
-            float lt = 0.f, ov = 0.f;
-#pragma unroll
-            for (int sp = 0; sp < kCrossSplit; ++sp) {
-              const float ms = pp[sp * kPS];
-              const float f = ms > -INFINITY ? __expf(ms - m) : 0.f;
-              lt += f * pp[sp * kPS + 1];
-              ov += f * pp[sp * kPS + 2 + (i & 63)];
-            }
-            act[i] = ov / lt;
-          }
-        }
-        __syncthreads();
-        for (; row < r1; row += SD) {
-          if (row != r0 + slot) { rows_load<LD, CD>(wr, w.w_co, D, row); bias = j == 0 ? w.b_co[row] : 0.f; }
-          const float acc = rows_dot<LD, CD>(wr, act);
-          if (j == 0) gput(G + O_Y2 + row, tag, acc + bias);
-        }
+      float cv = am_v[0];
+      int best_idx = am_i[0];
+      for (int w2 = 1; w2 < NPW; ++w2)
+        if (am_v[w2] > cv || (am_v[w2] == cv && am_i[w2] < best_idx)) { cv = am_v[w2]; best_idx = am_i[w2]; }
+      wg_barrier();  // B5: am_v/am_i are free again
+      const int gi = step - 3;
+      if (p.forced) {
+        if (wg == 0 && tid == 0 && p.argmax_dump && gi <= p.n_forced) p.argmax_dump[gi] = best_idx;
+        if (gi < p.n_forced) tok = p.forced[gi];
+      } else {
+        if (best_idx == p.eot || step + 1 >= p.n_ctx || n_out >= p.max_new) { n_done = 1; break; }
+        if (wg == 0 && tid == 0) p.out_ids[n_out] = best_idx;
+        ++n_out;
+        tok = best_idx;
       }
-
-      // ================================================================= mlp.0 + GELU (export_onnx.py:298)
-      {
-        const int r0 = (int)((long)wg * F / P), r1 = (int)((long)(wg + 1) * F / P);
-        const int slot = tid / LD, j = tid % LD;
-        u32x4 wr[CD];
-        int row = r0 + slot;
-        rows_load<LD, CD>(wr, w.w_fc1, D, row < r1 ? row : r0);
-        float bias = (row < r1 && j == 0) ? w.b_fc1[row] : 0.f;
-        unsigned y[GD];
-        const bool fail = gather<GD>(G + O_Y2, tag, y, p.err, [&](int k) { const int i = tid + k * PT; return i < D ? i : -1; });
-        if (ln_stage(y, true, w.mlp_ln_w, w.mlp_ln_b, fail)) AXW_GIVE_UP(0x700 + l)
-        for (; row < r1; row += SD) {
-          if (row != r0 + slot) { rows_load<LD, CD>(wr, w.w_fc1, D, row); bias = j == 0 ? w.b_fc1[row] : 0.f; }
-          const float acc = rows_dot<LD, CD>(wr, act);
-          if (j == 0) gput(G + O_HID + row, tag, gelu_erf(acc + bias));
-        }
-      }
-
-      // ================================================================= mlp.2
-      {
-        const int r0 = (int)((long)wg * D / P), r1 = (int)((long)(wg + 1) * D / P);
-        const int slot = tid / LF, j = tid % LF;
-        u32x4 wr[CF];
-        int row = r0 + slot;
-        rows_load<LF, CF>(wr, w.w_fc2, F, row < r1 ? row : r0);
-        float bias = (row < r1 && j == 0) ? w.b_fc2[row] : 0.f;
-        unsigned y[GF];
-        const bool fail = gather<GF>(G + O_HID, tag, y, p.err, [&](int k) { const int i = tid + k * PT; return i < F ? i : -1; });
-#pragma unroll
-        for (int k = 0; k < GF; ++k) { const int i = tid + k * PT; if (i < F) act[i] = __uint_as_float(y[k]); }
-        if (__syncthreads_or(fail)) AXW_GIVE_UP(0x800 + l)
-        for (; row < r1; row += SF) {
-          if (row != r0 + slot) { rows_load<LF, CF>(wr, w.w_fc2, F, row); bias = j == 0 ? w.b_fc2[row] : 0.f; }
-          const float acc = rows_dot<LF, CF>(wr, act);
-          if (j == 0) gput(G + O_Y3 + row, tag, acc + bias);
-        }
-        __syncthreads();  // act is rewritten by the next phase's stage
-      }
-    }  // layers
-
-    steps_run = step + 1;
-    // ===================================================================== token feedback (Whisper.cpp:207-222)
-    if (step < 3) {  // SOT steps: feed the next forced token, logits are discarded (Whisper.cpp:214-217)
-      tok = p.sot[step + 1];
-      continue;
     }
-    // logits = token_embedding . ln(x)   (tied embedding, export_onnx.py:364-385) + argmax (first max wins, Whisper.cpp:42-45)
-    int best_idx;
-    {
-      const int N = p.n_vocab;
-      const int r0 = (int)((long)wg * N / P), r1 = (int)((long)(wg + 1) * N / P);
-      const int slot = tid / LD, j = tid % LD;
-      const unsigned tag = (unsigned)(step * L + L);  // y3 of the last layer
-      u32x4 wn[CD];
-      int row = r0 + slot;
-      rows_load<LD, CD>(wn, p.tok_emb, D, row < r1 ? row : r0);
-      unsigned y[GD];
-      const bool fail = gather<GD>(G + O_Y3, tag, y, p.err, [&](int k) { const int i = tid + k * PT; return i < D ? i : -1; });
-      if (ln_stage(y, true, p.ln_w, p.ln_b, fail)) AXW_GIVE_UP(0x900)
-      float4 a[CD][2];
-#pragma unroll
-      for (int i = 0; i < CD; ++i) {
-        a[i][0] = *reinterpret_cast<const float4*>(act + (j + LD * i) * 8);
-        a[i][1] = *reinterpret_cast<const float4*>(act + (j + LD * i) * 8 + 4);
-      }
-      float bv = -INFINITY;
-      int bi = 0x7fffffff;
-      float* dump = p.logits_dump ? p.logits_dump + (long)(step - 3) * N : nullptr;
-      for (; row < r1; row += SD) {
-        u32x4 wr[CD];
-#pragma unroll
-        for (int i = 0; i < CD; ++i) wr[i] = wn[i];
-        const int nrow = row + SD;
-        rows_load<LD, CD>(wn, p.tok_emb, D, nrow < r1 ? nrow : r0);  // next pass in flight
-        const float acc = rows_dot_reg<LD, CD>(wr, a);
-        if (j == 0) {
-          if (dump) dump[row] = acc;
-          if (acc > bv) { bv = acc; bi = row; }
+#undef AXW_LN_STAGE
+  } else {
+    // ======================================================================================= compute waves
+    // The pollers spin; without a priority the arbiter gives their loops the same share of the issue slots as the
+    // waves that do the work (measured: decode 178 -> 158 ms for Whisper-small with this one instruction).
+    __builtin_amdgcn_s_setprio(3);
+    int ctid = tid - PL;
+    RowSet<LD, CD> rs_qkv, rs_o, rs_cq, rs_co, rs_fc1, rs_lg;
+    RowSet<LF, CF> rs_fc2;
+    rs_qkv.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid);
+    {  // the first layer's cross-attention unit has no previous layer to hide behind
+      const int cu0 = ca_unit_of(0);
+      if (cu0 >= 0) {
+        const int lane = ctid & 63, cw = __builtin_amdgcn_readfirstlane(ctid >> 6);
+        const long off = (long)(cu0 / kCrossSplit) * 24 * 4096 + (long)((cu0 % kCrossSplit) * NCW + cw) * 4096;
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_global_load_lds((gptr_t)(p.cross_k + off + i * 512 + lane * 8), (lds_ptr_t)(sK + cw * 4096 + i * 512), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gptr_t)(p.cross_v + off + i * 512 + lane * 8), (lds_ptr_t)(sV + cw * 4096 + i * 512), 16, 0, 0);
         }
       }
-      // workgroup argmax: lanes with j == 0 hold candidates; lower index wins ties
-      if (j != 0) { bv = -INFINITY; bi = 0x7fffffff; }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-      }
-      if (lane == 0) { am_v[wave] = bv; am_i[wave] = bi; }
-      __syncthreads();
-      if (tid == 0) {
-        for (int w2 = 1; w2 < PW; ++w2)
-          if (am_v[w2] > bv || (am_v[w2] == bv && am_i[w2] < bi)) { bv = am_v[w2]; bi = am_i[w2]; }
-        gput(G + O_AMAX + 2 * wg, (unsigned)(step + 1), bv);
-        gput_u(G + O_AMAX + 2 * wg + 1, (unsigned)(step + 1), (unsigned)bi);
-      }
-      // every workgroup merges all partials itself
-      unsigned v[1];
-      const bool fail2 = gather<1>(G + O_AMAX, (unsigned)(step + 1), v, p.err, [&](int) { return tid < 2 * P ? tid : -1; });
-      // lanes: even tid = value of workgroup tid/2, odd tid = index
-      float cv = (tid < 2 * P && !(tid & 1)) ? __uint_as_float(v[0]) : -INFINITY;
-      int ci = (int)__shfl_down(v[0], 1, 64);
-      if (tid >= 2 * P || (tid & 1)) { cv = -INFINITY; ci = 0x7fffffff; }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(cv, o, 64);
-        const int oi = __shfl_xor(ci, o, 64);
-        if (ov > cv || (ov == cv && oi < ci)) { cv = ov; ci = oi; }
-      }
-      __syncthreads();  // am_v/am_i of the partial stage are free again
-      if (lane == 0) { am_v[wave] = cv; am_i[wave] = ci; }
-      if (__syncthreads_or(fail2)) AXW_GIVE_UP(0xA00)
-      cv = am_v[0]; ci = am_i[0];
-      for (int w2 = 1; w2 < PW; ++w2)
-        if (am_v[w2] > cv || (am_v[w2] == cv && am_i[w2] < ci)) { cv = am_v[w2]; ci = am_i[w2]; }
-      best_idx = ci;
     }
-    const int gi = step - 3;
-    if (p.forced) {
-      if (wg == 0 && tid == 0 && p.argmax_dump && gi <= p.n_forced) p.argmax_dump[gi] = best_idx;
-      if (gi < p.n_forced) tok = p.forced[gi];
-    } else {
-      if (best_idx == p.eot || step + 1 >= p.n_ctx || n_out >= p.max_new) { n_done = 1; break; }
-      if (wg == 0 && tid == 0) p.out_ids[n_out] = best_idx;
-      ++n_out;
-      tok = best_idx;
+
+    for (int step = 0; step < p.total_steps; ++step) {
+      for (int l = 0; l < L; ++l) {
+        asm volatile("" : "+v"(ctid));
+        const bool tl_on = step == p.total_steps / 2 && l == L / 2;
+        const int lane = ctid & 63, cw = __builtin_amdgcn_readfirstlane(ctid >> 6);
+        constexpr long DD = (long)D * D;
+        const bf16* WL = p.wl + (long)l * DecArena::w_stride(D);
+        const float* FL = p.fl + (long)l * DecArena::f_stride(D);
+        const bf16 *w_qkv = WL + DecArena::W_QKV * DD, *w_o = WL + DecArena::W_O * DD, *w_cq = WL + DecArena::W_CQ * DD,
+                   *w_co = WL + DecArena::W_CO * DD, *w_fc1 = WL + DecArena::W_FC1 * DD, *w_fc2 = WL + DecArena::W_FC2 * DD;
+        const float *b_qkv = FL + DecArena::F_B_QKV * D, *b_o = FL + DecArena::F_B_O * D, *b_cq = FL + DecArena::F_B_CQ * D,
+                    *b_co = FL + DecArena::F_B_CO * D, *b_fc1 = FL + DecArena::F_B_FC1 * D, *b_fc2 = FL + DecArena::F_B_FC2 * D;
+        const unsigned tag = (unsigned)(step * L + l + 1);
+        const int cu = ca_unit_of(l);
+        // Cross K/V tiles are constant during the utterance: the unit this workgroup runs in the NEXT layer is staged
+        // into LDS now (LDS-DMA, 16 x 1 KiB per wave), a few instructions after each publish of this layer, so that no
+        // publish waits behind a burst of DMA requests. Units of one workgroup are at least two layers apart.
+        const int ln = l + 1 < L ? l + 1 : 0;
+        const int cun = ca_unit_of(ln);
+        auto kv_piece = [&](int i0, int i1) {
+          if (cun < 0) return;
+          const int kb = (cun % kCrossSplit) * NCW + cw;  // 64-key block of this wave (24 blocks = t_pad 1536)
+          const long off = (long)ln * p.cross_layer_stride + (long)(cun / kCrossSplit) * 24 * 4096 + (long)kb * 4096;
+          for (int i = i0; i < i1; ++i) {
+            const bf16* src = (i < 8 ? p.cross_k : p.cross_v) + off + (i & 7) * 512 + lane * 8;
+            bf16* dst = (i < 8 ? sK : sV) + cw * 4096 + (i & 7) * 512;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+          }
+        };
+        // ---- QKV rows (export_onnx.py:245-247)
+        AXW_BARRIER_CHECK(0x100 + l)
+        wg_barrier();
+        AXW_STAMP(16)
+        AXW_TL(18)
+        float res[2];
+        rs_qkv.run(w_qkv, b_qkv, D, act, ctid, res);
+        rs_qkv.publish(ctid, res, [&](int row, float v) { gput(G + O_QKV + row, tag, v); });
+        rs_o.prefetch(w_o, b_o, D, D, wg, P, ctid);
+        kv_piece(0, 2);
+        AXW_STAMP(17)
+        AXW_TL(10)
+        // ---- self-attention of one head over keys 0..step (export_onnx.py:103-147: the -60000 mask + the separate
+        //      current-token column of the reference equal causal attention)
+        if (l == sa_layer) {
+          AXW_BARRIER_CHECK(0x200 + l)
+          const int nblk = (step >> 6) + 1;
+          if (cw < nblk)
+            attn_block(sK + cw * 4096, sV + cw * 4096, qs, cw * 64 + lane <= step, pscr + cw * 64, wpart + cw * kPS, lane);
+          wg_barrier();
+          if (ctid < 64) {
+            float m, lt, ov;
+            merge_partials(wpart, nblk, ctid, &m, &lt, &ov);
+            gput(G + O_ATT + sa_head * 64 + ctid, tag, ov / lt);
+          }
+          AXW_STAMP(18)
+          AXW_TL(11)
+        }
+        // ---- attention output projection
+        AXW_BARRIER_CHECK(0x300 + l)
+        AXW_STAMP(19)
+        AXW_TL(19)
+        rs_o.run(w_o, b_o, D, act, ctid, res);
+        rs_o.publish(ctid, res, [&](int row, float v) { gput(G + O_Y1 + row, tag, v); });
+        rs_cq.prefetch(w_cq, b_cq, D, D, wg, P, ctid);
+        kv_piece(2, 5);
+        AXW_STAMP(20)
+        AXW_TL(12)
+        // ---- cross-attention query (export_onnx.py:221-230)
+        AXW_BARRIER_CHECK(0x400 + l)
+        wg_barrier();
+        AXW_STAMP(21)
+        AXW_TL(20)
+        rs_cq.run(w_cq, b_cq, D, act, ctid, res);
+        rs_cq.publish(ctid, res, [&](int row, float v) { gput(G + O_CQ + row, tag, v); });
+        rs_co.prefetch(w_co, b_co, D, D, wg, P, ctid);
+        kv_piece(5, 8);
+        AXW_STAMP(22)
+        AXW_TL(13)
+        // ---- cross-attention over one third of the 1536 padded keys
+        if (cu >= 0) {
+          const int ca_head = cu / kCrossSplit, ca_split = cu % kCrossSplit;
+          AXW_BARRIER_CHECK(0x500 + l)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own K/V tiles have landed
+          const int key = (ca_split * NCW + cw) * 64 + lane;
+          attn_block(sK + cw * 4096, sV + cw * 4096, qs, key < p.n_audio_ctx, pscr + cw * 64, wpart + cw * kPS, lane);
+          wg_barrier();
+          if (ctid < 64) {
+            float m, lt, ov;
+            merge_partials(wpart, NCW, ctid, &m, &lt, &ov);
+            u64* out = G + O_PART + (ca_head * kCrossSplit + ca_split) * kPS;
+            if (ctid == 0) { gput(out, tag, m); gput(out + 1, tag, lt); }
+            gput(out + 2 + ctid, tag, ov);
+          }
+          AXW_STAMP(23)
+          AXW_TL(14)
+        }
+        // ---- cross-attention output projection
+        AXW_BARRIER_CHECK(0x600 + l)
+        wg_barrier();
+        AXW_STAMP(24)
+        AXW_TL(21)
+        rs_co.run(w_co, b_co, D, act, ctid, res);
+        rs_co.publish(ctid, res, [&](int row, float v) { gput(G + O_Y2 + row, tag, v); });
+        rs_fc1.prefetch(w_fc1, b_fc1, D, F, wg, P, ctid);
+        kv_piece(8, 11);
+        AXW_STAMP(25)
+        AXW_TL(15)
+        // ---- mlp.0 + GELU (export_onnx.py:298)
+        AXW_BARRIER_CHECK(0x700 + l)
+        wg_barrier();
+        AXW_STAMP(26)
+        AXW_TL(22)
+        rs_fc1.run(w_fc1, b_fc1, D, act, ctid, res);
+        rs_fc1.publish(ctid, res, [&](int row, float v) { gput(G + O_HID + row, tag, gelu_erf(v)); });
+        rs_fc2.prefetch(w_fc2, b_fc2, F, D, wg, P, ctid);
+        kv_piece(11, 13);
+        AXW_STAMP(27)
+        AXW_TL(16)
+        // ---- mlp.2
+        AXW_BARRIER_CHECK(0x800 + l)
+        AXW_STAMP(28)
+        AXW_TL(23)
+        rs_fc2.run(w_fc2, b_fc2, F, act, ctid, res);
+        rs_fc2.publish(ctid, res, [&](int row, float v) { gput(G + O_Y3 + row, tag, v); });
+        AXW_STAMP(31)
+        // next consumer of the residual stream: the next layer's QKV rows, the vocabulary projection, or the next step
+        if (l + 1 < L) rs_qkv.prefetch(w_qkv + DecArena::w_stride(D), b_qkv + DecArena::f_stride(D), D, 3 * D, wg, P, ctid);
+        else if (step >= 3) rs_lg.prefetch(p.tok_emb, nullptr, D, p.n_vocab, wg, P, ctid);
+        else rs_qkv.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid);
+        kv_piece(13, 16);
+        AXW_STAMP(29)
+        AXW_TL(17)
+      }  // layers
+
+      steps_run = step + 1;
+      asm volatile("" : "+v"(ctid));
+      if (step < 3) {
+        tok = p.sot[step + 1];
+        continue;
+      }
+      // ---- logits = token_embedding . ln(x)  (tied embedding, export_onnx.py:364-385) + argmax (first max wins, Whisper.cpp:42-45)
+      {
+        constexpr int SD = CT / LD;
+        const int lane = ctid & 63, cw = __builtin_amdgcn_readfirstlane(ctid >> 6);
+        const int N = p.n_vocab;
+        const int slot = ctid / LD, j = ctid % LD;
+        AXW_BARRIER_CHECK(0x900)
+        wg_barrier();
+        float4 a[CD][2];
+#pragma unroll
+        for (int i = 0; i < CD; ++i) {
+          a[i][0] = *reinterpret_cast<const float4*>(act + (j + LD * i) * 8);
+          a[i][1] = *reinterpret_cast<const float4*>(act + (j + LD * i) * 8 + 4);
+        }
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        float* dump = p.logits_dump ? p.logits_dump + (long)(step - 3) * N : nullptr;
+        const int r0 = rs_lg.r0, r1 = rs_lg.r1;
+        u32x4 wn[CD];  // two passes ahead: rs_lg.w holds pass 0, wn pass 1
+        {
+          const int nrow = r0 + slot + SD;
+          rows_load<LD, CD>(wn, p.tok_emb, D, nrow < r1 ? nrow : r0, ctid);
+        }
+        for (int row = r0 + slot; row < r1; row += SD) {
+          u32x4 wr[CD];
+#pragma unroll
+          for (int i = 0; i < CD; ++i) { wr[i] = rs_lg.w[i]; rs_lg.w[i] = wn[i]; }
+          const int nrow = row + 2 * SD;
+          rows_load<LD, CD>(wn, p.tok_emb, D, nrow < r1 ? nrow : r0, ctid);
+          const float acc = rows_dot_reg<LD, CD>(wr, a);
+          if (j == 0) {
+            if (dump) dump[row] = acc;
+            if (acc > bv) { bv = acc; bi = row; }
+          }
+        }
+        // the next step's first rows: requested before the token is even known
+        rs_qkv.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid);
+        // workgroup argmax: lanes with j == 0 hold candidates; the lower index wins ties
+        if (j != 0) { bv = -INFINITY; bi = 0x7fffffff; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(bv, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { am_v[8 + cw] = bv; am_i[8 + cw] = bi; }
+        // compute waves only: named exchange through LDS, then wave 0 publishes. The pollers sit at B3 meanwhile.
+        wg_barrier();  // B3 (all waves)
+        if (ctid == 0) {
+          for (int w2 = 1; w2 < NCW; ++w2)
+            if (am_v[8 + w2] > bv || (am_v[8 + w2] == bv && am_i[8 + w2] < bi)) { bv = am_v[8 + w2]; bi = am_i[8 + w2]; }
+          gput(G + O_AMAX + 2 * wg, (unsigned)(step + 1), bv);
+          gput_u(G + O_AMAX + 2 * wg + 1, (unsigned)(step + 1), (unsigned)bi);
+        }
+        AXW_STAMP(30)
+        AXW_BARRIER_CHECK(0xA00)  // B4
+      }
+      float cv = am_v[0];
+      int best_idx = am_i[0];
+      for (int w2 = 1; w2 < NPW; ++w2)
+        if (am_v[w2] > cv || (am_v[w2] == cv && am_i[w2] < best_idx)) { cv = am_v[w2]; best_idx = am_i[w2]; }
+      wg_barrier();  // B5
+      const int gi = step - 3;
+      if (p.forced) {
+        if (gi < p.n_forced) tok = p.forced[gi];
+      } else {
+        if (best_idx == p.eot || step + 1 >= p.n_ctx || n_out >= p.max_new) { n_done = 1; break; }
+        ++n_out;
+        tok = best_idx;
+      }
     }
   }
 
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may still be in flight when the workgroup's LDS is released
+  if (p.prof) {
+    __syncthreads();
+    if (tid < 64) p.prof[(long)wg * 64 + tid] = prof_acc[tid];
+  }
   if (wg == 0 && tid == 0) {
     p.n_out[0] = n_out;
     p.state->step = steps_run;
     p.state->n_done = n_done;
   }
-#undef AXW_GIVE_UP
+#undef AXW_BARRIER_CHECK
+#undef AXW_STAMP
+#undef AXW_TL
 }
 
 // ---------------------------------------------------------------------------------------- host side
+int decode_persistent_grid(int d_model, int n_cu) {
+  int g = n_cu < d_model ? n_cu : d_model;  // every workgroup owns at least one row of the narrowest layer
+  return g < 256 ? g : 256;                 // the argmax merge reads 2 granules per workgroup with 512 poller lanes
+}
 bool decode_persistent_supported(int d_model, int n_head, int n_layer, int n_cu) {
   if (n_head * 64 != d_model) return false;
-  const int P = n_cu < d_model ? n_cu : d_model;
-  if (n_layer * n_head > P) return false;  // one (layer, head) self-attention cache per workgroup
+  const int P = decode_persistent_grid(d_model, n_cu);
+  // one (layer, head) self-attention cache per workgroup; the rest take the 3 * n_head cross-attention units of a layer
+  if (P - n_layer * n_head < 2 * kCrossSplit * n_head) return false;  // and units of one workgroup >= 2 layers apart
   switch (d_model) { case 128: case 256: case 384: case 512: case 768: case 1280: return true; default: return false; }
 }
-int decode_persistent_grid(int d_model, int n_cu) { return n_cu < d_model ? n_cu : d_model; }
 size_t decode_persistent_gran_bytes(int d_model, int grid) { return ((size_t)16 * d_model + 2 * (size_t)grid + 64) * 8; }
 
-static size_t persist_lds_bytes(int d) { return (size_t)kSelfBlocks * 4096 * 2 * 2 + ((size_t)5 * d + d / 8) * 4 + (PW * kPS + 2 * PW + 64 + 128) * 4; }
+static size_t persist_lds_bytes(int d) {
+  return (size_t)kKvBytes + ((size_t)4 * d + d / 8 + NCW * kPS + 2 * NPW + 64 + 16 + 16 + 16 + NCW * 64) * 4 + 64 * 8 + 64;
+}
 
 template <int LD, int CD, int LF, int CF>
 static hipError_t launch_one(const PersistParams& p, int grid, hipStream_t s) {

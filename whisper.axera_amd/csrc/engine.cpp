@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -59,9 +60,6 @@ Engine::Engine(const std::string& model_type, const std::string& model_path, con
       gran_bytes_ = decode_persistent_gran_bytes(cfg_.n_text_state, persist_grid_);
       d_gran_ = (u64*)dalloc(gran_bytes_, true);
       allocs_.push_back(d_gran_);
-      d_layers_ = (DecLayerW*)dalloc(dec_.size() * sizeof(DecLayerW));
-      allocs_.push_back(d_layers_);
-      HIP_CHECK(hipMemcpy(d_layers_, dec_.data(), dec_.size() * sizeof(DecLayerW), hipMemcpyHostToDevice));
     }
   }
   ensure_capacity(std::max(1, max_batch));
@@ -275,33 +273,51 @@ void Engine::load_weights(const std::string& path) {
   // cross K/V projection of every decoder layer as ONE GEMM: rows [all K | all V] (gemm.hip EPI_CROSS_KV)
   w_cross_kv_ = new_bf16((size_t)2 * L * d * d);
   b_cross_kv_ = new_f32((size_t)2 * L * d);
+  // decoder layer weights live in two arenas with a fixed per-layer stride (layout: DecArena in common.hpp), so the
+  // persistent decode kernel derives every address from two base pointers with scalar arithmetic
+  dec_w_arena_ = new_bf16((size_t)L * DecArena::w_stride(d));
+  dec_f_arena_ = new_f32((size_t)L * DecArena::f_stride(d));
   dec_.resize(L);
   for (int i = 0; i < L; ++i) {
     const std::string pre = "decoder.blocks." + std::to_string(i);
     DecLayerW& w = dec_[i];
-    bf16 *wq, *wo, *w1, *w2;
-    float *bq, *bo, *b1, *b2;
-    w.attn_ln_w = to_f32(pre + ".attn_ln.weight", {d});
-    w.attn_ln_b = to_f32(pre + ".attn_ln.bias", {d});
-    load_attn(pre + ".attn", wq, bq, wo, bo);
-    w.w_qkv = wq; w.b_qkv = bq; w.w_o = wo; w.b_o = bo;
-    w.cross_ln_w = to_f32(pre + ".cross_attn_ln.weight", {d});
-    w.cross_ln_b = to_f32(pre + ".cross_attn_ln.bias", {d});
-    bf16* wcq = new_bf16((size_t)d * d);
-    to_bf16_into(pre + ".cross_attn.query.weight", {d, d}, wcq);
-    w.w_cq = wcq;
-    w.b_cq = to_f32(pre + ".cross_attn.query.bias", {d});
+    bf16* wb = dec_w_arena_ + (size_t)i * DecArena::w_stride(d);
+    float* fb = dec_f_arena_ + (size_t)i * DecArena::f_stride(d);
+    const size_t dd = (size_t)d * d;
+    bf16 *w_qkv = wb + DecArena::W_QKV * dd, *w_o = wb + DecArena::W_O * dd, *w_cq = wb + DecArena::W_CQ * dd,
+         *w_co = wb + DecArena::W_CO * dd, *w_fc1 = wb + DecArena::W_FC1 * dd, *w_fc2 = wb + DecArena::W_FC2 * dd;
+    auto f = [&](int off) { return fb + (size_t)off * d; };
+    to_f32_into(pre + ".attn_ln.weight", {d}, f(DecArena::F_ATTN_LN_W));
+    to_f32_into(pre + ".attn_ln.bias", {d}, f(DecArena::F_ATTN_LN_B));
+    // q,k,v rows concatenated [3d][d]; key has no bias (upstream: bias=False): the arena is zero-initialised
+    to_bf16_into(pre + ".attn.query.weight", {d, d}, w_qkv);
+    to_bf16_into(pre + ".attn.key.weight", {d, d}, w_qkv + dd);
+    to_bf16_into(pre + ".attn.value.weight", {d, d}, w_qkv + 2 * dd);
+    to_f32_into(pre + ".attn.query.bias", {d}, f(DecArena::F_B_QKV));
+    to_f32_into(pre + ".attn.value.bias", {d}, f(DecArena::F_B_QKV) + 2 * d);
+    to_bf16_into(pre + ".attn.out.weight", {d, d}, w_o);
+    to_f32_into(pre + ".attn.out.bias", {d}, f(DecArena::F_B_O));
+    to_f32_into(pre + ".cross_attn_ln.weight", {d}, f(DecArena::F_CROSS_LN_W));
+    to_f32_into(pre + ".cross_attn_ln.bias", {d}, f(DecArena::F_CROSS_LN_B));
+    to_bf16_into(pre + ".cross_attn.query.weight", {d, d}, w_cq);
+    to_f32_into(pre + ".cross_attn.query.bias", {d}, f(DecArena::F_B_CQ));
     to_bf16_into(pre + ".cross_attn.key.weight", {d, d}, w_cross_kv_ + (size_t)i * d * d);
     to_bf16_into(pre + ".cross_attn.value.weight", {d, d}, w_cross_kv_ + (size_t)(L + i) * d * d);
     to_f32_into(pre + ".cross_attn.value.bias", {d}, b_cross_kv_ + (size_t)(L + i) * d);
-    bf16* wco = new_bf16((size_t)d * d);
-    to_bf16_into(pre + ".cross_attn.out.weight", {d, d}, wco);
-    w.w_co = wco;
-    w.b_co = to_f32(pre + ".cross_attn.out.bias", {d});
-    w.mlp_ln_w = to_f32(pre + ".mlp_ln.weight", {d});
-    w.mlp_ln_b = to_f32(pre + ".mlp_ln.bias", {d});
-    load_mlp(pre, w1, b1, w2, b2);
-    w.w_fc1 = w1; w.b_fc1 = b1; w.w_fc2 = w2; w.b_fc2 = b2;
+    to_bf16_into(pre + ".cross_attn.out.weight", {d, d}, w_co);
+    to_f32_into(pre + ".cross_attn.out.bias", {d}, f(DecArena::F_B_CO));
+    to_f32_into(pre + ".mlp_ln.weight", {d}, f(DecArena::F_MLP_LN_W));
+    to_f32_into(pre + ".mlp_ln.bias", {d}, f(DecArena::F_MLP_LN_B));
+    to_bf16_into(pre + ".mlp.0.weight", {4 * d, d}, w_fc1);
+    to_f32_into(pre + ".mlp.0.bias", {4 * d}, f(DecArena::F_B_FC1));
+    to_bf16_into(pre + ".mlp.2.weight", {d, 4 * d}, w_fc2);
+    to_f32_into(pre + ".mlp.2.bias", {d}, f(DecArena::F_B_FC2));
+    w.attn_ln_w = f(DecArena::F_ATTN_LN_W); w.attn_ln_b = f(DecArena::F_ATTN_LN_B);
+    w.cross_ln_w = f(DecArena::F_CROSS_LN_W); w.cross_ln_b = f(DecArena::F_CROSS_LN_B);
+    w.mlp_ln_w = f(DecArena::F_MLP_LN_W); w.mlp_ln_b = f(DecArena::F_MLP_LN_B);
+    w.w_qkv = w_qkv; w.w_o = w_o; w.w_cq = w_cq; w.w_co = w_co; w.w_fc1 = w_fc1; w.w_fc2 = w_fc2;
+    w.b_qkv = f(DecArena::F_B_QKV); w.b_o = f(DecArena::F_B_O); w.b_cq = f(DecArena::F_B_CQ); w.b_co = f(DecArena::F_B_CO);
+    w.b_fc1 = f(DecArena::F_B_FC1); w.b_fc2 = f(DecArena::F_B_FC2);
   }
   tok_emb_ = new_bf16((size_t)cfg_.n_vocab * d);
   to_bf16_into("decoder.token_embedding.weight", {cfg_.n_vocab, d}, tok_emb_);
@@ -752,7 +768,7 @@ int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float
   hipStream_t s = stream();
   const int Tc = cfg_.n_text_ctx, H = cfg_.n_text_head;
   PersistParams p{};
-  p.layers = d_layers_;
+  p.wl = dec_w_arena_; p.fl = dec_f_arena_;
   p.tok_emb = tok_emb_; p.pos = dec_pos_; p.ln_w = dec_ln_w_; p.ln_b = dec_ln_b_;
   p.cross_k = d_cross_k_; p.cross_v = d_cross_v_;  // slot 0
   p.cross_layer_stride = (long)cap_ * H * t_pad_ * 64;
@@ -764,6 +780,13 @@ int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float
   p.gran = d_gran_;
   p.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(d_gran_) + gran_bytes_ - 8);
   p.out_ids = d_out_ids_; p.n_out = d_nout_; p.state = d_state_;
+  long long* d_prof = nullptr;
+  const char* prof_path = getenv("AX_WHISPER_PERSIST_PROF");  // debugging aid: per-workgroup, per-phase time of the launch
+  if (prof_path) {
+    HIP_CHECK(hipMalloc((void**)&d_prof, (size_t)persist_grid_ * 64 * 8));
+    HIP_CHECK(hipMemset(d_prof, 0, (size_t)persist_grid_ * 64 * 8));
+  }
+  p.prof = d_prof;
   HIP_CHECK(hipMemsetAsync(d_gran_, 0, gran_bytes_, s));
   HIP_CHECK(hipMemsetAsync(d_state_, 0, sizeof(DecState), s));
   HIP_CHECK(hipMemsetAsync(d_nout_, 0, 4, s));
@@ -771,6 +794,19 @@ int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float
   HIP_CHECK(hipMemcpyAsync(&h_poll_[8], p.err, 4, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipMemcpyAsync(&h_poll_[9], &d_state_->step, 4, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
+  if (d_prof) {
+    std::vector<long long> hp((size_t)persist_grid_ * 64);
+    HIP_CHECK(hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_prof);
+    if (FILE* f = fopen(prof_path, "w")) {
+      fprintf(f, "# steps %d grid %d; rows = workgroups, columns 0-31 = phase tick sums, 32-63 = absolute ticks of one layer (100 MHz)\n", h_poll_[9], persist_grid_);
+      for (int g = 0; g < persist_grid_; ++g) {
+        for (int i = 0; i < 64; ++i) fprintf(f, "%lld ", hp[(size_t)g * 64 + i]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
   if (h_poll_[8] != 0) {
     fprintf(stderr, "[ax_whisper] persistent decode gave up (code 0x%x); falling back to the launch-per-phase path\n", (unsigned)h_poll_[8]);
     return -1;

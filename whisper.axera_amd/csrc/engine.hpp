@@ -93,7 +93,8 @@ class Engine {
   float *b_cross_kv_ = nullptr, *dec_pos_ = nullptr, *dec_ln_w_ = nullptr, *dec_ln_b_ = nullptr;
   int conv1_k_ = 0;
   std::vector<EncLayer> enc_;
-  std::vector<DecLayerW> dec_;
+  std::vector<DecLayerW> dec_;       // per-layer views into the two arenas below
+  bf16* dec_w_arena_ = nullptr; float* dec_f_arena_ = nullptr;
   struct DecLayerWP { const bf16 *w_qkv, *w_o, *w_cq, *w_co, *w_fc1, *w_fc2; };
   std::vector<DecLayerWP> dec_packed_;  // fragment-major copies for the batched decode path
   const bf16* tok_emb_packed_ = nullptr;
@@ -123,7 +124,6 @@ class Engine {
   // persistent batch-1 decode
   bool persistent_ok_ = false;      // model shape supported and not disabled (AX_WHISPER_DECODE=graph)
   int persist_grid_ = 0;
-  DecLayerW* d_layers_ = nullptr;   // device copy of dec_
   u64* d_gran_ = nullptr; size_t gran_bytes_ = 0;
   std::map<long, hipGraphExec_t> graphs_;  // key: batch * 1024 + max_new
   hipEvent_t ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
