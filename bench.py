@@ -120,15 +120,11 @@ def main():
     n_tok = float(np.mean([len(r) for r in ids]))
     dec_steps = stage["steps"] / args.steps
 
-    # ---- roofline of the dominant kernel family of the timed region: the decode loop's weight-streaming
-    # linear layers (gemv_kernel<..> for <= 4 clips, decode_gemm_kernel<..> beyond; ~2/3 of the GPU time in
-    # profiles/). Algorithmic bytes per decode step for that family = the bf16 decoder weights, each read exactly
-    # once per step for the whole batch (s*[L*14*d^2 + n_vocab*d]); per launch = that / launches per
-    # step. Duration: hipEvents on the engine's stream around `iters` replays of a step graph that holds ONLY
-    # that family's launches.
+    # ---- roofline of the dominant kernel of the timed region.
     iters = 50
     w_bytes, c_bytes, s_bytes = decode_step_bytes(dims, B, 224)
     small_batch = B <= 4
+    persistent = B == 1 and eng.L.AX_WHISPER_GetConfigInt(eng.h, b"persistent_decode") == 1
     n_launch = (dims["dec_layers"] * 6 + 1) * ((B + 3) // 4 if small_batch else (B + 63) // 64)
     ms_fam = eng.bench("decode_gemv", B, 224, iters)
     per_launch_s = ms_fam * 1e-3 / (iters * n_launch)
@@ -138,20 +134,40 @@ def main():
     step_gbs = (w_bytes + c_bytes + s_bytes) / (ms_step * 1e-3) / 1e9
     attn_gbs = (c_bytes + s_bytes) / (ms_attn * 1e-3) / 1e9
     fam = "gemv_kernel" if small_batch else "decode_gemm_kernel"
-    traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc_path):  # HBM bytes per launch from rocprofv3 --pmc passes (recipe in profiles/README.md)
-        rec = json.load(open(pmc_path)).get(f"{args.model}_b{B}", {}).get(fam)
-        if rec:
-            traffic = rec["hbm_bytes_per_launch"]
-    roofline = {"kernel": f"{fam}{'/gemv1_kernel' if small_batch else ''} (decode linear layers, all shapes)", "bound": "hbm", "achieved": round(fam_gbs, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fam_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "launches_per_decode_step": n_launch, "avg_launch_us": round(per_launch_s * 1e6, 3),
-                "bytes_per_launch": int(w_bytes / n_launch),
-                "decode_step": {"ms": round(ms_step, 4), "algorithmic_GBs": round(step_gbs, 1),
-                                "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
-                "decode_attention": {"ms_per_step": round(ms_attn, 4), "algorithmic_GBs": round(attn_gbs, 1),
-                                     "frac_of_hbm_peak": round(attn_gbs / HBM_PEAK_GBS, 4)}}
+    pmc = json.load(open(pmc_path)).get(f"{args.model}_b{B}", {}) if os.path.exists(pmc_path) else {}
+
+    def pmc_traffic(name):  # HBM bytes per launch from rocprofv3 --pmc passes (recipe in profiles/README.md)
+        rec = pmc.get(name)
+        return rec["hbm_bytes_per_launch"] if rec else None
+
+    graph_path = {"kernel": f"{fam}{'/gemv1_kernel' if small_batch else ''} (decode linear layers, all shapes)",
+                  "achieved": round(fam_gbs, 1), "frac": round(fam_gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(fam),
+                  "launches_per_decode_step": n_launch, "avg_launch_us": round(per_launch_s * 1e6, 3),
+                  "bytes_per_launch": int(w_bytes / n_launch),
+                  "decode_step": {"ms": round(ms_step, 4), "algorithmic_GBs": round(step_gbs, 1),
+                                  "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
+                  "decode_attention": {"ms_per_step": round(ms_attn, 4), "algorithmic_GBs": round(attn_gbs, 1),
+                                       "frac_of_hbm_peak": round(attn_gbs / HBM_PEAK_GBS, 4)}}
+    if persistent:
+        # Batch 1: the whole greedy loop of a clip is ONE launch of decode_persistent_kernel (99 % of the timed region).
+        # Algorithmic bytes per launch (SURVEY §8d per step, summed over the steps the launch ran): decoder-layer
+        # weights + cross-K/V every step, the vocabulary projection on the steps whose logits are used (all but the
+        # 3 SOT steps), self-K/V of the t+1 cached keys. Duration: hipEvents on the engine's stream around the
+        # launch (Engine::run_tokens, stage "decode"), averaged over the timed clips.
+        d_, L_, nv_ = dims["d"], dims["dec_layers"], dims["n_vocab"]
+        n_steps = int(round(dec_steps))
+        launch_bytes = n_steps * (2 * L_ * 14 * d_ * d_ + 2 * 2 * L_ * 1500 * d_) + max(n_steps - 3, 0) * 2 * nv_ * d_ \
+            + sum(2 * 2 * L_ * (t + 1) * d_ for t in range(n_steps))
+        launch_s = stage["decode_ms"] / args.steps * 1e-3
+        gbs = launch_bytes / launch_s / 1e9
+        roofline = {"kernel": "decode_persistent_kernel (the whole greedy loop of one clip: %d decoder steps in one launch)" % n_steps,
+                    "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "traffic": pmc_traffic("decode_persistent_kernel"), "launch_ms": round(launch_s * 1e3, 3),
+                    "bytes_per_launch": int(launch_bytes), "us_per_decode_step": round(launch_s * 1e6 / max(n_steps, 1), 2),
+                    "launch_per_phase_path": graph_path}
+    else:
+        roofline = dict({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}, **graph_path)
 
     # ---- the other two stages against their own rooflines: encoder = MFMA-bound, front-end = HBM-bound
     enc_flop = {"tiny": 40.48e9, "small": 386.63e9, "turbo": 2313.09e9}.get(args.model)

@@ -22,4 +22,8 @@ if not os.path.exists(os.path.join(mdir, "small", "small.safetensors")):
 e = wa.Whisper("small", mdir, "zh", device=0, max_batch=B)
 e.bench("encoder", B, 0, 1)
 e.bench("decode_step", B, 224, 4)
+if B == 1:  # the persistent batch-1 decode launch: one whole utterance (448 steps) = one launch
+    import numpy as np
+
+    e.run_tokens(modelgen.synth_clip(0, 480000))
 e.close()

@@ -15,7 +15,7 @@ from collections import defaultdict
 def family(name):
     if "gemv1_kernel" in name or "gemv_kernel" in name:
         return "gemv_kernel"  # the single-clip register kernel and the LDS kernel are one family (decode linears, <= 4 clips)
-    for f in ("decode_gemm_kernel", "decode_attention_kernel", "act_prep_kernel", "advance_kernel",
+    for f in ("decode_persistent_kernel", "decode_gemm_kernel", "decode_attention_kernel", "act_prep_kernel", "advance_kernel",
               "gemm_bf16_kernel", "encoder_attention_kernel", "layernorm_bf16_kernel", "stft_mel_kernel", "mel_normalize_kernel"):
         if f in name:
             return f

@@ -509,10 +509,16 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         }
         // ---- mlp.2
         {
-          unsigned y[GF];
-          const bool fail = gather<GF>(G + O_HID, tag, y, p.err, ctl, [&](int k) { const int i = tid + k * PL; return i < F ? i : -1; });
+          // in chunks of at most 6 granules per lane (register budget of the widest model)
+          constexpr int GC = GF <= 6 ? GF : (GF + 1) / 2;
+          bool fail = false;
 #pragma unroll
-          for (int k = 0; k < GF; ++k) { const int i = tid + k * PL; if (i < F) act[i] = __uint_as_float(y[k]); }
+          for (int c0 = 0; c0 < GF; c0 += GC) {
+            unsigned y[GC];
+            fail |= gather<GC>(G + O_HID, tag, y, p.err, ctl, [&](int k) { const int i = tid + (c0 + k) * PL; return (c0 + k < GF && i < F) ? i : -1; });
+#pragma unroll
+            for (int k = 0; k < GC; ++k) { const int i = tid + (c0 + k) * PL; if (c0 + k < GF && i < F) act[i] = __uint_as_float(y[k]); }
+          }
           if (fail) ctl[0] = 1;
           AXW_STAMP(13)
           AXW_TL(9)
@@ -573,9 +579,11 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     // waves that do the work (measured: decode 178 -> 158 ms for Whisper-small with this one instruction).
     __builtin_amdgcn_s_setprio(3);
     int ctid = tid - PL;
-    RowSet<LD, CD> rs_qkv, rs_o, rs_cq, rs_co, rs_fc1, rs_lg;
+    // two register sets for the d-wide layers are enough: a phase computes from one while the next phase's rows land
+    // in the other (qkv A, o B, cq A, co B, mlp.0 A, [mlp.2 F], next qkv / vocabulary A)
+    RowSet<LD, CD> ra, rb;
     RowSet<LF, CF> rs_fc2;
-    rs_qkv.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid);
+    ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid);
     {  // the first layer's cross-attention unit has no previous layer to hide behind
       const int cu0 = ca_unit_of(0);
       if (cu0 >= 0) {
@@ -623,9 +631,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_STAMP(16)
         AXW_TL(18)
         float res[2];
-        rs_qkv.run(w_qkv, b_qkv, D, act, ctid, res);
-        rs_qkv.publish(ctid, res, [&](int row, float v) { gput(G + O_QKV + row, tag, v); });
-        rs_o.prefetch(w_o, b_o, D, D, wg, P, ctid);
+        ra.run(w_qkv, b_qkv, D, act, ctid, res);
+        ra.publish(ctid, res, [&](int row, float v) { gput(G + O_QKV + row, tag, v); });
+        rb.prefetch(w_o, b_o, D, D, wg, P, ctid);
         kv_piece(0, 2);
         AXW_STAMP(17)
         AXW_TL(10)
@@ -649,9 +657,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_BARRIER_CHECK(0x300 + l)
         AXW_STAMP(19)
         AXW_TL(19)
-        rs_o.run(w_o, b_o, D, act, ctid, res);
-        rs_o.publish(ctid, res, [&](int row, float v) { gput(G + O_Y1 + row, tag, v); });
-        rs_cq.prefetch(w_cq, b_cq, D, D, wg, P, ctid);
+        rb.run(w_o, b_o, D, act, ctid, res);
+        rb.publish(ctid, res, [&](int row, float v) { gput(G + O_Y1 + row, tag, v); });
+        ra.prefetch(w_cq, b_cq, D, D, wg, P, ctid);
         kv_piece(2, 5);
         AXW_STAMP(20)
         AXW_TL(12)
@@ -660,9 +668,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         wg_barrier();
         AXW_STAMP(21)
         AXW_TL(20)
-        rs_cq.run(w_cq, b_cq, D, act, ctid, res);
-        rs_cq.publish(ctid, res, [&](int row, float v) { gput(G + O_CQ + row, tag, v); });
-        rs_co.prefetch(w_co, b_co, D, D, wg, P, ctid);
+        ra.run(w_cq, b_cq, D, act, ctid, res);
+        ra.publish(ctid, res, [&](int row, float v) { gput(G + O_CQ + row, tag, v); });
+        rb.prefetch(w_co, b_co, D, D, wg, P, ctid);
         kv_piece(5, 8);
         AXW_STAMP(22)
         AXW_TL(13)
@@ -689,9 +697,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         wg_barrier();
         AXW_STAMP(24)
         AXW_TL(21)
-        rs_co.run(w_co, b_co, D, act, ctid, res);
-        rs_co.publish(ctid, res, [&](int row, float v) { gput(G + O_Y2 + row, tag, v); });
-        rs_fc1.prefetch(w_fc1, b_fc1, D, F, wg, P, ctid);
+        rb.run(w_co, b_co, D, act, ctid, res);
+        rb.publish(ctid, res, [&](int row, float v) { gput(G + O_Y2 + row, tag, v); });
+        ra.prefetch(w_fc1, b_fc1, D, F, wg, P, ctid);
         kv_piece(8, 11);
         AXW_STAMP(25)
         AXW_TL(15)
@@ -700,8 +708,8 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         wg_barrier();
         AXW_STAMP(26)
         AXW_TL(22)
-        rs_fc1.run(w_fc1, b_fc1, D, act, ctid, res);
-        rs_fc1.publish(ctid, res, [&](int row, float v) { gput(G + O_HID + row, tag, gelu_erf(v)); });
+        ra.run(w_fc1, b_fc1, D, act, ctid, res);
+        ra.publish(ctid, res, [&](int row, float v) { gput(G + O_HID + row, tag, gelu_erf(v)); });
         rs_fc2.prefetch(w_fc2, b_fc2, F, D, wg, P, ctid);
         kv_piece(11, 13);
         AXW_STAMP(27)
@@ -714,9 +722,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         rs_fc2.publish(ctid, res, [&](int row, float v) { gput(G + O_Y3 + row, tag, v); });
         AXW_STAMP(31)
         // next consumer of the residual stream: the next layer's QKV rows, the vocabulary projection, or the next step
-        if (l + 1 < L) rs_qkv.prefetch(w_qkv + DecArena::w_stride(D), b_qkv + DecArena::f_stride(D), D, 3 * D, wg, P, ctid);
-        else if (step >= 3) rs_lg.prefetch(p.tok_emb, nullptr, D, p.n_vocab, wg, P, ctid);
-        else rs_qkv.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid);
+        if (l + 1 < L) ra.prefetch(w_qkv + DecArena::w_stride(D), b_qkv + DecArena::f_stride(D), D, 3 * D, wg, P, ctid);
+        else if (step >= 3) ra.prefetch(p.tok_emb, nullptr, D, p.n_vocab, wg, P, ctid);
+        else ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid);
         kv_piece(13, 16);
         AXW_STAMP(29)
         AXW_TL(17)
@@ -745,26 +753,40 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         float bv = -INFINITY;
         int bi = 0x7fffffff;
         float* dump = p.logits_dump ? p.logits_dump + (long)(step - 3) * N : nullptr;
-        const int r0 = rs_lg.r0, r1 = rs_lg.r1;
-        u32x4 wn[CD];  // two passes ahead: rs_lg.w holds pass 0, wn pass 1
-        {
-          const int nrow = r0 + slot + SD;
-          rows_load<LD, CD>(wn, p.tok_emb, D, nrow < r1 ? nrow : r0, ctid);
-        }
-        for (int row = r0 + slot; row < r1; row += SD) {
-          u32x4 wr[CD];
-#pragma unroll
-          for (int i = 0; i < CD; ++i) { wr[i] = rs_lg.w[i]; rs_lg.w[i] = wn[i]; }
-          const int nrow = row + 2 * SD;
-          rows_load<LD, CD>(wn, p.tok_emb, D, nrow < r1 ? nrow : r0, ctid);
+        const int r0 = ra.r0, r1 = ra.r1;
+        auto consume = [&](const u32x4 (&wr)[CD], int row) {
           const float acc = rows_dot_reg<LD, CD>(wr, a);
           if (j == 0) {
             if (dump) dump[row] = acc;
             if (acc > bv) { bv = acc; bi = row; }
           }
+        };
+        if constexpr (CD <= 3) {  // two passes ahead: ra.w holds pass 0, wn pass 1
+          u32x4 wn[CD];
+          {
+            const int nrow = r0 + slot + SD;
+            rows_load<LD, CD>(wn, p.tok_emb, D, nrow < r1 ? nrow : r0, ctid);
+          }
+          for (int row = r0 + slot; row < r1; row += SD) {
+            u32x4 wr[CD];
+#pragma unroll
+            for (int i = 0; i < CD; ++i) { wr[i] = ra.w[i]; ra.w[i] = wn[i]; }
+            const int nrow = row + 2 * SD;
+            rows_load<LD, CD>(wn, p.tok_emb, D, nrow < r1 ? nrow : r0, ctid);
+            consume(wr, row);
+          }
+        } else {  // wide rows: one pass ahead (register budget)
+          for (int row = r0 + slot; row < r1; row += SD) {
+            u32x4 wr[CD];
+#pragma unroll
+            for (int i = 0; i < CD; ++i) wr[i] = ra.w[i];
+            const int nrow = row + SD;
+            rows_load<LD, CD>(ra.w, p.tok_emb, D, nrow < r1 ? nrow : r0, ctid);
+            consume(wr, row);
+          }
         }
         // the next step's first rows: requested before the token is even known
-        rs_qkv.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid);
+        ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid);
         // workgroup argmax: lanes with j == 0 hold candidates; the lower index wins ties
         if (j != 0) { bv = -INFINITY; bi = 0x7fffffff; }
 #pragma unroll

@@ -62,6 +62,7 @@ Engine::Engine(const std::string& model_type, const std::string& model_path, con
       allocs_.push_back(d_gran_);
     }
   }
+  cfg_.ints["persistent_decode"] = persistent_ok_ ? 1 : 0;  // visible through AX_WHISPER_GetConfigInt
   ensure_capacity(std::max(1, max_batch));
   HIP_CHECK(hipStreamSynchronize(own_stream_));
 }
@@ -740,6 +741,7 @@ int Engine::greedy_loop(int batch, int max_new) {
     if (steps >= 0) return steps;
     // the persistent launch gave up (it needs every workgroup resident at once): use the launch-per-phase path from now on
     persistent_ok_ = false;
+    cfg_.ints["persistent_decode"] = 0;
   }
   reset_decode_state(batch);
   hipGraphExec_t g = step_graph(batch, max_new);
@@ -919,7 +921,7 @@ void Engine::decode_forced(int batch, const int32_t* forced, int n_forced, float
   bool done = false;
   if (batch == 1 && persistent_ok_) {
     if (run_persistent(cfg_.n_text_ctx, d_forced, n_forced, d_logits, d_arg) >= 0) done = true;
-    else persistent_ok_ = false;
+    else { persistent_ok_ = false; cfg_.ints["persistent_decode"] = 0; }
   }
   if (!done) reset_decode_state(batch);
   for (int st = 0; !done && st < 4 + n_forced; ++st) {
