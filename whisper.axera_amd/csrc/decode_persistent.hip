@@ -175,9 +175,19 @@ struct RowSet {
   u32x4 w[CH];
   float bias;
   int r0, r1;
-  __device__ __forceinline__ void prefetch(const bf16* W, const float* b, int K, int N, int wg, int P, int ctid) {
-    r0 = (int)((unsigned)wg * (unsigned)N / (unsigned)P);  // wg * N < 2^31 (256 workgroups x 51866 rows)
-    r1 = (int)((unsigned)(wg + 1) * (unsigned)N / (unsigned)P);
+  // first < 0: rows dealt evenly over all workgroups; else one full pass (SLOTS rows) per producer, producers =
+  // workgroups first, first + 1, ... (the others get no rows)
+  __device__ __forceinline__ void prefetch(const bf16* W, const float* b, int K, int N, int wg, int P, int ctid, int first = -1) {
+    if (first < 0) {
+      r0 = (int)((unsigned)wg * (unsigned)N / (unsigned)P);  // wg * N < 2^31 (256 workgroups x 51866 rows)
+      r1 = (int)((unsigned)(wg + 1) * (unsigned)N / (unsigned)P);
+    } else {
+      constexpr int SLOTS = CT / LPR;
+      int pidx = wg - first;
+      if (pidx < 0) pidx += P;
+      r0 = pidx * SLOTS < N ? pidx * SLOTS : 0;
+      r1 = pidx * SLOTS < N ? (r0 + SLOTS < N ? r0 + SLOTS : N) : 0;
+    }
     const int slot = ctid / LPR, j = ctid % LPR;
     const int row = r0 + slot;
     rows_load<LPR, CH>(w, W, K, row < r1 ? row : r0, ctid);
@@ -579,11 +589,21 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     // waves that do the work (measured: decode 178 -> 158 ms for Whisper-small with this one instruction).
     __builtin_amdgcn_s_setprio(3);
     int ctid = tid - PL;
+    // Which workgroups produce the rows of a phase. A hand-off is faster the fewer workgroups publish into it
+    // (12 producers: 0.9 us, 256: 2-2.7 us), so a layer's rows go to as few producers as one full pass each allows
+    // (16 rows for K = d). Every workgroup must still publish in at least one all-to-all phase of every layer — that
+    // is what bounds how far any consumer can lag behind a producer that reuses a buffer one layer later — so the
+    // 4d-wide layer (first workgroups) and the 3d-wide one (last workgroups) are packed only if together they cover
+    // the grid; otherwise the 4d-wide layer keeps the even deal over all workgroups.
+    constexpr int SLD = CT / LD, NP_Q = (3 * D + SLD - 1) / SLD, NP_F = (F + SLD - 1) / SLD;
+    const int pk_qkv = NP_Q <= P ? P - NP_Q : -1;
+    const int pk_f = (NP_F <= P && NP_Q <= P && NP_F + NP_Q >= P) ? 0 : -1;
+    const int pk_d = 0;  // d rows in passes of CT/LD (or CT/LF) rows: never more producers than workgroups (P <= d)
     // two register sets for the d-wide layers are enough: a phase computes from one while the next phase's rows land
     // in the other (qkv A, o B, cq A, co B, mlp.0 A, [mlp.2 F], next qkv / vocabulary A)
     RowSet<LD, CD> ra, rb;
     RowSet<LF, CF> rs_fc2;
-    ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid);
+    ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid, pk_qkv);
     {  // the first layer's cross-attention unit has no previous layer to hide behind
       const int cu0 = ca_unit_of(0);
       if (cu0 >= 0) {
@@ -633,7 +653,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         float res[2];
         ra.run(w_qkv, b_qkv, D, act, ctid, res);
         ra.publish(ctid, res, [&](int row, float v) { gput(G + O_QKV + row, tag, v); });
-        rb.prefetch(w_o, b_o, D, D, wg, P, ctid);
+        rb.prefetch(w_o, b_o, D, D, wg, P, ctid, pk_d);
         kv_piece(0, 2);
         AXW_STAMP(17)
         AXW_TL(10)
@@ -659,7 +679,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_TL(19)
         rb.run(w_o, b_o, D, act, ctid, res);
         rb.publish(ctid, res, [&](int row, float v) { gput(G + O_Y1 + row, tag, v); });
-        ra.prefetch(w_cq, b_cq, D, D, wg, P, ctid);
+        ra.prefetch(w_cq, b_cq, D, D, wg, P, ctid, pk_d);
         kv_piece(2, 5);
         AXW_STAMP(20)
         AXW_TL(12)
@@ -670,7 +690,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_TL(20)
         ra.run(w_cq, b_cq, D, act, ctid, res);
         ra.publish(ctid, res, [&](int row, float v) { gput(G + O_CQ + row, tag, v); });
-        rb.prefetch(w_co, b_co, D, D, wg, P, ctid);
+        rb.prefetch(w_co, b_co, D, D, wg, P, ctid, pk_d);
         kv_piece(5, 8);
         AXW_STAMP(22)
         AXW_TL(13)
@@ -699,7 +719,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_TL(21)
         rb.run(w_co, b_co, D, act, ctid, res);
         rb.publish(ctid, res, [&](int row, float v) { gput(G + O_Y2 + row, tag, v); });
-        ra.prefetch(w_fc1, b_fc1, D, F, wg, P, ctid);
+        ra.prefetch(w_fc1, b_fc1, D, F, wg, P, ctid, pk_f);
         kv_piece(8, 11);
         AXW_STAMP(25)
         AXW_TL(15)
@@ -710,7 +730,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_TL(22)
         ra.run(w_fc1, b_fc1, D, act, ctid, res);
         ra.publish(ctid, res, [&](int row, float v) { gput(G + O_HID + row, tag, gelu_erf(v)); });
-        rs_fc2.prefetch(w_fc2, b_fc2, F, D, wg, P, ctid);
+        rs_fc2.prefetch(w_fc2, b_fc2, F, D, wg, P, ctid, pk_d);
         kv_piece(11, 13);
         AXW_STAMP(27)
         AXW_TL(16)
@@ -722,9 +742,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         rs_fc2.publish(ctid, res, [&](int row, float v) { gput(G + O_Y3 + row, tag, v); });
         AXW_STAMP(31)
         // next consumer of the residual stream: the next layer's QKV rows, the vocabulary projection, or the next step
-        if (l + 1 < L) ra.prefetch(w_qkv + DecArena::w_stride(D), b_qkv + DecArena::f_stride(D), D, 3 * D, wg, P, ctid);
+        if (l + 1 < L) ra.prefetch(w_qkv + DecArena::w_stride(D), b_qkv + DecArena::f_stride(D), D, 3 * D, wg, P, ctid, pk_qkv);
         else if (step >= 3) ra.prefetch(p.tok_emb, nullptr, D, p.n_vocab, wg, P, ctid);
-        else ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid);
+        else ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid, pk_qkv);
         kv_piece(13, 16);
         AXW_STAMP(29)
         AXW_TL(17)
@@ -786,7 +806,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           }
         }
         // the next step's first rows: requested before the token is even known
-        ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid);
+        ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid, pk_qkv);
         // workgroup argmax: lanes with j == 0 hold candidates; the lower index wins ties
         if (j != 0) { bv = -INFINITY; bi = 0x7fffffff; }
 #pragma unroll
