@@ -1,5 +1,5 @@
 for f in 0 0; do
-  AX_WHISPER_PERSIST_FLAGS=$f timeout -k 10 300 python bench.py --no-cpu-baseline --steps 4 --warmup 1 2>/dev/null | python -c "
+  timeout -k 10 300 python bench.py --no-cpu-baseline --steps 4 --warmup 1 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('flags $f', d['value'], d['stage_ms'])"
 done
 AX_WHISPER_DECODE=graph timeout -k 10 300 python bench.py --no-cpu-baseline --steps 4 --warmup 1 2>/dev/null | python -c "

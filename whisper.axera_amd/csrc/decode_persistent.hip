@@ -291,7 +291,7 @@ __device__ __forceinline__ void merge_partials(const float* wpart, int nb, int c
 
 // ---------------------------------------------------------------------------------------- the kernel
 // d_model = 8*LD*CD (rows with K = d: LD lanes x CD 16-byte chunks), 4*d_model = 8*LF*CF.
-template <int LD, int CD, int LF, int CF>
+template <int LD, int CD, int LF, int CF, bool PROF>
 __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) {
   constexpr int D = 8 * LD * CD, F = 8 * LF * CF, H = D / 64;
   static_assert(F == 4 * D, "mlp width");
@@ -329,18 +329,23 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   const int sa_unit = P - 1 - wg;
   const int sa_layer = sa_unit < L * H ? sa_unit / H : -1, sa_head = sa_unit % H;
   const int NS = P - L * H;
+  // producers of the d-row phases (one pass of CT/LD resp. CT/LF rows each, workgroups 0..): only they consume the
+  // attention outputs / cross-attention partials / mlp hidden vector; every other workgroup skips those three phases
+  // altogether (no polls, no barriers): a hand-off is the faster the fewer workgroups poll it (-5 % decode time)
+  constexpr int NP_D = (D + CT / LD - 1) / (CT / LD), NP_F2 = (D + CT / LF - 1) / (CT / LF);
+  const bool in_o = wg < NP_D, in_f2 = wg < NP_F2;
 
   for (int i = tid; i < kKvBytes / 16; i += PT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};  // masked keys must be finite
   if (tid < 16) ctl[tid] = 0;
-  if (p.prof && tid < 64) prof_acc[tid] = 0;
+  if (PROF && tid < 64) prof_acc[tid] = 0;
   __syncthreads();
 
-  long long t_last = p.prof ? wall_clock64() : 0;
+  long long t_last = PROF ? wall_clock64() : 0;
   // pollers stamp slots 0..15 (thread 0), compute waves 16..31 (thread PL)
 #define AXW_TL(IDX) \
-  if (p.prof && tl_on && (tid == 0 || tid == PL)) prof_acc[32 + (IDX)] = wall_clock64();
+  if (PROF && tl_on && (tid == 0 || tid == PL)) prof_acc[32 + (IDX)] = wall_clock64();
 #define AXW_STAMP(IDX) \
-  if (p.prof && (tid == 0 || tid == PL)) { const long long t_now = wall_clock64(); prof_acc[IDX] += t_now - t_last; t_last = t_now; }
+  if (PROF && (tid == 0 || tid == PL)) { const long long t_now = wall_clock64(); prof_acc[IDX] += t_now - t_last; t_last = t_now; }
   // first barrier of a phase: everybody learns whether a poller gave up
 #define AXW_BARRIER_CHECK(CODE)                                                                                          \
   {                                                                                                                      \
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_STAMP(3)
         }
         // ---- attention output projection
-        {
+        if (in_o) {
           unsigned y[GD];
           const bool fail = gather<GD>(G + O_ATT, tag, y, p.err, ctl, idx_d);
 #pragma unroll
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_STAMP(8)
         }
         // ---- cross-attention output projection: merge the partials of every head
-        {
+        if (in_o) {
           unsigned y[GP];
           const bool fail = gather<GP>(G + O_PART, tag, y, p.err, ctl, [&](int k) { const int i = tid + k * PL; return i < NPART ? i : -1; });
           float* pbuf = act + D;  // [H][kCrossSplit][66]
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_TL(8)
         }
         // ---- mlp.2
-        {
+        if (in_f2) {
           // in chunks of at most 6 granules per lane (register budget of the widest model)
           constexpr int GC = GF <= 6 ? GF : (GF + 1) / 2;
           bool fail = false;
@@ -674,11 +679,13 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_TL(11)
         }
         // ---- attention output projection
-        AXW_BARRIER_CHECK(0x300 + l)
-        AXW_STAMP(19)
-        AXW_TL(19)
-        rb.run(w_o, b_o, D, act, ctid, res);
-        rb.publish(ctid, res, [&](int row, float v) { gput(G + O_Y1 + row, tag, v); });
+        if (in_o) {
+          AXW_BARRIER_CHECK(0x300 + l)
+          AXW_STAMP(19)
+          AXW_TL(19)
+          rb.run(w_o, b_o, D, act, ctid, res);
+          rb.publish(ctid, res, [&](int row, float v) { gput(G + O_Y1 + row, tag, v); });
+        }
         ra.prefetch(w_cq, b_cq, D, D, wg, P, ctid, pk_d);
         kv_piece(2, 5);
         AXW_STAMP(20)
@@ -713,12 +720,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_TL(14)
         }
         // ---- cross-attention output projection
-        AXW_BARRIER_CHECK(0x600 + l)
-        wg_barrier();
-        AXW_STAMP(24)
-        AXW_TL(21)
-        rb.run(w_co, b_co, D, act, ctid, res);
-        rb.publish(ctid, res, [&](int row, float v) { gput(G + O_Y2 + row, tag, v); });
+        if (in_o) {
+          AXW_BARRIER_CHECK(0x600 + l)
+          wg_barrier();
+          AXW_STAMP(24)
+          AXW_TL(21)
+          rb.run(w_co, b_co, D, act, ctid, res);
+          rb.publish(ctid, res, [&](int row, float v) { gput(G + O_Y2 + row, tag, v); });
+        }
         ra.prefetch(w_fc1, b_fc1, D, F, wg, P, ctid, pk_f);
         kv_piece(8, 11);
         AXW_STAMP(25)
@@ -735,12 +744,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_STAMP(27)
         AXW_TL(16)
         // ---- mlp.2
-        AXW_BARRIER_CHECK(0x800 + l)
-        AXW_STAMP(28)
-        AXW_TL(23)
-        rs_fc2.run(w_fc2, b_fc2, F, act, ctid, res);
-        rs_fc2.publish(ctid, res, [&](int row, float v) { gput(G + O_Y3 + row, tag, v); });
-        AXW_STAMP(31)
+        if (in_f2) {
+          AXW_BARRIER_CHECK(0x800 + l)
+          AXW_STAMP(28)
+          AXW_TL(23)
+          rs_fc2.run(w_fc2, b_fc2, F, act, ctid, res);
+          rs_fc2.publish(ctid, res, [&](int row, float v) { gput(G + O_Y3 + row, tag, v); });
+          AXW_STAMP(31)
+        }
         // next consumer of the residual stream: the next layer's QKV rows, the vocabulary projection, or the next step
         if (l + 1 < L) ra.prefetch(w_qkv + DecArena::w_stride(D), b_qkv + DecArena::f_stride(D), D, 3 * D, wg, P, ctid, pk_qkv);
         else if (step >= 3) ra.prefetch(p.tok_emb, nullptr, D, p.n_vocab, wg, P, ctid);
@@ -844,7 +855,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may still be in flight when the workgroup's LDS is released
-  if (p.prof) {
+  if (PROF) {
     __syncthreads();
     if (tid < 64) p.prof[(long)wg * 64 + tid] = prof_acc[tid];
   }
@@ -876,14 +887,20 @@ static size_t persist_lds_bytes(int d) {
   return (size_t)kKvBytes + ((size_t)4 * d + d / 8 + NCW * kPS + 2 * NPW + 64 + 16 + 16 + 16 + NCW * 64) * 4 + 64 * 8 + 64;
 }
 
-template <int LD, int CD, int LF, int CF>
-static hipError_t launch_one(const PersistParams& p, int grid, hipStream_t s) {
+template <int LD, int CD, int LF, int CF, bool PROF>
+static hipError_t launch_one_prof(const PersistParams& p, int grid, hipStream_t s) {
   const size_t lds = persist_lds_bytes(8 * LD * CD);
-  auto kfn = decode_persistent_kernel<LD, CD, LF, CF>;
+  auto kfn = decode_persistent_kernel<LD, CD, LF, CF, PROF>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(PT), lds, s, p);
   return hipGetLastError();
+}
+
+// the profiling stamps are a separate instantiation: the production kernel carries none of their code
+template <int LD, int CD, int LF, int CF>
+static hipError_t launch_one(const PersistParams& p, int grid, hipStream_t s) {
+  return p.prof ? launch_one_prof<LD, CD, LF, CF, true>(p, grid, s) : launch_one_prof<LD, CD, LF, CF, false>(p, grid, s);
 }
 
 hipError_t launch_decode_persistent(const PersistParams& p, int d_model, int grid, hipStream_t s) {
