@@ -81,3 +81,31 @@ def test_persistent_repeated_runs_are_deterministic(built_lib, micro_case):
         assert first == again
     finally:
         e.close()
+
+
+def test_persistent_gives_up_and_falls_back(built_lib, micro_case, monkeypatch):
+    """Every spin in the persistent launch is bounded: with a workgroup that never publishes (test hook) the launch
+    drains within seconds, the handle switches to the launch-per-phase decoder and still returns the right ids."""
+    import time
+
+    import modelgen
+
+    clip = modelgen.synth_clip(4, 64000)
+    ref = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=1)
+    try:
+        want = ref.run_tokens(clip, max_new=20)
+    finally:
+        ref.close()
+    monkeypatch.setenv("AX_WHISPER_PERSIST_FAULT", "1")
+    e = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=1)
+    try:
+        assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_decode") == 1
+        t0 = time.time()
+        got = e.run_tokens(clip, max_new=20)
+        dt = time.time() - t0
+        assert got == want
+        assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_decode") == 0
+        assert dt < 30.0, dt
+        assert e.run_tokens(clip, max_new=20) == want  # stays on the fallback path
+    finally:
+        e.close()

@@ -335,6 +335,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   constexpr int NP_D = (D + CT / LD - 1) / (CT / LD), NP_F2 = (D + CT / LF - 1) / (CT / LF);
   const bool in_o = wg < NP_D, in_f2 = wg < NP_F2;
 
+  if (p.fault && wg == 0) return;  // test hook: a workgroup that never publishes; everybody else must give up and drain
   for (int i = tid; i < kKvBytes / 16; i += PT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};  // masked keys must be finite
   if (tid < 16) ctl[tid] = 0;
   if (PROF && tid < 64) prof_acc[tid] = 0;

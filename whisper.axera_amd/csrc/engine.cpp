@@ -789,6 +789,7 @@ int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float
     HIP_CHECK(hipMemset(d_prof, 0, (size_t)persist_grid_ * 64 * 8));
   }
   p.prof = d_prof;
+  p.fault = getenv("AX_WHISPER_PERSIST_FAULT") ? 1 : 0;
   HIP_CHECK(hipMemsetAsync(d_gran_, 0, gran_bytes_, s));
   HIP_CHECK(hipMemsetAsync(d_state_, 0, sizeof(DecState), s));
   HIP_CHECK(hipMemsetAsync(d_nout_, 0, 4, s));
