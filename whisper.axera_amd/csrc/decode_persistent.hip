@@ -20,7 +20,7 @@
 //     the rows of the NEXT phase right after publishing the current one, a whole hand-off ahead of their use;
 //   * the self-attention K/V cache of one (layer, head) lives in the LDS of the workgroup that owns that head for
 //     the whole utterance (448 keys x 64 x 2 x bf16 = 112 KB): it never touches HBM. Workgroups that own no head
-//     use the same LDS region to stage cross-attention K/V tiles by LDS-DMA two phases before their use;
+//     use the same LDS region to stage cross-attention K/V tiles by LDS-DMA one layer before their use;
 //   * every workgroup keeps its own copy of the residual stream, so a LayerNorm needs no extra hand-off;
 //   * the token feedback (argmax merge, SOT forcing, eot / context stop, embedding of the next token) is computed
 //     redundantly by every workgroup from the gathered argmax partials: the loop never returns to the host.
