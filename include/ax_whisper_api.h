@@ -75,6 +75,11 @@ AX_WHISPER_API int AX_WHISPER_RunDeviceBatchTokens(AX_WHISPER_HANDLE handle, con
 /** ids -> bytes (base64 table of {type}-tokens.txt, Whisper.cpp:224-229); ids >= the table
  *  size are skipped. *result malloc'd. */
 AX_WHISPER_API int AX_WHISPER_Detokenize(AX_WHISPER_HANDLE handle, const int32_t* ids, int n, char** result);
+/** The zh post-pass of Whisper::run (cpp/src/Whisper.cpp:231-236: opencc::SimpleConverter("t2s.json").Convert)
+ *  on its own: config_path names an OpenCC JSON configuration (cpp/t2s.json) whose .ocd2 dictionaries sit next
+ *  to it; text is UTF-8. *result malloc'd. Run* apply it themselves for language "zh" when t2s.json is found in
+ *  $AX_WHISPER_OPENCC_DIR, the working directory (the reference's rule) or the model directory. Host-only. */
+AX_WHISPER_API int AX_WHISPER_ConvertT2S(const char* config_path, const char* text, char** result);
 
 /* ---- additions: stage-level entry points (parity tests, profiling) ------------------- */
 

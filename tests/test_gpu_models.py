@@ -138,3 +138,38 @@ def test_server_asr_round_trip(built_lib, micro_case):
         assert all(o[0] == 200 and o[1]["text"] == js["text"] for o in out)  # micro-batched requests agree with a single one
     finally:
         proc.kill()
+
+
+def test_zh_transcript_goes_through_t2s(built_lib, micro_case, monkeypatch):
+    """Whisper.cpp:231-236: for language zh the Run* text result is the detokenised bytes after OpenCC's t2s pass
+    (when the reference's t2s.json + dictionaries are found); other languages and the token-id entry points are raw."""
+    import ctypes as C
+
+    from conftest import GOLDEN, load_demo_pcm
+
+    pcm = load_demo_pcm()
+    cfg = os.path.join(GOLDEN, "opencc", "t2s.json")
+    monkeypatch.setenv("AX_WHISPER_OPENCC_DIR", os.path.join(GOLDEN, "opencc"))
+    zh = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=1)
+    en = built_lib.Whisper("micro", micro_case.root, "en", device=0, max_batch=1)
+    try:
+        assert zh.L.AX_WHISPER_GetConfigInt(zh.h, b"t2s") == 1 and en.L.AX_WHISPER_GetConfigInt(en.h, b"t2s") == 0
+        for e in (zh, en):
+            ids = e.run_tokens(pcm, max_new=48)
+            raw = e.detokenize(ids)
+            out = C.c_void_p()
+            a = np.ascontiguousarray(pcm, dtype=np.float32)
+            assert e.L.AX_WHISPER_RunPCM(e.h, a.ctypes.data_as(C.POINTER(C.c_float)), len(a), C.byref(out)) == 0
+            got = C.string_at(out.value)
+            e.L._free(out.value)
+            if e is en:
+                assert got.startswith(raw[:16]) or raw.startswith(got[:16])  # same decode, unconverted
+                continue
+            exp = C.c_void_p()
+            full = e.detokenize(e.run_tokens(pcm))
+            assert e.L.AX_WHISPER_ConvertT2S(cfg.encode(), full, C.byref(exp)) == 0
+            assert got == C.string_at(exp.value)
+            e.L._free(exp.value)
+    finally:
+        zh.close()
+        en.close()

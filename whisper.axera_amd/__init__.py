@@ -40,6 +40,7 @@ SYMBOLS = {
     "AX_WHISPER_RunPCMBatch": (C.c_int, [C.c_void_p, C.POINTER(fp), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "AX_WHISPER_RunDeviceBatchTokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, ip, C.POINTER(C.c_int)]),
     "AX_WHISPER_Detokenize": (C.c_int, [C.c_void_p, ip, C.c_int, C.POINTER(C.c_void_p)]),
+    "AX_WHISPER_ConvertT2S": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "AX_WHISPER_ComputeMel": (C.c_int, [C.c_void_p, fp, C.c_int, fp]),
     "AX_WHISPER_EncodeMel": (C.c_int, [C.c_void_p, fp, C.c_int]),
     "AX_WHISPER_GetCrossKV": (C.c_int, [C.c_void_p, C.c_int, fp, fp]),
@@ -72,6 +73,17 @@ def load_library():
         L._free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
+
+
+def convert_t2s(config_path: str, text: str) -> str:
+    """The reference's zh post-pass on its own (cpp/src/Whisper.cpp:231-236): OpenCC t2s.json + its .ocd2 dictionaries."""
+    L = load_library()
+    out = C.c_void_p()
+    if L.AX_WHISPER_ConvertT2S(os.fspath(config_path).encode(), text.encode("utf-8"), C.byref(out)) != 0:
+        raise RuntimeError("AX_WHISPER_ConvertT2S failed: " + (L.AX_WHISPER_LastError(None) or b"").decode())
+    s = C.string_at(out.value).decode("utf-8")
+    L._free(out.value)
+    return s
 
 
 def _f32(a):

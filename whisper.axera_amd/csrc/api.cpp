@@ -6,8 +6,8 @@
 // Differences, all fixes of reference defects: no exception crosses the ABI
 // (json / file errors become NULL), a failed Init does not leak, a handle is serialised by a
 // mutex (the reference's handle is not re-entrant although whisper_srv calls it from a thread
-// pool), and the OpenCC Traditional->Simplified pass (Whisper.cpp:231-236) is not applied: parity
-// is defined on token ids and the raw detokenised bytes.
+// pool). The OpenCC Traditional->Simplified pass of zh transcripts (Whisper.cpp:231-236) is applied by t2s.hpp when
+// the reference's t2s.json + .ocd2 dictionaries are found; AX_WHISPER_Detokenize returns the raw bytes.
 #include "../../include/ax_whisper_api.h"
 
 #include <climits>
@@ -133,7 +133,7 @@ AX_WHISPER_API int AX_WHISPER_RunPCMBatch(AX_WHISPER_HANDLE handle, const float*
     std::vector<int32_t> ids((size_t)batch * Tc);
     std::vector<int> n(batch);
     e.run_tokens(pcm, nullptr, 0, num_samples, batch, 0, ids.data(), n.data());
-    for (int b = 0; b < batch; ++b) results[b] = strdup(e.detokenize(ids.data() + (size_t)b * Tc, n[b]).c_str());
+    for (int b = 0; b < batch; ++b) results[b] = strdup(e.transcript(ids.data() + (size_t)b * Tc, n[b]).c_str());
   });
 }
 
@@ -141,6 +141,22 @@ AX_WHISPER_API int AX_WHISPER_Detokenize(AX_WHISPER_HANDLE handle, const int32_t
   if (!handle || (!ids && n > 0) || !result) return -1;
   *result = nullptr;
   return guarded(handle, [&](Engine& e) { *result = strdup(e.detokenize(ids, n).c_str()); });
+}
+
+AX_WHISPER_API int AX_WHISPER_ConvertT2S(const char* config_path, const char* text, char** result) {
+  if (!config_path || !text || !result) return -1;
+  *result = nullptr;
+  try {
+    axw::T2SConverter conv(config_path);
+    *result = strdup(conv.convert(text).c_str());
+    return *result ? 0 : -1;
+  } catch (const std::exception& e) {
+    g_init_error = e.what();
+    return -1;
+  } catch (...) {
+    g_init_error = "unknown error";
+    return -1;
+  }
 }
 
 AX_WHISPER_API int AX_WHISPER_GetConfigInt(AX_WHISPER_HANDLE handle, const char* key) {

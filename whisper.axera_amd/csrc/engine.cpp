@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 
 #include "host_io.hpp"
 
@@ -42,6 +43,7 @@ Engine::Engine(const std::string& model_type, const std::string& model_path, con
   const std::string dir = model_path + "/" + model_type;
   load_config(dir, model_type, language);
   tokens_ = load_token_table(dir + "/" + model_type + "-tokens.txt");
+  load_t2s(model_path);
   load_weights(dir + "/" + model_type + ".safetensors");
 
   if (max_batch <= 0) {
@@ -63,6 +65,7 @@ Engine::Engine(const std::string& model_type, const std::string& model_path, con
     }
   }
   cfg_.ints["persistent_decode"] = persistent_ok_ ? 1 : 0;  // visible through AX_WHISPER_GetConfigInt
+  cfg_.ints["t2s"] = t2s_ ? 1 : 0;
   ensure_capacity(std::max(1, max_batch));
   HIP_CHECK(hipStreamSynchronize(own_stream_));
 }
@@ -122,6 +125,7 @@ void Engine::load_config(const std::string& dir, const std::string& type, const 
   auto it = std::find(cfg_.lang_codes.begin(), cfg_.lang_codes.end(), language);
   if (it == cfg_.lang_codes.end()) it = std::find(cfg_.lang_codes.begin(), cfg_.lang_codes.end(), std::string("zh"));
   if (it == cfg_.lang_codes.end()) it = cfg_.lang_codes.begin();
+  effective_lang_ = *it;  // Whisper.cpp:244-248: an unknown language silently becomes DEFAULT_LANG
   sot_seq_[0] = cfg_.sot;
   sot_seq_[1] = cfg_.lang_tokens[it - cfg_.lang_codes.begin()];
   sot_seq_[2] = cfg_.transcribe;
@@ -852,6 +856,28 @@ void Engine::run_tokens(const float* const* pcm, const float* d_pcm, int d_strid
   (void)hipEventElapsedTime(&timings[2], ev_[2], ev_[3]);
   timings[3] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   timings[4] = (float)steps;
+}
+
+// Whisper.cpp:231-236: zh transcripts pass through OpenCC's t2s.json. The reference resolves "t2s.json" (and the two
+// .ocd2 dictionaries it names) relative to the working directory; here: $AX_WHISPER_OPENCC_DIR, the working directory,
+// then the model directory. Missing files are not an error (the text then stays as decoded), a broken file is.
+void Engine::load_t2s(const std::string& model_path) {
+  if (effective_lang_ != "zh") return;
+  std::vector<std::string> dirs;
+  if (const char* e = getenv("AX_WHISPER_OPENCC_DIR")) dirs.push_back(std::string(e) + "/");
+  dirs.push_back("");
+  dirs.push_back(model_path + "/");
+  for (const std::string& d : dirs) {
+    std::ifstream f(d + "t2s.json");
+    if (!f.is_open()) continue;
+    t2s_.reset(new T2SConverter(d + "t2s.json"));
+    return;
+  }
+}
+
+std::string Engine::transcript(const int32_t* ids, int n) const {
+  std::string s = detokenize(ids, n);
+  return t2s_ ? t2s_->convert(s) : s;
 }
 
 // Whisper.cpp:224-229 with bounds checks: bytes are concatenated, ids beyond the table skipped.

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "t2s.hpp"
 
 namespace axw {
 
@@ -36,6 +37,9 @@ class Engine {
   void run_tokens(const float* const* pcm, const float* d_pcm, int d_stride, const int* n_samples, int batch, int max_new,
                   int32_t* ids, int* n_ids);
   std::string detokenize(const int32_t* ids, int n) const;
+  // detokenize + the reference's zh post-pass (Traditional -> Simplified, Whisper.cpp:231-236) when its OpenCC data files were found
+  std::string transcript(const int32_t* ids, int n) const;
+  bool has_t2s() const { return (bool)t2s_; }
 
   // stage-level
   void compute_mel(const float* pcm, int n_samples, float* mel_out);
@@ -62,6 +66,7 @@ class Engine {
   void* dalloc(size_t bytes, bool zero = false);
   void load_config(const std::string& dir, const std::string& type, const std::string& language);
   void load_weights(const std::string& path);
+  void load_t2s(const std::string& model_path);
   void ensure_capacity(int batch);
   void free_slot_buffers();
   void upload_pcm(const float* const* pcm, const int* n_samples, int batch);
@@ -81,6 +86,8 @@ class Engine {
   ModelConfig cfg_;
   int sot_seq_[4] = {0, 0, 0, 0};
   std::vector<std::string> tokens_;
+  std::unique_ptr<T2SConverter> t2s_;  // zh only
+  std::string effective_lang_;
   std::mutex mu_;
   int device_ = 0;
   hipStream_t own_stream_ = nullptr, user_stream_ = nullptr;
