@@ -205,7 +205,9 @@ struct RowSet {
     if (row1 < r1) {
       rows_load<LPR, CH>(w, W, K, row1, ctid);
       const float b1 = (b && j == 0) ? b[row1] : 0.f;
-      res[1] = rows_dot<LPR, CH>(w, act, ctid) + b1;
+      int ctid2 = ctid;
+      asm volatile("" : "+v"(ctid2));  // re-read the activations from LDS: keeping them live across both passes spills
+      res[1] = rows_dot<LPR, CH>(w, act, ctid2) + b1;
     }
   }
   template <typename EPI>
@@ -779,18 +781,25 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         const int slot = ctid / LD, j = ctid % LD;
         AXW_BARRIER_CHECK(0x900)
         wg_barrier();
-        float4 a[CD][2];
+        // activations of this lane's chunks stay in registers over all passes (wide models: re-read from LDS per pass,
+        // the registers are needed for the rows in flight)
+        constexpr bool kActInRegs = CD <= 3;
+        float4 a[kActInRegs ? CD : 1][2];
+        if constexpr (kActInRegs) {
 #pragma unroll
-        for (int i = 0; i < CD; ++i) {
-          a[i][0] = *reinterpret_cast<const float4*>(act + (j + LD * i) * 8);
-          a[i][1] = *reinterpret_cast<const float4*>(act + (j + LD * i) * 8 + 4);
+          for (int i = 0; i < CD; ++i) {
+            a[i][0] = *reinterpret_cast<const float4*>(act + (j + LD * i) * 8);
+            a[i][1] = *reinterpret_cast<const float4*>(act + (j + LD * i) * 8 + 4);
+          }
         }
         float bv = -INFINITY;
         int bi = 0x7fffffff;
         float* dump = p.logits_dump ? p.logits_dump + (long)(step - 3) * N : nullptr;
         const int r0 = ra.r0, r1 = ra.r1;
         auto consume = [&](const u32x4 (&wr)[CD], int row) {
-          const float acc = rows_dot_reg<LD, CD>(wr, a);
+          float acc;
+          if constexpr (kActInRegs) acc = rows_dot_reg<LD, CD>(wr, a);
+          else acc = rows_dot<LD, CD>(wr, act, ctid);
           if (j == 0) {
             if (dump) dump[row] = acc;
             if (acc > bv) { bv = acc; bi = row; }
