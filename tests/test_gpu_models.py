@@ -140,7 +140,7 @@ def test_server_asr_round_trip(built_lib, micro_case):
         proc.kill()
 
 
-def test_zh_transcript_goes_through_t2s(built_lib, micro_case, monkeypatch):
+def test_zh_transcript_goes_through_t2s(built_lib, micro_case, monkeypatch, tmp_path):
     """Whisper.cpp:231-236: for language zh the Run* text result is the detokenised bytes after OpenCC's t2s pass
     (when the reference's t2s.json + dictionaries are found); other languages and the token-id entry points are raw."""
     import ctypes as C
@@ -148,8 +148,10 @@ def test_zh_transcript_goes_through_t2s(built_lib, micro_case, monkeypatch):
     from conftest import GOLDEN, load_demo_pcm
 
     pcm = load_demo_pcm()
-    cfg = os.path.join(GOLDEN, "opencc", "t2s.json")
-    monkeypatch.setenv("AX_WHISPER_OPENCC_DIR", os.path.join(GOLDEN, "opencc"))
+    from test_t2s import opencc_t2s_dir
+
+    cfg = opencc_t2s_dir(str(tmp_path / "opencc"))
+    monkeypatch.setenv("AX_WHISPER_OPENCC_DIR", os.path.dirname(cfg))
     zh = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=1)
     en = built_lib.Whisper("micro", micro_case.root, "en", device=0, max_batch=1)
     try:

@@ -1,5 +1,5 @@
 """CPU: the Traditional -> Simplified post-pass of zh transcripts (cpp/src/Whisper.cpp:231-236, OpenCC t2s.json) read
-from the reference's own data files (tests/golden/opencc: t2s.json, TSPhrases.ocd2, TSCharacters.ocd2) by
+from the reference's own dictionaries (tests/golden/opencc: TSPhrases.ocd2, TSCharacters.ocd2; t2s.json is written here) by
 whisper.axera_amd/csrc/t2s.hpp through the C ABI (host-only entry point, no GPU needed).
 
 Expected strings are standard OpenCC t2s behaviour: single characters through TSCharacters, and the phrase exceptions
@@ -10,10 +10,33 @@ import pytest
 
 from conftest import GOLDEN
 
-CFG = os.path.join(GOLDEN, "opencc", "t2s.json")
+OCC = os.path.join(GOLDEN, "opencc")
 
 
-def test_characters_and_phrases(built_lib):
+def opencc_t2s_dir(dst):
+    """A directory laid out like the reference's deployment: t2s.json (the standard OpenCC Traditional -> Simplified
+    configuration: mmseg over TSPhrases, then the group [TSPhrases, TSCharacters]) next to the two dictionaries."""
+    import json
+    import shutil
+
+    os.makedirs(dst, exist_ok=True)
+    for f in ("TSPhrases.ocd2", "TSCharacters.ocd2"):
+        shutil.copy(os.path.join(OCC, f), os.path.join(dst, f))
+    ocd2 = lambda f: {"type": "ocd2", "file": f}
+    cfg = {"name": "Traditional Chinese to Simplified Chinese",
+           "segmentation": {"type": "mmseg", "dict": ocd2("TSPhrases.ocd2")},
+           "conversion_chain": [{"dict": {"type": "group", "dicts": [ocd2("TSPhrases.ocd2"), ocd2("TSCharacters.ocd2")]}}]}
+    with open(os.path.join(dst, "t2s.json"), "w") as f:
+        json.dump(cfg, f, indent=2)
+    return os.path.join(dst, "t2s.json")
+
+
+@pytest.fixture(scope="module")
+def CFG(tmp_path_factory):
+    return opencc_t2s_dir(str(tmp_path_factory.mktemp("opencc")))
+
+
+def test_characters_and_phrases(built_lib, CFG):
     t2s = lambda s: built_lib.convert_t2s(CFG, s)
     # the reference README's demo transcript is already Simplified: unchanged
     assert t2s("甚至出现交易几乎停止的情况") == "甚至出现交易几乎停止的情况"
@@ -34,7 +57,7 @@ def test_characters_and_phrases(built_lib):
     assert t2s("𢶫") == "𢫞"
 
 
-def test_dictionary_is_read_completely(built_lib):
+def test_dictionary_is_read_completely(built_lib, CFG):
     """Every key of TSCharacters is one character and converts to something non-empty; idempotence on the result for a
     sample (Simplified text has no Traditional keys left, except characters that are both)."""
     t2s = lambda s: built_lib.convert_t2s(CFG, s)
@@ -45,12 +68,12 @@ def test_dictionary_is_read_completely(built_lib):
     assert t2s(out) == out
 
 
-def test_bad_files_fail_cleanly(built_lib, tmp_path):
+def test_bad_files_fail_cleanly(built_lib, tmp_path, CFG):
     with pytest.raises(RuntimeError):
         built_lib.convert_t2s(str(tmp_path / "missing.json"), "x")
     bad = tmp_path / "t2s.json"
     bad.write_text(open(CFG).read())
     (tmp_path / "TSPhrases.ocd2").write_bytes(b"OPENCC_MARISA_0.2.5We love Marisa.\x00" + b"\x10" * 40)
-    (tmp_path / "TSCharacters.ocd2").write_bytes(open(os.path.join(GOLDEN, "opencc", "TSCharacters.ocd2"), "rb").read()[:1000])
+    (tmp_path / "TSCharacters.ocd2").write_bytes(open(os.path.join(OCC, "TSCharacters.ocd2"), "rb").read()[:1000])
     with pytest.raises(RuntimeError):
         built_lib.convert_t2s(str(bad), "體")
