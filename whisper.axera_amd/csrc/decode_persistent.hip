@@ -41,7 +41,8 @@ constexpr int NPW = 8, NCW = 8;    // poller waves, compute waves
 constexpr int PL = NPW * 64;       // poller lanes
 constexpr int CT = NCW * 64;       // compute threads
 constexpr int kSpinMax = 1 << 21;  // polls before a lane gives up (~1 s; a real wait is microseconds)
-constexpr int kPS = 66;            // attention partial record: m, l, o[64]
+constexpr int kPS = 66;            // attention partial record in LDS: m, l, o[64]
+constexpr int kRec = 80;           // cross-attention partial record as granules: o[64] (four full lines), m, l; 5-line stride
 constexpr int kCrossSplit = 3;     // cross-attention key ranges per head (8 blocks of 64 keys each = 8 compute waves)
 constexpr int kKvBytes = 2 * NCW * 8192;  // LDS K/V region: K [8 blk][8][64][8] bf16 + V [512 keys][64] bf16
 
@@ -210,15 +211,23 @@ struct RowSet {
       res[1] = rows_dot<LPR, CH>(w, act, ctid2) + b1;
     }
   }
-  template <typename EPI>
-  __device__ __forceinline__ void publish(int ctid, const float (&res)[2], EPI epi) const {
+  // Publishes this workgroup's rows (contiguous granules r0..r1-1 of `buf`) with ONE store instruction: the slot
+  // leaders drop f(result) into pk[] (LDS), every compute wave bumps an LDS counter, and the wave that arrives last
+  // stores all rows. Several waves each storing a few granules of the same 128-byte lines cost the hand-off 1.7 us
+  // (profiles/microbench/publish_shape.cpp: 48 producers x 16 rows, 3.4 -> 1.75 us per phase).
+  template <typename F>
+  __device__ __forceinline__ void publish(int ctid, const float (&res)[2], float* pk, int* cnt, u64* buf, unsigned tag, F f) const {
     constexpr int SLOTS = CT / LPR;
-    const int slot = ctid / LPR, j = ctid % LPR;
+    const int slot = ctid / LPR, j = ctid % LPR, lane = ctid & 63;
     if (j == 0) {
-      const int row = r0 + slot;
-      if (row < r1) epi(row, res[0]);
-      if (row + SLOTS < r1) epi(row + SLOTS, res[1]);
+      if (r0 + slot < r1) pk[slot] = f(res[0]);
+      if (r0 + slot + SLOTS < r1) pk[slot + SLOTS] = f(res[1]);
     }
+    __builtin_amdgcn_wave_barrier();
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if ((old + 1) % NCW == 0 && lane < r1 - r0) gput(buf + r0 + lane, tag, pk[lane]);
   }
 };
 
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   // granule buffers (u64 units)
   constexpr int O_QKV = 0, O_ATT = 3 * D, O_Y1 = 4 * D, O_CQ = 5 * D, O_PART = 6 * D, O_Y2 = 10 * D, O_HID = 11 * D, O_Y3 = 15 * D,
                 O_AMAX = 16 * D;
-  static_assert(NPART <= 3 * D + D / 8, "partial buffer");
+  static_assert(NPART <= 3 * D + D / 8 && NU * kRec <= 4 * D, "partial buffer");
   static_assert(kCrossSplit * NCW == 24, "cross-attention key blocks");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -315,7 +324,8 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   float* am_v = qs + 64;                                     // [16] argmax scratch
   int* am_i = reinterpret_cast<int*>(am_v + 16);             // [16]
   int* ctl = am_i + 16;                                      // [16]: 0 give-up flag, 1 argmax of the step
-  float* pscr = reinterpret_cast<float*>(ctl + 16);          // [NCW][64] probability transpose scratch
+  float* pk = reinterpret_cast<float*>(ctl + 16);            // [64] this workgroup's rows of the phase, assembled for the one-instruction publish
+  float* pscr = pk + 64;                                     // [NCW][64] probability transpose scratch
   long long* prof_acc = reinterpret_cast<long long*>(pscr + NCW * 64);  // [64] per-phase time sums + one layer's absolute timeline (profiling runs only)
 
   // tid is re-derived behind an opaque asm at the top of every layer: without it the compiler hoists every
@@ -492,7 +502,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         // ---- cross-attention output projection: merge the partials of every head
         if (in_o) {
           unsigned y[GP];
-          const bool fail = gather<GP>(G + O_PART, tag, y, p.err, ctl, [&](int k) { const int i = tid + k * PL; return i < NPART ? i : -1; });
+          const bool fail = gather<GP>(G + O_PART, tag, y, p.err, ctl, [&](int k) { const int i = tid + k * PL; return i < NPART ? (i / kPS) * kRec + i % kPS : -1; });
           float* pbuf = act + D;  // [H][kCrossSplit][66]
 #pragma unroll
           for (int k = 0; k < GP; ++k) { const int i = tid + k * PL; if (i < NPART) pbuf[i] = __uint_as_float(y[k]); }
@@ -504,8 +514,18 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           for (int k = 0; k < GD; ++k) {
             const int i = tid + k * PL;
             if (i < D) {
-              float m, lt, ov;
-              merge_partials(pbuf + (i >> 6) * kCrossSplit * kPS, kCrossSplit, i & 63, &m, &lt, &ov);
+              const float* pp = pbuf + (i >> 6) * kCrossSplit * kPS;  // records [o[64], m, l] of this head's key ranges
+              float m = pp[64];
+#pragma unroll
+              for (int sp = 1; sp < kCrossSplit; ++sp) m = fmaxf(m, pp[sp * kPS + 64]);
+              float lt = 0.f, ov = 0.f;
+#pragma unroll
+              for (int sp = 0; sp < kCrossSplit; ++sp) {
+                const float ms = pp[sp * kPS + 64];
+                const float f = ms > -INFINITY ? __expf(ms - m) : 0.f;
+                lt += f * pp[sp * kPS + 65];
+                ov += f * pp[sp * kPS + (i & 63)];
+              }
               act[i] = ov / lt;
             }
           }
@@ -660,7 +680,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_TL(18)
         float res[2];
         ra.run(w_qkv, b_qkv, D, act, ctid, res);
-        ra.publish(ctid, res, [&](int row, float v) { gput(G + O_QKV + row, tag, v); });
+        ra.publish(ctid, res, pk, ctl + 2, G + O_QKV, tag, [](float v) { return v; });
         rb.prefetch(w_o, b_o, D, D, wg, P, ctid, pk_d);
         kv_piece(0, 2);
         AXW_STAMP(17)
@@ -687,7 +707,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_STAMP(19)
           AXW_TL(19)
           rb.run(w_o, b_o, D, act, ctid, res);
-          rb.publish(ctid, res, [&](int row, float v) { gput(G + O_Y1 + row, tag, v); });
+          rb.publish(ctid, res, pk, ctl + 2, G + O_Y1, tag, [](float v) { return v; });
         }
         ra.prefetch(w_cq, b_cq, D, D, wg, P, ctid, pk_d);
         kv_piece(2, 5);
@@ -699,7 +719,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_STAMP(21)
         AXW_TL(20)
         ra.run(w_cq, b_cq, D, act, ctid, res);
-        ra.publish(ctid, res, [&](int row, float v) { gput(G + O_CQ + row, tag, v); });
+        ra.publish(ctid, res, pk, ctl + 2, G + O_CQ, tag, [](float v) { return v; });
         rb.prefetch(w_co, b_co, D, D, wg, P, ctid, pk_d);
         kv_piece(5, 8);
         AXW_STAMP(22)
@@ -718,9 +738,10 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           if (ctid < 64) {
             float m, lt, ov;
             merge_partials(wpart, NCW, ctid, &m, &lt, &ov);
-            u64* out = G + O_PART + (ca_head * kCrossSplit + ca_split) * kPS;
-            if (ctid == 0) { gput(out, tag, m); gput(out + 1, tag, lt); }
-            gput(out + 2 + ctid, tag, ov);
+            // one 64-lane store of o (four full lines) + one 2-lane store of (m, l)
+            u64* out = G + O_PART + (ca_head * kCrossSplit + ca_split) * kRec;
+            gput(out + ctid, tag, ov);
+            if (ctid < 2) gput(out + 64 + ctid, tag, ctid == 0 ? m : lt);
           }
           AXW_STAMP(23)
           AXW_TL(14)
@@ -732,7 +753,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_STAMP(24)
           AXW_TL(21)
           rb.run(w_co, b_co, D, act, ctid, res);
-          rb.publish(ctid, res, [&](int row, float v) { gput(G + O_Y2 + row, tag, v); });
+          rb.publish(ctid, res, pk, ctl + 2, G + O_Y2, tag, [](float v) { return v; });
         }
         ra.prefetch(w_fc1, b_fc1, D, F, wg, P, ctid, pk_f);
         kv_piece(8, 11);
@@ -744,7 +765,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_STAMP(26)
         AXW_TL(22)
         ra.run(w_fc1, b_fc1, D, act, ctid, res);
-        ra.publish(ctid, res, [&](int row, float v) { gput(G + O_HID + row, tag, gelu_erf(v)); });
+        ra.publish(ctid, res, pk, ctl + 2, G + O_HID, tag, [](float v) { return gelu_erf(v); });
         rs_fc2.prefetch(w_fc2, b_fc2, F, D, wg, P, ctid, pk_d);
         kv_piece(11, 13);
         AXW_STAMP(27)
@@ -755,7 +776,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_STAMP(28)
           AXW_TL(23)
           rs_fc2.run(w_fc2, b_fc2, F, act, ctid, res);
-          rs_fc2.publish(ctid, res, [&](int row, float v) { gput(G + O_Y3 + row, tag, v); });
+          rs_fc2.publish(ctid, res, pk, ctl + 2, G + O_Y3, tag, [](float v) { return v; });
           AXW_STAMP(31)
         }
         // next consumer of the residual stream: the next layer's QKV rows, the vocabulary projection, or the next step
@@ -845,9 +866,11 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         if (ctid == 0) {
           for (int w2 = 1; w2 < NCW; ++w2)
             if (am_v[8 + w2] > bv || (am_v[8 + w2] == bv && am_i[8 + w2] < bi)) { bv = am_v[8 + w2]; bi = am_i[8 + w2]; }
-          gput(G + O_AMAX + 2 * wg, (unsigned)(step + 1), bv);
-          gput_u(G + O_AMAX + 2 * wg + 1, (unsigned)(step + 1), (unsigned)bi);
+          am_v[8] = bv; am_i[8] = bi;
         }
+        __builtin_amdgcn_wave_barrier();
+        if (ctid < 2)  // value and index of this workgroup's best row in ONE store instruction
+          gput_u(G + O_AMAX + 2 * wg + ctid, (unsigned)(step + 1), ctid == 0 ? __float_as_uint(am_v[8]) : (unsigned)am_i[8]);
         AXW_STAMP(30)
         AXW_BARRIER_CHECK(0xA00)  // B4
       }
@@ -897,7 +920,7 @@ bool decode_persistent_supported(int d_model, int n_head, int n_layer, int n_cu)
 size_t decode_persistent_gran_bytes(int d_model, int grid) { return ((size_t)16 * d_model + 2 * (size_t)grid + 64) * 8; }
 
 static size_t persist_lds_bytes(int d) {
-  return (size_t)kKvBytes + ((size_t)4 * d + d / 8 + NCW * kPS + 2 * NPW + 64 + 16 + 16 + 16 + NCW * 64) * 4 + 64 * 8 + 64;
+  return (size_t)kKvBytes + ((size_t)4 * d + d / 8 + NCW * kPS + 2 * NPW + 64 + 16 + 16 + 16 + 64 + NCW * 64) * 4 + 64 * 8 + 64;
 }
 
 template <int LD, int CD, int LF, int CF, bool PROF>
