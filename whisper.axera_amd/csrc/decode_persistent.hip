@@ -306,7 +306,8 @@ template <int LD, int CD, int LF, int CF, bool PROF>
 __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) {
   constexpr int D = 8 * LD * CD, F = 8 * LF * CF, H = D / 64;
   static_assert(F == 4 * D, "mlp width");
-  constexpr int GD = (D + PL - 1) / PL, GF = (F + PL - 1) / PL, NPART = H * kCrossSplit * kPS, GP = (NPART + PL - 1) / PL;
+  constexpr int GD = (D + PL - 1) / PL, NPART = H * kCrossSplit * kPS;
+  constexpr int NP1 = (NPART + 1) / 2, GP1 = (NP1 + PL - 1) / PL, GP2 = (NPART - NP1 + CT - 1) / CT;  // partial-record gather, split between the roles
   constexpr int NU = kCrossSplit * H;  // cross-attention units per layer
   // granule buffers (u64 units)
   constexpr int O_QKV = 0, O_ATT = 3 * D, O_Y1 = 4 * D, O_CQ = 5 * D, O_PART = 6 * D, O_Y2 = 10 * D, O_HID = 11 * D, O_Y3 = 15 * D,
@@ -501,11 +502,12 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         }
         // ---- cross-attention output projection: merge the partials of every head
         if (in_o) {
-          unsigned y[GP];
-          const bool fail = gather<GP>(G + O_PART, tag, y, p.err, ctl, [&](int k) { const int i = tid + k * PL; return i < NPART ? (i / kPS) * kRec + i % kPS : -1; });
+          // the pollers collect the first NP1 granules of the partial records, the (idle) compute waves the rest
+          unsigned y[GP1];
+          const bool fail = gather<GP1>(G + O_PART, tag, y, p.err, ctl, [&](int k) { const int i = tid + k * PL; return i < NP1 ? (i / kPS) * kRec + i % kPS : -1; });
           float* pbuf = act + D;  // [H][kCrossSplit][66]
 #pragma unroll
-          for (int k = 0; k < GP; ++k) { const int i = tid + k * PL; if (i < NPART) pbuf[i] = __uint_as_float(y[k]); }
+          for (int k = 0; k < GP1; ++k) { const int i = tid + k * PL; if (i < NP1) pbuf[i] = __uint_as_float(y[k]); }
           if (fail) ctl[0] = 1;
           AXW_STAMP(9)
           AXW_TL(5)
@@ -545,18 +547,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_STAMP(12)
           AXW_TL(8)
         }
-        // ---- mlp.2
+        // ---- mlp.2: the 4d-wide hidden vector is the largest hand-off; the pollers collect its first half, the compute
+        //      waves (idle until it is complete, their rows already in registers) the second half
         if (in_f2) {
-          // in chunks of at most 6 granules per lane (register budget of the widest model)
-          constexpr int GC = GF <= 6 ? GF : (GF + 1) / 2;
-          bool fail = false;
+          constexpr int GH = (F / 2 + PL - 1) / PL;
+          unsigned y[GH];
+          const bool fail = gather<GH>(G + O_HID, tag, y, p.err, ctl, [&](int k) { const int i = tid + k * PL; return i < F / 2 ? i : -1; });
 #pragma unroll
-          for (int c0 = 0; c0 < GF; c0 += GC) {
-            unsigned y[GC];
-            fail |= gather<GC>(G + O_HID, tag, y, p.err, ctl, [&](int k) { const int i = tid + (c0 + k) * PL; return (c0 + k < GF && i < F) ? i : -1; });
-#pragma unroll
-            for (int k = 0; k < GC; ++k) { const int i = tid + (c0 + k) * PL; if (c0 + k < GF && i < F) act[i] = __uint_as_float(y[k]); }
-          }
+          for (int k = 0; k < GH; ++k) { const int i = tid + k * PL; if (i < F / 2) act[i] = __uint_as_float(y[k]); }
           if (fail) ctl[0] = 1;
           AXW_STAMP(13)
           AXW_TL(9)
@@ -748,6 +746,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         }
         // ---- cross-attention output projection
         if (in_o) {
+          {
+            unsigned y[GP2];
+            const bool fail = gather<GP2>(G + O_PART, tag, y, p.err, ctl, [&](int k) { const int i = NP1 + ctid + k * CT; return i < NPART ? (i / kPS) * kRec + i % kPS : -1; });
+            float* pbuf = act + D;
+#pragma unroll
+            for (int k = 0; k < GP2; ++k) { const int i = NP1 + ctid + k * CT; if (i < NPART) pbuf[i] = __uint_as_float(y[k]); }
+            if (fail) ctl[0] = 1;
+          }
           AXW_BARRIER_CHECK(0x600 + l)
           wg_barrier();
           AXW_STAMP(24)
@@ -772,6 +778,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_TL(16)
         // ---- mlp.2
         if (in_f2) {
+          {
+            constexpr int GH = (F / 2 + CT - 1) / CT;
+            unsigned y[GH];
+            const bool fail = gather<GH>(G + O_HID, tag, y, p.err, ctl, [&](int k) { const int i = ctid + k * CT; return i < F / 2 ? F / 2 + i : -1; });
+#pragma unroll
+            for (int k = 0; k < GH; ++k) { const int i = ctid + k * CT; if (i < F / 2) act[F / 2 + i] = __uint_as_float(y[k]); }
+            if (fail) ctl[0] = 1;
+          }
           AXW_BARRIER_CHECK(0x800 + l)
           AXW_STAMP(28)
           AXW_TL(23)
