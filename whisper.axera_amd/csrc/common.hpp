@@ -217,6 +217,7 @@ struct PersistParams {
   const int* sot;               // device [4]
   const int* forced; int n_forced; float* logits_dump; int* argmax_dump;   // teacher forcing (tests)
   u64* gran; unsigned* err;     // granule area + error word, zeroed before every launch
+  int gran_bytes;               // size of the granule area (buffer-resource bound of the 16-byte polls)
   int* out_ids; int* n_out; DecState* state;
   int fault;                    // test hook (AX_WHISPER_PERSIST_FAULT=1): workgroup 0 leaves at once, so the launch must give up
   long long* prof;              // optional [grid][64]: per-phase 100 MHz tick sums + one layer's absolute timeline (AX_WHISPER_PERSIST_PROF), else nullptr

@@ -100,6 +100,32 @@ __device__ __forceinline__ unsigned eget(const unsigned* e) {
   return __hip_atomic_load((gu32*)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Pair polls: 16-byte sc1 loads of two adjacent granules (profiles/microbench/publish_shape.cpp: a hand-off gathered
+// with 16-byte polls completes 0.25 us earlier than with 8-byte ones). pidx(k) = granule index of the k-th pair of this
+// lane (even), < 0: none. v[2k], v[2k+1] = the two values. Returns true on give-up.
+template <int NP, typename IDX>
+__device__ __forceinline__ bool gather2(__amdgpu_buffer_rsrc_t rs, unsigned tag, unsigned (&v)[2 * NP], const unsigned* err, const int* ctl, IDX pidx) {
+  bool ok[NP];
+  int ix[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) { ix[k] = pidx(k); ok[k] = ix[k] < 0; v[2 * k] = 0u; v[2 * k + 1] = 0u; }
+  for (int spins = 0; spins < kSpinMax; ++spins) {
+    bool all = true;
+    u32x4 x[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) if (!ok[k]) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ix[k] * 8, 0, 16);  // aux 16 = sc1
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+      if (!ok[k]) {
+        if (x[k][1] == tag && x[k][3] == tag) { v[2 * k] = x[k][0]; v[2 * k + 1] = x[k][2]; ok[k] = true; } else all = false;
+      }
+    if (all) return false;
+    if ((spins & 63) == 63 && *(volatile const int*)ctl) return true;  // a wave of this workgroup gave up
+    if ((spins & 1023) == 1023 && eget(err)) return true;             // another workgroup gave up: leave as well
+  }
+  return true;
+}
+
 // Lane `tid` collects granules idx(k) for k < MAXG (idx < 0: none) of epoch `tag`; returns true on give-up.
 template <int MAXG, typename IDX>
 __device__ __forceinline__ bool gather(const u64* buf, unsigned tag, unsigned (&v)[MAXG], const unsigned* err, const int* ctl, IDX idx) {
@@ -306,8 +332,10 @@ template <int LD, int CD, int LF, int CF, bool PROF>
 __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) {
   constexpr int D = 8 * LD * CD, F = 8 * LF * CF, H = D / 64;
   static_assert(F == 4 * D, "mlp width");
-  constexpr int GD = (D + PL - 1) / PL, NPART = H * kCrossSplit * kPS;
-  constexpr int NP1 = (NPART + 1) / 2, GP1 = (NP1 + PL - 1) / PL, GP2 = (NPART - NP1 + CT - 1) / CT;  // partial-record gather, split between the roles
+  // a poller lane owns PAIRS of adjacent vector elements: pair tid + j*PL (j < GPD) = elements 2*pair, 2*pair + 1
+  constexpr int GPD = (D / 2 + PL - 1) / PL, GD = 2 * GPD, NPART = H * kCrossSplit * kPS;
+  constexpr int NPP = NPART / 2, NPP1 = (NPP + 1) / 2, GP1 = (NPP1 + PL - 1) / PL, GP2 = (NPP - NPP1 + CT - 1) / CT;  // partial-record pairs, split between the roles
+  static_assert(NPART % 2 == 0 && kPS % 2 == 0 && kRec % 2 == 0 && D % 2 == 0, "pair polls need even layouts");
   constexpr int NU = kCrossSplit * H;  // cross-attention units per layer
   // granule buffers (u64 units)
   constexpr int O_QKV = 0, O_ATT = 3 * D, O_Y1 = 4 * D, O_CQ = 5 * D, O_PART = 6 * D, O_Y2 = 10 * D, O_HID = 11 * D, O_Y3 = 15 * D,
@@ -336,6 +364,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   const int P = gridDim.x, wg = blockIdx.x;
   const int L = p.n_layer;
   u64* const G = p.gran;
+  const __amdgpu_buffer_rsrc_t GR = __builtin_amdgcn_make_buffer_rsrc((void*)p.gran, 0, p.gran_bytes, 0x27000);
 
   // self-attention ownership: unit (l, h) -> workgroup P-1-(l*H+h). The other NS workgroups take the cross-attention
   // units: unit u of layer l -> workgroup (l*NU + u) % NS.
@@ -385,22 +414,24 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     float x[GD];        // residual stream, element tid + k*PL
     float lg[GD], lb[GD];
     float shift = 0.f;  // LayerNorm variance shift (previous mean): sums stay small without a second pass
+    auto el = [&](int k) { return 2 * (tid + (k >> 1) * PL) + (k & 1); };  // vector element of register slot k
     auto ln_prefetch = [&](const float* g, const float* be) {
 #pragma unroll
       for (int k = 0; k < GD; ++k) {
-        const int i = tid + k * PL;
+        const int i = el(k);
         lg[k] = i < D ? g[i] : 0.f;
         lb[k] = i < D ? be[i] : 0.f;
       }
     };
-    auto idx_d = [&](int k) { const int i = tid + k * PL; return i < D ? i : -1; };
+    // the pairs of a d-wide vector that starts at granule `base`
+#define AXW_PAIRS_D(BASE) [&](int j) { const int pr = tid + j * PL; return 2 * pr < D ? (BASE) + 2 * pr : -1; }
 
     // x += y, LayerNorm into act[0..D): two workgroup barriers
 #define AXW_LN_STAGE(Y, ADD, FAIL, CODE)                                                    \
   {                                                                                          \
     float s1 = 0.f, s2 = 0.f;                                                                \
     _Pragma("unroll") for (int k = 0; k < GD; ++k) {                                         \
-      if (tid + k * PL < D) {                                                                \
+      if (el(k) < D) {                                                                       \
         if (ADD) x[k] += __uint_as_float(Y[k]);                                              \
         const float t = x[k] - shift;                                                        \
         s1 += t; s2 += t * t;                                                                \
@@ -415,7 +446,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     const float dm = t1 / D, var = fmaxf(t2 / D - dm * dm, 0.f);                             \
     const float mean = shift + dm, rstd = rsqrtf(var + 1e-5f);                               \
     _Pragma("unroll") for (int k = 0; k < GD; ++k) {                                         \
-      const int i = tid + k * PL;                                                            \
+      const int i = el(k);                                                                   \
       if (i < D) act[i] = (x[k] - mean) * rstd * lg[k] + lb[k];                              \
     }                                                                                        \
     shift = mean;                                                                            \
@@ -426,7 +457,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
       // x = token_embedding[tok] + positional_embedding[step]   (export_onnx.py:334-336)
 #pragma unroll
       for (int k = 0; k < GD; ++k) {
-        const int i = tid + k * PL;
+        const int i = el(k);
         x[k] = i < D ? (float)p.tok_emb[(long)tok * D + i] + p.pos[(long)step * D + i] : 0.f;
       }
       ln_prefetch(p.fl + DecArena::F_ATTN_LN_W * D, p.fl + DecArena::F_ATTN_LN_B * D);
@@ -440,7 +471,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         {
           unsigned y[GD];
           bool fail = false;
-          if (l > 0) fail = gather<GD>(G + O_Y3, tag - 1, y, p.err, ctl, idx_d);
+          if (l > 0) fail = gather2<GPD>(GR, tag - 1, y, p.err, ctl, AXW_PAIRS_D(O_Y3));
           AXW_STAMP(0)
           AXW_TL(0)
           AXW_LN_STAGE(y, l > 0, fail, 0x100 + l)
@@ -450,14 +481,18 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         }
         // ---- self-attention owner: collect q, k, v of the head; append k, v to the LDS cache
         if (l == sa_layer) {
-          unsigned v[1];
-          const bool fail = gather<1>(G + O_QKV, tag, v, p.err, ctl, [&](int) { return tid < 192 ? (tid >> 6) * D + sa_head * 64 + (tid & 63) : -1; });
-          if (tid < 64) qs[tid] = __uint_as_float(v[0]);
-          else if (tid < 128) {  // K row `step`, blocked [blk][d/8][key%64][8]
-            const int dd = tid - 64;
-            sK[(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (bf16)__uint_as_float(v[0]);
-          } else if (tid < 192) {
-            sV[step * 64 + (tid - 128)] = (bf16)__uint_as_float(v[0]);
+          unsigned v[2];  // lanes 0-31: q, 32-63: k, 64-95: v of the head, two adjacent dims each
+          const bool fail = gather2<1>(GR, tag, v, p.err, ctl, [&](int) { return tid < 96 ? O_QKV + (tid >> 5) * D + sa_head * 64 + 2 * (tid & 31) : -1; });
+          if (tid < 96) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int dd = 2 * (tid & 31) + e;
+              const float val = __uint_as_float(v[e]);
+              if (tid < 32) qs[dd] = val;
+              else if (tid < 64)  // K row `step`, blocked [blk][d/8][key%64][8]
+                sK[(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (bf16)val;
+              else sV[step * 64 + dd] = (bf16)val;
+            }
           }
           if (fail) ctl[0] = 1;
           AXW_STAMP(2)
@@ -468,9 +503,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         // ---- attention output projection
         if (in_o) {
           unsigned y[GD];
-          const bool fail = gather<GD>(G + O_ATT, tag, y, p.err, ctl, idx_d);
+          const bool fail = gather2<GPD>(GR, tag, y, p.err, ctl, AXW_PAIRS_D(O_ATT));
 #pragma unroll
-          for (int k = 0; k < GD; ++k) { const int i = tid + k * PL; if (i < D) act[i] = __uint_as_float(y[k]); }
+          for (int k = 0; k < GD; ++k) { const int i = el(k); if (i < D) act[i] = __uint_as_float(y[k]); }
           if (fail) ctl[0] = 1;
           AXW_STAMP(4)
           AXW_TL(2)
@@ -479,7 +514,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         // ---- cross-attention query
         {
           unsigned y[GD];
-          const bool fail = gather<GD>(G + O_Y1, tag, y, p.err, ctl, idx_d);
+          const bool fail = gather2<GPD>(GR, tag, y, p.err, ctl, AXW_PAIRS_D(O_Y1));
           AXW_STAMP(5)
           AXW_TL(3)
           AXW_LN_STAGE(y, true, fail, 0x400 + l)
@@ -491,9 +526,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         const int cu = ca_unit_of(l);
         if (cu >= 0) {
           const int ca_head = cu / kCrossSplit;
-          unsigned v[1];
-          const bool fail = gather<1>(G + O_CQ, tag, v, p.err, ctl, [&](int) { return tid < 64 ? ca_head * 64 + tid : -1; });
-          if (tid < 64) qs[tid] = __uint_as_float(v[0]);
+          unsigned v[2];
+          const bool fail = gather2<1>(GR, tag, v, p.err, ctl, [&](int) { return tid < 32 ? O_CQ + ca_head * 64 + 2 * tid : -1; });
+          if (tid < 32) { qs[2 * tid] = __uint_as_float(v[0]); qs[2 * tid + 1] = __uint_as_float(v[1]); }
           if (fail) ctl[0] = 1;
           AXW_STAMP(7)
           AXW_BARRIER_CHECK(0x500 + l)
@@ -503,11 +538,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         // ---- cross-attention output projection: merge the partials of every head
         if (in_o) {
           // the pollers collect the first NP1 granules of the partial records, the (idle) compute waves the rest
-          unsigned y[GP1];
-          const bool fail = gather<GP1>(G + O_PART, tag, y, p.err, ctl, [&](int k) { const int i = tid + k * PL; return i < NP1 ? (i / kPS) * kRec + i % kPS : -1; });
+          unsigned y[2 * GP1];  // pair pi of the records: record pi / 33, granules 2 * (pi % 33), +1
+          const bool fail = gather2<GP1>(GR, tag, y, p.err, ctl, [&](int j) { const int pi = tid + j * PL; return pi < NPP1 ? O_PART + (pi / (kPS / 2)) * kRec + 2 * (pi % (kPS / 2)) : -1; });
           float* pbuf = act + D;  // [H][kCrossSplit][66]
 #pragma unroll
-          for (int k = 0; k < GP1; ++k) { const int i = tid + k * PL; if (i < NP1) pbuf[i] = __uint_as_float(y[k]); }
+          for (int j = 0; j < GP1; ++j) {
+            const int pi = tid + j * PL;
+            if (pi < NPP1) { pbuf[2 * pi] = __uint_as_float(y[2 * j]); pbuf[2 * pi + 1] = __uint_as_float(y[2 * j + 1]); }
+          }
           if (fail) ctl[0] = 1;
           AXW_STAMP(9)
           AXW_TL(5)
@@ -538,7 +576,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         // ---- mlp.0
         {
           unsigned y[GD];
-          const bool fail = gather<GD>(G + O_Y2, tag, y, p.err, ctl, idx_d);
+          const bool fail = gather2<GPD>(GR, tag, y, p.err, ctl, AXW_PAIRS_D(O_Y2));
           AXW_STAMP(11)
           AXW_TL(7)
           AXW_LN_STAGE(y, true, fail, 0x700 + l)
@@ -550,11 +588,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         // ---- mlp.2: the 4d-wide hidden vector is the largest hand-off; the pollers collect its first half, the compute
         //      waves (idle until it is complete, their rows already in registers) the second half
         if (in_f2) {
-          constexpr int GH = (F / 2 + PL - 1) / PL;
-          unsigned y[GH];
-          const bool fail = gather<GH>(G + O_HID, tag, y, p.err, ctl, [&](int k) { const int i = tid + k * PL; return i < F / 2 ? i : -1; });
+          constexpr int GH = (F / 4 + PL - 1) / PL;  // pairs per lane of the first half
+          unsigned y[2 * GH];
+          const bool fail = gather2<GH>(GR, tag, y, p.err, ctl, [&](int j) { const int pi = tid + j * PL; return pi < F / 4 ? O_HID + 2 * pi : -1; });
 #pragma unroll
-          for (int k = 0; k < GH; ++k) { const int i = tid + k * PL; if (i < F / 2) act[i] = __uint_as_float(y[k]); }
+          for (int j = 0; j < GH; ++j) {
+            const int pi = tid + j * PL;
+            if (pi < F / 4) { act[2 * pi] = __uint_as_float(y[2 * j]); act[2 * pi + 1] = __uint_as_float(y[2 * j + 1]); }
+          }
           if (fail) ctl[0] = 1;
           AXW_STAMP(13)
           AXW_TL(9)
@@ -571,16 +612,15 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
       // ---- final LayerNorm for the vocabulary projection, then merge the argmax partials of every workgroup
       {
         unsigned y[GD];
-        const bool fail = gather<GD>(G + O_Y3, (unsigned)(step * L + L), y, p.err, ctl, idx_d);
+        const bool fail = gather2<GPD>(GR, (unsigned)(step * L + L), y, p.err, ctl, AXW_PAIRS_D(O_Y3));
         AXW_LN_STAGE(y, true, fail, 0x900)
         AXW_STAMP(14)
         wg_barrier();  // B3: the compute waves have their workgroup argmax
-        unsigned v[1];
-        const bool fail2 = gather<1>(G + O_AMAX, (unsigned)(step + 1), v, p.err, ctl, [&](int) { return tid < 2 * P ? tid : -1; });
-        // even lane = value of workgroup tid/2, odd lane = its index; first max wins (Whisper.cpp:42-45)
-        float cv = (tid < 2 * P && !(tid & 1)) ? __uint_as_float(v[0]) : -INFINITY;
-        int ci = (int)__shfl_down(v[0], 1, 64);
-        if (tid >= 2 * P || (tid & 1)) { cv = -INFINITY; ci = 0x7fffffff; }
+        unsigned v[2];  // {value, row index} of workgroup tid: one pair
+        const bool fail2 = gather2<1>(GR, (unsigned)(step + 1), v, p.err, ctl, [&](int) { return tid < P ? O_AMAX + 2 * tid : -1; });
+        // first max wins (Whisper.cpp:42-45)
+        float cv = tid < P ? __uint_as_float(v[0]) : -INFINITY;
+        int ci = tid < P ? (int)v[1] : 0x7fffffff;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
           const float ov = __shfl_xor(cv, o, 64);
@@ -609,6 +649,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
       }
     }
 #undef AXW_LN_STAGE
+#undef AXW_PAIRS_D
   } else {
     // ======================================================================================= compute waves
     // The pollers spin; without a priority the arbiter gives their loops the same share of the issue slots as the
@@ -747,11 +788,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         // ---- cross-attention output projection
         if (in_o) {
           {
-            unsigned y[GP2];
-            const bool fail = gather<GP2>(G + O_PART, tag, y, p.err, ctl, [&](int k) { const int i = NP1 + ctid + k * CT; return i < NPART ? (i / kPS) * kRec + i % kPS : -1; });
+            unsigned y[2 * GP2];
+            const bool fail = gather2<GP2>(GR, tag, y, p.err, ctl, [&](int j) { const int pi = NPP1 + ctid + j * CT; return pi < NPP ? O_PART + (pi / (kPS / 2)) * kRec + 2 * (pi % (kPS / 2)) : -1; });
             float* pbuf = act + D;
 #pragma unroll
-            for (int k = 0; k < GP2; ++k) { const int i = NP1 + ctid + k * CT; if (i < NPART) pbuf[i] = __uint_as_float(y[k]); }
+            for (int j = 0; j < GP2; ++j) {
+              const int pi = NPP1 + ctid + j * CT;
+              if (pi < NPP) { pbuf[2 * pi] = __uint_as_float(y[2 * j]); pbuf[2 * pi + 1] = __uint_as_float(y[2 * j + 1]); }
+            }
             if (fail) ctl[0] = 1;
           }
           AXW_BARRIER_CHECK(0x600 + l)
@@ -779,11 +823,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         // ---- mlp.2
         if (in_f2) {
           {
-            constexpr int GH = (F / 2 + CT - 1) / CT;
-            unsigned y[GH];
-            const bool fail = gather<GH>(G + O_HID, tag, y, p.err, ctl, [&](int k) { const int i = ctid + k * CT; return i < F / 2 ? F / 2 + i : -1; });
+            constexpr int GH = (F / 4 + CT - 1) / CT;
+            unsigned y[2 * GH];
+            const bool fail = gather2<GH>(GR, tag, y, p.err, ctl, [&](int j) { const int pi = ctid + j * CT; return pi < F / 4 ? O_HID + F / 2 + 2 * pi : -1; });
 #pragma unroll
-            for (int k = 0; k < GH; ++k) { const int i = ctid + k * CT; if (i < F / 2) act[F / 2 + i] = __uint_as_float(y[k]); }
+            for (int j = 0; j < GH; ++j) {
+              const int pi = ctid + j * CT;
+              if (pi < F / 4) { act[F / 2 + 2 * pi] = __uint_as_float(y[2 * j]); act[F / 2 + 2 * pi + 1] = __uint_as_float(y[2 * j + 1]); }
+            }
             if (fail) ctl[0] = 1;
           }
           AXW_BARRIER_CHECK(0x800 + l)

@@ -788,6 +788,7 @@ int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float
   p.sot = d_sot_;
   p.forced = d_forced; p.n_forced = n_forced; p.logits_dump = d_logits; p.argmax_dump = d_argmax;
   p.gran = d_gran_;
+  p.gran_bytes = (int)gran_bytes_;
   p.err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(d_gran_) + gran_bytes_ - 8);
   p.out_ids = d_out_ids_; p.n_out = d_nout_; p.state = d_state_;
   long long* d_prof = nullptr;
