@@ -497,7 +497,6 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           if (fail) ctl[0] = 1;
           AXW_STAMP(2)
           AXW_BARRIER_CHECK(0x200 + l)
-          wg_barrier();
           AXW_STAMP(3)
         }
         // ---- attention output projection
@@ -532,7 +531,6 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           if (fail) ctl[0] = 1;
           AXW_STAMP(7)
           AXW_BARRIER_CHECK(0x500 + l)
-          wg_barrier();
           AXW_STAMP(8)
         }
         // ---- cross-attention output projection: merge the partials of every head
@@ -731,11 +729,15 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           const int nblk = (step >> 6) + 1;
           if (cw < nblk)
             attn_block(sK + cw * 4096, sV + cw * 4096, qs, cw * 64 + lane <= step, pscr + cw * 64, wpart + cw * kPS, lane);
-          wg_barrier();
-          if (ctid < 64) {
+          // no second workgroup barrier: the compute wave that arrives last merges the block partials and publishes
+          __builtin_amdgcn_wave_barrier();
+          int old = 0;
+          if (lane == 0) old = __hip_atomic_fetch_add(ctl + 3, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+          old = __builtin_amdgcn_readfirstlane(old);
+          if ((old + 1) % NCW == 0) {
             float m, lt, ov;
-            merge_partials(wpart, nblk, ctid, &m, &lt, &ov);
-            gput(G + O_ATT + sa_head * 64 + ctid, tag, ov / lt);
+            merge_partials(wpart, nblk, lane, &m, &lt, &ov);
+            gput(G + O_ATT + sa_head * 64 + lane, tag, ov / lt);
           }
           AXW_STAMP(18)
           AXW_TL(11)
@@ -773,8 +775,12 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           asm volatile("" ::: "memory");
           const int key = (ca_split * NCW + cw) * 64 + lane;
           attn_block(sK + cw * 4096, sV + cw * 4096, qs, key < p.n_audio_ctx, pscr + cw * 64, wpart + cw * kPS, lane);
-          wg_barrier();
-          if (ctid < 64) {
+          __builtin_amdgcn_wave_barrier();
+          int old = 0;
+          if (lane == 0) old = __hip_atomic_fetch_add(ctl + 3, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+          old = __builtin_amdgcn_readfirstlane(old);
+          if ((old + 1) % NCW == 0) {  // the wave that arrives last merges and publishes
+            const int ctid = lane;
             float m, lt, ov;
             merge_partials(wpart, NCW, ctid, &m, &lt, &ov);
             // one 64-lane store of o (four full lines) + one 2-lane store of (m, l)
