@@ -9,8 +9,9 @@
 // bound by per-phase latency, not by HBM. As separate graph nodes a phase costs ~4.4 us (kernel
 // boundary + wave start + activation round trip + drain). Here one 1024-thread workgroup per CU stays resident for
 // the whole utterance and the phases hand their outputs over INSIDE the launch:
-//   * every output element travels as one 8-byte {tag, value} granule written by ONE sc1 (write-through) store and
-//     polled with sc1 loads — the data is the flag, no fence, no separate barrier
+//   * every output element travels as one 8-byte {tag, value} granule; a producer assembles its rows in LDS and ONE
+//     wave stores them with ONE sc1 (write-through) instruction (a full 128-byte line), consumers poll pairs of
+//     granules with 16-byte sc1 loads — the data is the flag, no fence, no separate barrier
 //     (cdna_hip_programming.md §6 Guideline 16 form R2; tags = step * n_layer + layer + 1, never 0, buffers zeroed
 //     before every launch);
 //   * the waves of a workgroup have fixed ROLES: waves 0-7 ("pollers") gather granules, keep the residual stream in
