@@ -20,7 +20,16 @@ namespace axw {
       throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);       \
   } while (0)
 
-constexpr int kLogitsRT = 2;  // weight-row tiles per wave of the batched vocabulary projection (32 rows / workgroup)
+// weight-row tiles per wave of the batched vocabulary projection (16 rows each per workgroup); AX_WHISPER_LOGITS_RT overrides (1, 2, 4)
+static int logits_rt() {
+  static const int v = [] {
+    const char* e = getenv("AX_WHISPER_LOGITS_RT");
+    const int r = e ? atoi(e) : 2;
+    return (r == 1 || r == 2 || r == 4) ? r : 2;
+  }();
+  return v;
+}
+#define kLogitsRT logits_rt()
 
 static int dtype_code(const std::string& d) { return d == "F32" ? 0 : d == "BF16" ? 1 : 2; }
 

@@ -27,76 +27,117 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 
 // Epilogue of one wave's 64x64 sub-tile (2x2 accumulator tiles), shared by both tile shapes.
+//   normal:  acc[i][j][e] = C[m = mb + i*32 + row(e,h)][n = nb + j*32 + r]
+//   swapped: acc[i][j][e] = C[m = mb + i*32 + r][n = nb + j*32 + row(e,h)],  row(e,h) = (e&3) + 8*(e>>2) + 4*h
+// In both orientations a lane holds single elements of 16 different output rows, so writing from the registers
+// costs 64 narrow store instructions per wave (and, for the in-place residual add, 64 dependent load -> add -> store
+// round trips: 33 us per 256x128 tile against 16 us for its whole k-loop). Instead every wave parks its sub-tile
+// as fp32 in its own 16 KB of the staging buffers (idle once the k-loop is done) with the lanes along the output's
+// CONTIGUOUS axis, and reads it back as rows: one 16-byte ds_read per lane = 4 consecutive outputs, a wave
+// instruction = 4 full rows of the sub-tile, every global access on whole 128/256-byte row segments, all loads of
+// the residual add issued before the first store. The one layout that is contiguous along neither axis of the
+// accumulator tile (the decoder's blocked cross K) keeps the register path: its lanes already store 8 contiguous
+// bytes each, 512 contiguous bytes per wave instruction.
 template <int EPI, bool SWAPPED>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][2], int mb, int nb, int bz, int r, int h) {
-  // ------------------------------------------------------------------ epilogue
-  // normal:  acc[i][j][e] = C[m = mb + i*32 + row(e,h)][n = nb + j*32 + r]
-  // swapped: acc[i][j][e] = C[m = mb + i*32 + r][n = nb + j*32 + row(e,h)],  row(e,h) = (e&3) + 8*(e>>2) + 4*h
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][2], float* lw, int mb, int nb, int bz, int lane) {
+  const int r = lane & 31, h = lane >> 5;
   const int d = p.d_model;
-
-  if constexpr (!SWAPPED) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = nb + j * 32 + r;
-      const float bias = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = mb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (m >= p.M) continue;
-          float v = acc[i][j][e] + bias;
-          if constexpr (EPI == EPI_BIAS_BF16) {
-            reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] = (bf16)v;
-          } else if constexpr (EPI == EPI_BIAS_GELU_BF16) {
-            reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] = (bf16)gelu_erf_fast(v);
-          } else if constexpr (EPI == EPI_GELU_POS_F32) {
-            reinterpret_cast<float*>(p.C)[(long)bz * p.c_batch_stride + (long)m * p.ldc + n] =
-                gelu_erf(v) + p.aux[(long)m * p.N + n];
-          } else if constexpr (EPI == EPI_RESID_F32) {
-            float* c = reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n;
-            *c += v;
-          } else if constexpr (EPI == EPI_QKV) {  // Q (n < d) or K (d <= n < 2d), both bf16 [m][d]
-            if (n < d) reinterpret_cast<bf16*>(p.C)[(long)bz * p.c_batch_stride + (long)m * d + n] = (bf16)v;
-            else reinterpret_cast<bf16*>(p.C2)[(long)bz * p.c2_batch_stride + (long)m * d + (n - d)] = (bf16)v;
-          } else {  // EPI_CROSS_KV, V rows [n_layer*d, 2*n_layer*d): [l][slot][head][t_pad][64]
-            const int nv = n - p.n_layer * d;
-            const int l = nv / d, c = nv - l * d;
-            const int head = c >> 6, dd = c & 63;
-            const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + head;
-            reinterpret_cast<bf16*>(p.C2)[(slot * p.t_pad + m) * 64 + dd] = (bf16)v;
-          }
-        }
-      }
-    }
-  } else {
+  if constexpr (EPI == EPI_CROSS_KV && SWAPPED) {  // K rows [0, n_layer*d): blocked [l][slot][head][m/64][dd/8][m%64][8]
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = mb + i * 32 + r;
       if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        if constexpr (EPI == EPI_QKV) {  // V^T [head][64][t_pad], lanes run along m (coalesced)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int n = nb + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const float v = acc[i][j][e] + (p.bias ? p.bias[n] : 0.f);
-            const int c = n - 2 * d;
-            reinterpret_cast<bf16*>(p.C3)[(long)bz * p.c3_batch_stride + (long)c * p.t_pad + m] = (bf16)v;
+        for (int q = 0; q < 4; ++q) {
+          const int n = nb + j * 32 + 8 * q + 4 * h;
+          const int l = n / d, c = n - l * d;
+          const int head = c >> 6, dd = c & 63;
+          bf16x4 pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pk[e] = (bf16)(acc[i][j][4 * q + e] + (p.bias ? p.bias[n + e] : 0.f));
+          const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + head;
+          bf16* dst = reinterpret_cast<bf16*>(p.C) + slot * p.t_pad * 64 + (long)(m >> 6) * 4096 + (dd >> 3) * 512 + (m & 63) * 8 + (dd & 7);
+          *reinterpret_cast<bf16x4*>(dst) = pk;
+        }
+      }
+    }
+  } else {
+    // park: LDS row = index along the accumulator's register axis, LDS column = lane axis (conflict-free b32 stores)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int reg_ax = (SWAPPED ? j : i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int lane_ax = (SWAPPED ? i : j) * 32 + r;
+          lw[reg_ax * 64 + lane_ax] = acc[i][j][e];
+        }
+    // read back rows: lane -> row 4t + (lane>>4), columns 4*(lane&15) .. +3
+    const int rr = lane >> 4, cc = (lane & 15) * 4;
+    if constexpr (!SWAPPED) {  // rows = m, columns = n
+      const int n = nb + cc;
+      f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+      if constexpr (EPI == EPI_RESID_F32) {
+        f32x4 cur[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int m = min(mb + 4 * t + rr, p.M - 1);
+          cur[t] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int row = 4 * t + rr, m = mb + row;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc) + bias4 + cur[t];
+          if (m < p.M) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n) = v;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int row = 4 * t + rr, m = mb + row;
+          if (m >= p.M) continue;
+          f32x4 v = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc) + bias4;
+          if constexpr (EPI == EPI_GELU_POS_F32) {
+            const f32x4 pos = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.N + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]) + pos[e];
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n) = v;
+          } else {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)(EPI == EPI_BIAS_GELU_BF16 ? gelu_erf_fast(v[e]) : v[e]);
+            bf16* dst;
+            if constexpr (EPI == EPI_QKV) {  // Q (n < d) or K (d <= n < 2d), both bf16 [m][d]
+              dst = n < d ? reinterpret_cast<bf16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * d + n
+                          : reinterpret_cast<bf16*>(p.C2) + (long)bz * p.c2_batch_stride + (long)m * d + (n - d);
+            } else if constexpr (EPI == EPI_CROSS_KV) {  // V rows [n_layer*d, 2*n_layer*d): [l][slot][head][t_pad][64]
+              const int nv = n - p.n_layer * d;
+              const int l = nv / d, c = nv - l * d;
+              const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + (c >> 6);
+              dst = reinterpret_cast<bf16*>(p.C2) + (slot * p.t_pad + m) * 64 + (c & 63);
+            } else {
+              dst = reinterpret_cast<bf16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n;
+            }
+            *reinterpret_cast<bf16x4*>(dst) = o;
           }
-        } else {  // EPI_CROSS_KV K rows [0, n_layer*d): blocked [l][slot][head][m/64][dd/8][m%64][8]; 4 consecutive dd per quad
+        }
+      }
+    } else {  // EPI_QKV swapped: rows = n (V^T [head][64][t_pad]: row c = n - 2d), columns = m (4 consecutive frames per lane)
+      static_assert(EPI == EPI_QKV, "swapped row epilogue: V^T only");
+      const int m = mb + cc;
+      if (m < p.M) {  // M % 4 == 0 (checked by launch_gemm)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int n = nb + j * 32 + 8 * q + 4 * h;
-            const int l = n / d, c = n - l * d;
-            const int head = c >> 6, dd = c & 63;
-            bf16x4 pk;
+        for (int t = 0; t < 16; ++t) {
+          const int row = 4 * t + rr, n = nb + row;
+          const float bias = p.bias ? p.bias[n] : 0.f;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc);
+          bf16x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = (bf16)(acc[i][j][4 * q + e] + (p.bias ? p.bias[n + e] : 0.f));
-            const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + head;
-            bf16* dst = reinterpret_cast<bf16*>(p.C) + slot * p.t_pad * 64 + (long)(m >> 6) * 4096 + (dd >> 3) * 512 + (m & 63) * 8 + (dd & 7);
-            *reinterpret_cast<bf16x4*>(dst) = pk;
-          }
+          for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] + bias);
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C3) + (long)bz * p.c3_batch_stride + (long)(n - 2 * d) * p.t_pad + m) = o;
         }
       }
     }
@@ -201,7 +242,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   }
   compute((nk - 1) & 1);
 
-  gemm_epilogue<EPI, SWAPPED>(p, acc, m0 + wm * 64, n0 + wn * 64, bz, r, h);
+  __syncthreads();  // every wave is done with the staging buffers: they now hold the parked sub-tiles
+  gemm_epilogue<EPI, SWAPPED>(p, acc, reinterpret_cast<float*>(smem) + wave * 4096, m0 + wm * 64, n0 + wn * 64, bz, lane);
 }
 
 // ---------------------------------------------------------------------------- 256 x 128 tile, 3-stage LDS-DMA ring
@@ -303,7 +345,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
     if (kt + 2 < nk) stage((kt + 2) % 3, kt + 2);  // refills the buffer k-tile kt-1 was read from
     compute(kt % 3);
   }
-  gemm_epilogue<EPI, SWAPPED>(p, acc, m0 + wm * 64, n0 + wn * 64, bz, r, h);
+  __syncthreads();  // every wave is done with the ring: it now holds the parked sub-tiles (8 x 16 KB)
+  gemm_epilogue<EPI, SWAPPED>(p, acc, reinterpret_cast<float*>(smem) + wave * 4096, m0 + wm * 64, n0 + wn * 64, bz, lane);
 }
 
 template <int EPI, bool SW>
@@ -326,7 +369,8 @@ void launch_gemm(const GemmParams& p, hipStream_t s) {
     case EPI_BIAS_GELU_BF16: launch_one<EPI_BIAS_GELU_BF16, false>(p, 0, p.N, s); break;
     case EPI_GELU_POS_F32: launch_one<EPI_GELU_POS_F32, false>(p, 0, p.N, s); break;
     case EPI_RESID_F32: launch_one<EPI_RESID_F32, false>(p, 0, p.N, s); break;
-    case EPI_QKV:  // Q,K rows normal; V rows with swapped operands (V^T output)
+    case EPI_QKV:  // Q,K rows normal; V rows with swapped operands (V^T output, four consecutive frames per lane)
+      if (p.M % 4 != 0) { fprintf(stderr, "[ax_whisper] launch_gemm: EPI_QKV needs M %% 4 == 0 (M=%d)\n", p.M); abort(); }
       launch_one<EPI_QKV, false>(p, 0, 2 * p.d_model, s);
       launch_one<EPI_QKV, true>(p, 2 * p.d_model, 3 * p.d_model, s);
       break;
