@@ -38,8 +38,10 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 // the residual add issued before the first store. The one layout that is contiguous along neither axis of the
 // accumulator tile (the decoder's blocked cross K) keeps the register path: its lanes already store 8 contiguous
 // bytes each, 512 contiguous bytes per wave instruction.
-template <int EPI, bool SWAPPED>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][2], float* lw, int mb, int nb, int bz, int lane) {
+// NI = 32-row accumulator tiles per wave along M, I0 = the first of the two that this call writes.
+template <int EPI, bool SWAPPED, int NI = 2, int I0 = 0>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&accw)[NI][2], float* lw, int mb, int nb, int bz, int lane) {
+  f32x16 (&acc)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&accw[I0]);
   const int r = lane & 31, h = lane >> 5;
   const int d = p.d_model;
   if constexpr (EPI == EPI_CROSS_KV && SWAPPED) {  // K rows [0, n_layer*d): blocked [l][slot][head][m/64][dd/8][m%64][8]
@@ -349,13 +351,129 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
   gemm_epilogue<EPI, SWAPPED>(p, acc, reinterpret_cast<float*>(smem) + wave * 4096, m0 + wm * 64, n0 + wn * 64, bz, lane);
 }
 
+// ---------------------------------------------------------------------------- 256 x 256 tile, 128 x 64 per wave
+// For launches with enough 256-square tiles to fill the chip. 8 waves as 2 (M) x 4 (N), each a 128x64 sub-tile =
+// 4x2 accumulator tiles (128 VGPRs): per k-step a wave reads 6 fragments for 8 MFMAs (the 64x64 sub-tile: 4 for 4),
+// and a k-tile costs 64 KB of staging for 4.2 MFLOP x 4 = 128 FLOP per staged byte (256x128: 85) — the k-loop of
+// these kernels is bound by how many staged bytes can be in flight, not by the matrix pipe. Two 64 KB stages: k-tile
+// t+1 streams in (LDS-DMA) while k-tile t is multiplied. Same swizzled LDS image and epilogues as above.
+constexpr int BM3 = 256, BN3 = 256;
+constexpr int A3_BYTES = BM3 * BK * 2;      // 32 KB
+constexpr int STAGE3_BYTES = 2 * A3_BYTES;  // A | W
+
+template <int EPI, bool SWAPPED>
+__global__ __launch_bounds__(512) void gemm256sq_bf16_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 32 KB | W 32 KB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 31, h = lane >> 5;
+  int n0, m0, bz;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+    const int nt = p.n_tiles, mt = (p.M + BM3 - 1) / BM3;
+    n0 = p.n_begin + (wg % nt) * BN3;
+    const int rest = wg / nt;
+    m0 = (rest % mt) * BM3;
+    bz = rest / mt;
+  }
+  const bf16* A = p.A + (long)bz * p.a_batch_stride;
+  const bf16* W = p.W;
+
+  const int ld_row = tid >> 3, ld_c = tid & 7;  // lane l of wave w: tile row 8w + l/8 (+64 i), chunk position l%8
+  const bf16* a_src[4];
+  const bf16* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = ld_row + 64 * i;
+    const int gc = (ld_c ^ ((row >> 1) & 7)) * 8;
+    a_src[i] = A + (long)min(m0 + row, p.M - 1) * p.lda + gc;
+    w_src[i] = W + (long)(n0 + row) * p.K + gc;
+  }
+  auto stage = [&](int buf, int kt) {  // 8 LDS-DMA pieces (1 KiB each) per wave
+    char* base = smem + buf * STAGE3_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + kt * BK), (lds_ptr_t)(base + (64 * i + 8 * wave) * (BK * 2)), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + kt * BK), (lds_ptr_t)(base + A3_BYTES + (64 * i + 8 * wave) * (BK * 2)), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto compute = [&](int buf) {
+    const char* Ab = smem + buf * STAGE3_BYTES;
+    const char* Wb = Ab + A3_BYTES;
+    bf16x8 af[2][4], wf[2][2];
+    auto frags = [&](int s, int set) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[set][j] = *reinterpret_cast<const bf16x8*>(Wb + swz(wn * 64 + j * 32 + r, 2 * s + h));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[set][i] = *reinterpret_cast<const bf16x8*>(Ab + swz(wm * 128 + i * 32 + r, 2 * s + h));
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < 3) frags(s + 1, (s + 1) & 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = SWAPPED ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], wf[s & 1][j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // k-tile kt is in LDS (every wave's pieces); every wave is done reading k-tile kt-1
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    compute(kt & 1);
+  }
+#ifdef AXW_GEMM_NO_EPILOGUE  // microbenchmark: the k-loop alone (accumulators kept alive)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+  return;
+#endif
+  __syncthreads();  // the staging buffers now hold the parked sub-tiles (8 x 16 KB), one 64-row half at a time
+  float* lw = reinterpret_cast<float*>(smem) + wave * 4096;
+  gemm_epilogue<EPI, SWAPPED, 4, 0>(p, acc, lw, m0 + wm * 128, n0 + wn * 64, bz, lane);
+  gemm_epilogue<EPI, SWAPPED, 4, 2>(p, acc, lw, m0 + wm * 128 + 64, n0 + wn * 64, bz, lane);
+}
+
+int gemm_force_tile = 0;  // 0: by tile count; 1: 128x128, 2: 256x128, 3: 256x256 (microbenchmarks)
+
 template <int EPI, bool SW>
 static void launch_one(GemmParams p, int n_begin, int n_end, hipStream_t s) {
   if (n_end <= n_begin) return;
   p.n_begin = n_begin;
+  const int mt256 = (p.M + BM2 - 1) / BM2;
+  if ((n_end - n_begin) % BN3 == 0) {
+    const int tiles_sq = (n_end - n_begin) / BN3 * mt256 * p.batch;
+    // one workgroup per CU: a launch runs in ceil(tiles / 256) rounds; the square tile is ~1.15x faster per flop
+    auto fill = [](int tiles) { return (double)tiles / (double)((tiles + 255) / 256 * 256); };
+    const bool sq_pays = tiles_sq >= 256 && 1.15 * fill(tiles_sq) >= fill(2 * tiles_sq);
+    if (gemm_force_tile == 3 || (gemm_force_tile == 0 && sq_pays)) {
+      p.n_tiles = (n_end - n_begin) / BN3;
+      hipLaunchKernelGGL((gemm256sq_bf16_kernel<EPI, SW>), dim3(tiles_sq), dim3(512), 2 * STAGE3_BYTES, s, p);
+      return;
+    }
+  }
   p.n_tiles = (n_end - n_begin) / BN;
-  const int tiles256 = p.n_tiles * ((p.M + BM2 - 1) / BM2) * p.batch;
-  if (tiles256 >= 256 && p.K >= 2 * BK) {  // enough 256-row tiles for every CU: deep-ring kernel
+  const int tiles256 = p.n_tiles * mt256 * p.batch;
+  if (gemm_force_tile == 2 || (gemm_force_tile == 0 && tiles256 >= 256 && p.K >= 2 * BK)) {  // enough 256-row tiles for every CU: deep-ring kernel
     hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SW>), dim3(tiles256), dim3(512), 3 * STAGE2_BYTES, s, p);
     return;
   }
