@@ -190,6 +190,25 @@ struct DecGemmParams {
   int ksplit; int part_batch;              // GEPI_PARTIAL: K slices (grid.y) and the clip stride of the partial buffer
 };
 void launch_decode_gemm(const DecGemmParams& p, hipStream_t s);
+
+// Clip-block form of the batched linear layer: one workgroup = 16 clips x 16*rt weight rows over the whole K, so the
+// activations of a workgroup are 16 rows instead of 64, LayerNorm of the residual stream can be the prologue (no
+// separate preparation launch, no activation round trip through memory) and the residual add can be the epilogue
+// (every output element has exactly one owner: no split-K partials to fold).
+struct DecCGemmParams {
+  const bf16* W;                           // fragment-major packed weights
+  const float* bias; int N, K, batch;
+  const float* x; const float* ln_w; const float* ln_b;   // ln_w != nullptr: input = LayerNorm(x [batch][K] fp32)
+  const bf16* a_hi; const bf16* a_lo;      // else: fragment-major bf16 pair
+  int nbs;                                 // allocated clip blocks (stride of the pair layouts)
+  int epilogue;                            // GEPI_STORE / GEPI_GELU / GEPI_RESID / GEPI_QKV_CACHE
+  int rt;                                  // 1 or 2
+  float* out;                              // fp32 [batch][N] (STORE, RESID: out += y; q of QKV_CACHE)
+  bf16* out_hi; bf16* out_lo;              // GEPI_GELU: bf16 pair
+  bf16* k_cache; bf16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;
+  const DecState* state;
+};
+void launch_decode_cgemm(const DecCGemmParams& p, hipStream_t s);
 int decode_gemm_grid(int N, int rt);
 void launch_act_prep(float* x, const float* g, const float* be, bf16* hi, bf16* lo, int batch, int K, bool do_ln, int nbs,
                      const float* part, int n_part, int part_batch, const float* part_bias, hipStream_t s);

@@ -141,6 +141,13 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
   const bf16* alo = p.a_lo + ks_base * ((long)p.nbs * 512) + lane * 8;
   const long a_step = (long)p.nbs * 512;  // elements between consecutive k-steps of the activations
 
+  // The bias of this thread's outputs is requested first: every output of a thread has the same weight row
+  // (512 % (16 * RT) == 0), and a load issued in the epilogue, behind the reduction barrier, would add one more
+  // memory round trip to a launch that is a single dependent chain.
+  static_assert(512 % (16 * RT) == 0, "row of a thread's outputs");
+  float bias_t = 0.f;
+  if (p.bias && p.epilogue != GEPI_PARTIAL && n0 + tid % (16 * RT) < p.N) bias_t = p.bias[n0 + tid % (16 * RT)];
+
   f32x4 acc[RT][NB];
 #pragma unroll
   for (int t = 0; t < RT; ++t)
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
       p.out[((long)blockIdx.y * p.part_batch + b) * p.N + n] = y;
       continue;
     }
-    y += p.bias ? p.bias[n] : 0.f;
+    y += bias_t;
     switch (p.epilogue) {
       case GEPI_STORE: p.out[(long)b * p.N + n] = y; break;
       case GEPI_GELU: store_pair_frag(gelu_erf(y), p.out_hi, p.out_lo, b, n, p.nbs); break;
@@ -256,6 +263,195 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
       p.amax_idx[(long)tid * p.amax_stride + blockIdx.x] = best_i;
     }
   }
+}
+
+// ---------------------------------------------------------------------------- clip-block GEMM (DecCGemmParams)
+// grid = (weight-row blocks of 16*RT, clip blocks of 16); 8 waves split K (k-steps w, w+8, ...), reduce through LDS;
+// at most one output per thread (RT <= 2), so the bias and the residual value are requested before anything else.
+// CH > 0: LayerNorm prologue, CH = k-steps per wave held in registers (K = 256*CH at most); CH == 0: bf16-pair input.
+template <int RT, int CH>
+__global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
+  __shared__ __attribute__((aligned(16))) float red[8 * RT * 256];  // [wave][t][clip][row]
+  __shared__ float stat[2][8][16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * (16 * RT), cb = blockIdx.y;
+  const int KS = p.K / 32;
+  const int nb0 = blockIdx.x * RT, n_rb = (p.N + 15) / 16;
+
+  // this thread's output: weight row n0 + tid % (16 RT), clip cb*16 + tid / (16 RT)
+  const int o_n = n0 + tid % (16 * RT), o_b = cb * 16 + tid / (16 * RT);
+  const bool has_out = tid < RT * 256 && o_n < p.N && o_b < p.batch;
+  float bias_t = 0.f, old_t = 0.f;
+  if (has_out && p.bias) bias_t = p.bias[o_n];
+  if (has_out && p.epilogue == GEPI_RESID) old_t = p.out[(long)o_b * p.N + o_n];
+  const int step = p.epilogue == GEPI_QKV_CACHE ? p.state->step : 0;
+
+  const bf16* wrow[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) wrow[t] = p.W + (long)min(nb0 + t, n_rb - 1) * KS * 512 + lane * 8;
+
+  f32x4 acc[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+
+  if constexpr (CH > 0) {
+    // weights of this wave's k-steps: all requested before the LayerNorm arithmetic
+    bf16x8 w[CH][RT];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ks = min(wave + 8 * c, KS - 1);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) w[c][t] = *reinterpret_cast<const bf16x8*>(wrow[t] + (long)ks * 512);
+    }
+    // lane (r, q) holds x[clip r][k = ks*32 + 8q .. +8] of every k-step of this wave: exactly its MFMA B fragment
+    const float* xr = p.x + (long)min(cb * 16 + r, p.batch - 1) * p.K;
+    f32x4 v[CH][2], gg[CH][2], bb[CH][2];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int k0 = min(wave + 8 * c, KS - 1) * 32 + q * 8;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        v[c][u] = *reinterpret_cast<const f32x4*>(xr + k0 + 4 * u);
+        gg[c][u] = *reinterpret_cast<const f32x4*>(p.ln_w + k0 + 4 * u);
+        bb[c][u] = *reinterpret_cast<const f32x4*>(p.ln_b + k0 + 4 * u);
+      }
+    }
+    // two-pass statistics per clip: lanes (r, 0..3) of 8 waves hold one row between them
+    float s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (wave + 8 * c < KS) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) s1 += (v[c][u][0] + v[c][u][1]) + (v[c][u][2] + v[c][u][3]);
+      }
+    s1 += __shfl_xor(s1, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    if (q == 0) stat[0][wave][r] = s1;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < 8; ++w2) mean += stat[0][w2][r];
+    mean /= (float)p.K;
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (wave + 8 * c < KS) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float t2 = v[c][u][e] - mean; s2 += t2 * t2; }
+      }
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (q == 0) stat[1][wave][r] = s2;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < 8; ++w2) var += stat[1][w2][r];
+    const float rstd = rsqrtf(var / (float)p.K + 1e-5f);
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (wave + 8 * c < KS) {
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float y = (v[c][u][e] - mean) * rstd * gg[c][u][e] + bb[c][u][e];
+            bf16 hh, ll;
+            split_bf16(y, hh, ll);
+            hi[4 * u + e] = hh; lo[4 * u + e] = ll;
+          }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][t], hi, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][t], lo, acc[t], 0, 0, 0);
+        }
+      }
+  } else {
+    const bf16* ahi = p.a_hi + (long)cb * 512 + lane * 8;
+    const bf16* alo = p.a_lo + (long)cb * 512 + lane * 8;
+    const long a_step = (long)p.nbs * 512;
+    struct Frag { bf16x8 w[RT], h, l; };
+    auto load = [&](Frag& f, int ks) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t) f.w[t] = *reinterpret_cast<const bf16x8*>(wrow[t] + (long)ks * 512);
+      f.h = *reinterpret_cast<const bf16x8*>(ahi + ks * a_step);
+      f.l = *reinterpret_cast<const bf16x8*>(alo + ks * a_step);
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t], f.h, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t], f.l, acc[t], 0, 0, 0);
+      }
+    };
+    Frag f0, f1, f2, f3;  // four k-steps in flight per wave
+    if (wave < KS) load(f0, wave);
+    if (wave + 8 < KS) load(f1, wave + 8);
+    if (wave + 16 < KS) load(f2, wave + 16);
+    if (wave + 24 < KS) load(f3, wave + 24);
+    for (int ks = wave; ks < KS; ks += 32) {
+      mma(f0);
+      if (ks + 32 < KS) load(f0, ks + 32);
+      if (ks + 8 < KS) { mma(f1); if (ks + 40 < KS) load(f1, ks + 40); }
+      if (ks + 16 < KS) { mma(f2); if (ks + 48 < KS) load(f2, ks + 48); }
+      if (ks + 24 < KS) { mma(f3); if (ks + 56 < KS) load(f3, ks + 56); }
+    }
+  }
+
+  // split-K reduction across the 8 waves: red[wave][t][clip r][row 4q + e]
+#pragma unroll
+  for (int t = 0; t < RT; ++t) *reinterpret_cast<f32x4*>(red + ((wave * RT + t) * 16 + r) * 16 + 4 * q) = acc[t];
+  __syncthreads();
+  if (!has_out) return;
+  const int nl = tid % (16 * RT), bl = tid / (16 * RT);
+  const int t = nl >> 4, nn = nl & 15;
+  float y = bias_t;
+#pragma unroll
+  for (int w2 = 0; w2 < 8; ++w2) y += red[((w2 * RT + t) * 16 + bl) * 16 + nn];
+  const int n = o_n, b = o_b;
+  switch (p.epilogue) {
+    case GEPI_STORE: p.out[(long)b * p.N + n] = y; break;
+    case GEPI_RESID: p.out[(long)b * p.N + n] = old_t + y; break;
+    case GEPI_GELU: store_pair_frag(gelu_erf(y), p.out_hi, p.out_lo, b, n, p.nbs); break;
+    case GEPI_QKV_CACHE: {
+      const int d = p.d_model;
+      if (n < d) {
+        p.out[(long)b * d + n] = y;
+      } else {
+        const int cc = (n < 2 * d) ? n - d : n - 2 * d;
+        const int head = cc >> 6, dd = cc & 63;
+        const long base = (long)b * p.kv_batch_stride + (long)head * p.n_ctx_pad * 64;
+        if (n < 2 * d) p.k_cache[base + (long)(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (bf16)y;
+        else p.v_cache[base + (long)step * 64 + dd] = (bf16)y;
+      }
+      break;
+    }
+  }
+}
+
+template <int RT>
+static void launch_cg(const DecCGemmParams& p, hipStream_t s) {
+  const dim3 grid((p.N + 16 * RT - 1) / (16 * RT), (p.batch + 15) / 16);
+  const int ch = p.ln_w ? (p.K / 32 + 7) / 8 : 0;
+  switch (ch) {
+    case 0: hipLaunchKernelGGL((decode_cgemm_kernel<RT, 0>), grid, dim3(512), 0, s, p); break;
+    case 1: case 2: hipLaunchKernelGGL((decode_cgemm_kernel<RT, 2>), grid, dim3(512), 0, s, p); break;
+    case 3: hipLaunchKernelGGL((decode_cgemm_kernel<RT, 3>), grid, dim3(512), 0, s, p); break;
+    case 4: hipLaunchKernelGGL((decode_cgemm_kernel<RT, 4>), grid, dim3(512), 0, s, p); break;
+    case 5: hipLaunchKernelGGL((decode_cgemm_kernel<RT, 5>), grid, dim3(512), 0, s, p); break;
+    default: fprintf(stderr, "[ax_whisper] launch_decode_cgemm: LayerNorm prologue supports K <= 1280 (K=%d)\n", p.K); abort();
+  }
+}
+void launch_decode_cgemm(const DecCGemmParams& p, hipStream_t s) {
+  if (p.K % 128 != 0) { fprintf(stderr, "[ax_whisper] launch_decode_cgemm: unsupported K=%d\n", p.K); abort(); }
+  if (p.rt == 2) launch_cg<2>(p, s);
+  else launch_cg<1>(p, s);
 }
 
 int decode_gemm_grid(int N, int rt) { return (N + 16 * rt - 1) / (16 * rt); }

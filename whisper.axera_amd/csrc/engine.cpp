@@ -681,12 +681,53 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     return p;
   };
 
+  // Clip-block GEMMs (decode_cgemm_kernel): LayerNorm is the prologue of its consumer and the residual add the
+  // epilogue of its producer, so a layer is 8 launches instead of 11 (AX_WHISPER_BATCHED_LN=0: the older sequence
+  // with a separate LayerNorm/bf16-pair preparation launch and split-K partials).
+  static const bool fused_ln = [] { const char* e = getenv("AX_WHISPER_BATCHED_LN"); return !(e && e[0] == '0'); }();
+  const bool ln_fits = d % 128 == 0 && d <= 1280;
+  auto cgemm = [&](const bf16* W, const float* bias, int N, int K, int epi, int rt) {
+    DecCGemmParams c{};
+    c.W = W; c.bias = bias; c.N = N; c.K = K; c.batch = batch; c.nbs = nbs_; c.epilogue = epi; c.rt = rt;
+    c.d_model = d; c.n_ctx_pad = Tc; c.state = d_state_;
+    return c;
+  };
+  auto cgo = [&](const DecCGemmParams& c) { if (step_mask_ & 1) launch_decode_cgemm(c, s); };
+  const int n_blk = (batch + 15) / 16;
+  // two row tiles per workgroup where one would make more workgroups than can be resident at once
+  auto rt_for = [&](int N) { return (N / 16) * n_blk > 512 ? 2 : 1; };
+
   for (int l = 0; l < L; ++l) {
     const DecLayerW& w = dec_[l];
     bf16* sk = d_self_k_ + (size_t)l * cap_ * self_stride;
     bf16* sv = d_self_v_ + (size_t)l * cap_ * self_stride;
     const bf16* ck = d_cross_k_ + (size_t)l * cap_ * cross_stride;
     const bf16* cv = d_cross_v_ + (size_t)l * cap_ * cross_stride;
+    if (fused_ln && ln_fits) {
+      const DecLayerWP& wq = dec_packed_[l];
+      DecCGemmParams c = cgemm(wq.w_qkv, w.b_qkv, 3 * d, d, GEPI_QKV_CACHE, rt_for(3 * d));
+      c.x = d_xdec_; c.ln_w = w.attn_ln_w; c.ln_b = w.attn_ln_b;
+      c.out = d_qdec_; c.k_cache = sk; c.v_cache = sv; c.kv_batch_stride = self_stride;
+      cgo(c);
+      attn(sk, sv, self_stride, -1, Tc / 64);
+      c = cgemm(wq.w_o, w.b_o, d, d, GEPI_RESID, 1);
+      c.a_hi = d_att_[0]; c.a_lo = d_att_[1]; c.out = d_xdec_;
+      cgo(c);
+      c = cgemm(wq.w_cq, w.b_cq, d, d, GEPI_STORE, 1);
+      c.x = d_xdec_; c.ln_w = w.cross_ln_w; c.ln_b = w.cross_ln_b; c.out = d_qdec_;
+      cgo(c);
+      attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64);
+      c = cgemm(wq.w_co, w.b_co, d, d, GEPI_RESID, 1);
+      c.a_hi = d_att_[0]; c.a_lo = d_att_[1]; c.out = d_xdec_;
+      cgo(c);
+      c = cgemm(wq.w_fc1, w.b_fc1, 4 * d, d, GEPI_GELU, rt_for(4 * d));
+      c.x = d_xdec_; c.ln_w = w.mlp_ln_w; c.ln_b = w.mlp_ln_b; c.out_hi = d_hidp_[0]; c.out_lo = d_hidp_[1];
+      cgo(c);
+      c = cgemm(wq.w_fc2, w.b_fc2, d, 4 * d, GEPI_RESID, 1);
+      c.a_hi = d_hidp_[0]; c.a_lo = d_hidp_[1]; c.out = d_xdec_;
+      cgo(c);
+      continue;
+    }
     ln(w.attn_ln_w, w.attn_ln_b);
     const DecLayerWP& wp = dec_packed_[l];
     DecGemmParams p = base(wp.w_qkv, w.b_qkv, 3 * d, d, d_act_[0], d_act_[1], GEPI_QKV_CACHE);
