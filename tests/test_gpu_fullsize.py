@@ -67,3 +67,55 @@ def test_small_batched_clips(engine, small_case, oracle_mod):
     logits, _ = engine.decode_forced(6, forced)
     for b, (ids, lg) in refs.items():
         print("small B=6 clip", b, "logits err", _check(got[b], ids, lg, logits[b]))
+
+
+def test_small_encoder_tile_shapes_agree(built_lib, small_case):
+    """22 clips in one encoder pass run the 256x256-tile GEMM (enough tiles to fill the chip), one clip the 128x128
+    tile: cross K/V of the same clip must agree within a bf16 ulp of its magnitude (the two kernels differ only in
+    fp32 summation order and in where a value is narrowed to bf16)."""
+    from make_model_goldens_inputs import demo_mel, synth_mel
+
+    B = 22
+    mels = [demo_mel(80), synth_mel(7, 80, 3000), synth_mel(8, 80, 1700)]
+    e = built_lib.Whisper("small", small_case.root, "zh", device=0, max_batch=B)
+    try:
+        e.encode_mel(np.stack([mels[b % 3] for b in range(B)]))
+        batched = {b: e.get_cross_kv(b) for b in (0, 1, 2, 20, 21)}
+        for b, (kb, vb) in batched.items():
+            e.encode_mel(mels[b % 3])
+            k1, v1 = e.get_cross_kv(0)
+            dk, dv = np.abs(kb - k1), np.abs(vb - v1)
+            print(f"slot {b}: cross K/V batch-22 vs batch-1 max diff {dk.max():.3e} {dv.max():.3e}, mean {dk.mean():.2e}")
+            tol = 2.0 ** -7 * np.maximum(np.abs(k1), 1.0)  # two bf16 ulps
+            assert (dk <= tol).all() and (dv <= 2.0 ** -7 * np.maximum(np.abs(v1), 1.0)).all()
+            assert dk.mean() < 2e-3 and dv.mean() < 2e-3
+    finally:
+        e.close()
+
+
+def test_small_batched_decode_sequences_agree(built_lib, small_case, monkeypatch):
+    """The clip-block decode sequence (LayerNorm as GEMM prologue, residual add as epilogue) and the older one
+    (separate LayerNorm/bf16-pair launch, split-K partials) give the same teacher-forced logits and argmax ids."""
+    from make_model_goldens_inputs import demo_mel, synth_mel
+
+    B, n = 18, 8
+    mels = np.stack([demo_mel(80) if b % 2 == 0 else synth_mel(30 + b, 80, 3000 if b % 3 else 1500) for b in range(B)])
+    forced = np.tile(np.arange(100, 100 + n, dtype=np.int32), (B, 1))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AX_WHISPER_BATCHED_LN", mode)
+        e = built_lib.Whisper("small", small_case.root, "zh", device=0, max_batch=B)
+        try:
+            assert e.L.AX_WHISPER_GetConfigInt(e.h, b"batched_ln") == int(mode)
+            e.encode_mel(mels)
+            out[mode] = e.decode_forced(B, forced)
+        finally:
+            e.close()
+    lg1, am1 = out["1"]
+    lg0, am0 = out["0"]
+    err = np.abs(lg1 - lg0).max()
+    print("clip-block vs split-K sequence: logits diff", err)
+    assert err < 2e-3
+    srt = np.sort(lg0, axis=2)
+    margin = srt[:, :, -1] - srt[:, :, -2]
+    assert ((am1 == am0) | (margin < 4e-3)).all()

@@ -74,6 +74,14 @@ Engine::Engine(const std::string& model_type, const std::string& model_path, con
     }
   }
   cfg_.ints["persistent_decode"] = persistent_ok_ ? 1 : 0;  // visible through AX_WHISPER_GetConfigInt
+  {  // batched decode as clip-block GEMMs with LayerNorm prologue / residual epilogue (enqueue_decode_step_batched)
+    const char* e = getenv("AX_WHISPER_BATCHED_LN");
+    const int d = cfg_.n_text_state;
+    // measured on MI355X: faster for d_model 768 at 16-64 clips (+2..8 %); slower for 1280 (-3 %: without split-K the
+    // 5120-deep mlp.2 is 20 dependent k-steps per wave on 80-320 workgroups), which keeps the split-K sequence
+    batched_ln_ = !(e && e[0] == '0') && d % 128 == 0 && d <= 1024;
+    cfg_.ints["batched_ln"] = batched_ln_ ? 1 : 0;
+  }
   cfg_.ints["t2s"] = t2s_ ? 1 : 0;
   ensure_capacity(std::max(1, max_batch));
   HIP_CHECK(hipStreamSynchronize(own_stream_));
@@ -684,10 +692,6 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
   // Clip-block GEMMs (decode_cgemm_kernel): LayerNorm is the prologue of its consumer and the residual add the
   // epilogue of its producer, so a layer is 8 launches instead of 11 (AX_WHISPER_BATCHED_LN=0: the older sequence
   // with a separate LayerNorm/bf16-pair preparation launch and split-K partials).
-  static const bool fused_ln = [] { const char* e = getenv("AX_WHISPER_BATCHED_LN"); return !(e && e[0] == '0'); }();
-  // measured on MI355X: faster for d_model 768 at 16-64 clips (+2..8 %); slower for 1280 (-3 %: without split-K the
-  // 5120-deep mlp.2 is 20 dependent k-steps per wave on 80-320 workgroups), which keeps the split-K sequence
-  const bool ln_fits = d % 128 == 0 && d <= 1024;
   auto cgemm = [&](const bf16* W, const float* bias, int N, int K, int epi, int rt) {
     DecCGemmParams c{};
     c.W = W; c.bias = bias; c.N = N; c.K = K; c.batch = batch; c.nbs = nbs_; c.epilogue = epi; c.rt = rt;
@@ -705,7 +709,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     bf16* sv = d_self_v_ + (size_t)l * cap_ * self_stride;
     const bf16* ck = d_cross_k_ + (size_t)l * cap_ * cross_stride;
     const bf16* cv = d_cross_v_ + (size_t)l * cap_ * cross_stride;
-    if (fused_ln && ln_fits) {
+    if (batched_ln_) {
       const DecLayerWP& wq = dec_packed_[l];
       DecCGemmParams c = cgemm(wq.w_qkv, w.b_qkv, 3 * d, d, GEPI_QKV_CACHE, rt_for(3 * d));
       c.x = d_xdec_; c.ln_w = w.attn_ln_w; c.ln_b = w.attn_ln_b;

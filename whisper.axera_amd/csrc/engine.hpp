@@ -129,6 +129,7 @@ class Engine {
   int split_self_ = 2, split_cross_ = 6;
   int step_mask_ = 15;  // bench only: 1 GEMV/GEMM launches, 2 attention launches, 4 advance, 8 act_prep
   // persistent batch-1 decode
+  bool batched_ln_ = false;         // batched decode: clip-block GEMM sequence (AX_WHISPER_BATCHED_LN=0 disables)
   bool persistent_ok_ = false;      // model shape supported and not disabled (AX_WHISPER_DECODE=graph)
   int persist_grid_ = 0;
   u64* d_gran_ = nullptr; size_t gran_bytes_ = 0;
