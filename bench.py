@@ -60,14 +60,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # AXW_BENCH_FORCE_DIST=1: run the RCCL group, the barriers and the result gather even with one rank (a rehearsal of
+    # the N>1 code path on a one-GPU box)
+    use_dist = world > 1 or os.environ.get("AXW_BENCH_FORCE_DIST") == "1"
+    saved_stdout = None
+    if use_dist:
+        # RCCL prints a version banner on stdout when its communicator is created; stdout must carry the ONE JSON
+        # line only, so everything until then goes to stderr (file-descriptor level: the banner comes from C code)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier(device_ids=[local_rank])
 
     # ---- synthetic-weight model directory (no weights exist in the reference or this image)
@@ -92,7 +101,7 @@ def main():
 
     def one_step():
         ids = eng.run_device_tokens(d_pcm.data_ptr(), n_samp, [n_samp] * B, max_new=args.max_new)
-        if world > 1:  # the ONE collective of the path: result gather over RCCL/xGMI
+        if use_dist:  # the ONE collective of the path: result gather over RCCL/xGMI
             dp.gather_ids(ids, B, device=dev)
         return ids
 
@@ -110,7 +119,7 @@ def main():
     torch.cuda.synchronize(dev)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -224,11 +233,15 @@ def main():
                                          f"steps measured ({t_dec_step * 1e3:.1f} ms/step) scaled to {dec_steps:.0f} steps; "
                                          f"CPU oracle (bf16 policy), {threads} OpenMP threads of {os.cpu_count()}",
                                "ids_agree_prefix": f"{agree}/{len(cpu_ids)}"}
-    if rank == 0:
-        print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if saved_stdout is not None:
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -49,7 +49,10 @@ def gather_ids(local_rows: Sequence[Sequence[int]], rows_per_rank: int, device=N
     t = pack_ids(local_rows, rows_per_rank, n_ctx)
     if device is not None:
         t = t.to(device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    import os
+
+    rehearse = os.environ.get("AXW_BENCH_FORCE_DIST") == "1"  # run the collective even with one rank
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not rehearse):
         return unpack_ids(t.cpu())
     parts = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
     dist.all_gather(parts, t, group=group)
