@@ -3,7 +3,9 @@ with B clips (Whisper-small, 30 s synthetic clips resident in HBM). Does the ban
 overlap the latency-bound linear layers of the other?
 
     python profiles/scripts/replicas_b64.py [B] [R]
+    AXW_CU_MASK=contig|stride python ...   # every replica on its own stream restricted to 256/R CUs (hipExtStreamCreateWithCUMask)
 """
+import ctypes
 import os
 import sys
 import threading
@@ -29,9 +31,27 @@ d_pcm = torch.from_numpy(clips).to(dev)
 torch.cuda.synchronize()
 
 
+def masked_stream(r, R, kind, n_cu=256):
+    hip = ctypes.CDLL("libamdhip64.so")
+    bits = [0] * (n_cu // 32)
+    for cu in range(n_cu):
+        mine = (cu * R // n_cu == r) if kind == "contig" else (cu % R == r)
+        if mine:
+            bits[cu // 32] |= 1 << (cu % 32)
+    arr = (ctypes.c_uint32 * len(bits))(*bits)
+    st = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(len(bits)), arr)
+    assert rc == 0, rc
+    return st.value
+
+
 def run(R, iters=2):
     per = B // R
     engs = [wa.Whisper("small", mdir, "zh", device=0, max_batch=per) for _ in range(R)]
+    kind = os.environ.get("AXW_CU_MASK")
+    if kind and R > 1:
+        for r, e in enumerate(engs):
+            e.set_stream(masked_stream(r, R, kind))
     outs = [None] * R
 
     def work(r):

@@ -16,6 +16,7 @@
 // Epilogues mirror decode_gemv.hip: bias, GELU (writes the bf16 pair), residual add, q + KV-cache append,
 // vocabulary argmax partials (first max wins, Whisper.cpp:42-45).
 #include "common.hpp"
+#include <algorithm>
 
 namespace axw {
 
@@ -454,7 +455,125 @@ void launch_decode_cgemm(const DecCGemmParams& p, hipStream_t s) {
   else launch_cg<1>(p, s);
 }
 
-int decode_gemm_grid(int N, int rt) { return (N + 16 * rt - 1) / (16 * rt); }
+// ---------------------------------------------------------------------------- vocabulary projection (rt == 0)
+// The tied-embedding logits of up to 64 clips: 80 MB of weights against 196 KB of activations. One workgroup per CU
+// stays for its share of the 16-row weight blocks: every wave keeps the activation fragments of ITS k-steps (all clip
+// blocks, hi and lo) in registers for the whole launch, so an iteration streams nothing but 16 rows of weights
+// (requested one iteration ahead), and a thread keeps the running argmax of its (clip, row lane) over all iterations
+// (rows ascend, strict >, so the first maximum wins as in Whisper.cpp:42-45). The launch-per-row-block form
+// (decode_gemm_kernel<2, 4>: 1621 workgroups, one resident per CU, each re-reading all activations and paying its own
+// load -> MFMA -> reduce -> epilogue chain) took 60 us per step at 64 clips.
+template <int NB, int CH>
+__global__ __launch_bounds__(512) void decode_logits_kernel(DecGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);  // [2][8 waves][NB][16 clips][16 rows]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int KS = p.K / 32, n_rb = (p.N + 15) / 16, G = gridDim.x;
+
+  bf16x8 ah[CH][NB], al[CH][NB];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const long ks = min(wave + 8 * c, KS - 1);
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      ah[c][cb] = *reinterpret_cast<const bf16x8*>(p.a_hi + (ks * p.nbs + cb) * 512 + lane * 8);
+      al[c][cb] = *reinterpret_cast<const bf16x8*>(p.a_lo + (ks * p.nbs + cb) * 512 + lane * 8);
+    }
+  }
+  auto loadw = [&](bf16x8 (&w)[CH], int rb) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      w[c] = *reinterpret_cast<const bf16x8*>(p.W + ((long)min(rb, n_rb - 1) * KS + min(wave + 8 * c, KS - 1)) * 512 + lane * 8);
+  };
+  bf16x8 w0[CH], w1[CH];
+  loadw(w0, blockIdx.x);
+  if (p.state->step < p.skip_before_step) return;  // SOT steps: logits are discarded (Whisper.cpp:214-217)
+
+  constexpr int NU = (NB * 256 + 511) / 512;  // outputs per thread and iteration
+  float bv[NU];
+  int bi[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) { bv[u] = -INFINITY; bi[u] = 0x7fffffff; }
+
+  auto body = [&](const bf16x8 (&w)[CH], int rb, int it) {
+    f32x4 acc[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[cb][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (wave + 8 * c < KS) {
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c], ah[c][cb], acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c], al[c][cb], acc[cb], 0, 0, 0);
+        }
+      }
+    float* rd = red + (it & 1) * (8 * NB * 256);  // two buffers: a wave may park iteration i+1 while others still sum i
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) *reinterpret_cast<f32x4*>(rd + ((wave * NB + cb) * 16 + r) * 16 + 4 * q) = acc[cb];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int o = tid + 512 * u;
+      if (o < NB * 256) {
+        const int cb = o >> 8, bl = (o >> 4) & 15, nn = o & 15;
+        float y = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < 8; ++w2) y += rd[((w2 * NB + cb) * 16 + bl) * 16 + nn];
+        const int n = rb * 16 + nn, b = cb * 16 + bl;
+        if (n < p.N && b < p.batch) {
+          if (p.logits_dump) p.logits_dump[(long)b * p.logits_dump_stride + n] = y;
+          if (y > bv[u]) { bv[u] = y; bi[u] = n; }
+        }
+      }
+    }
+  };
+  int it = 0;
+  for (int rb = blockIdx.x; rb < n_rb; rb += 2 * G) {
+    if (rb + G < n_rb) loadw(w1, rb + G);
+    body(w0, rb, it++);
+    if (rb + G >= n_rb) break;
+    if (rb + 2 * G < n_rb) loadw(w0, rb + 2 * G);
+    body(w1, rb + G, it++);
+  }
+  // the 16 lanes that share a clip hold its candidates of different row lanes: lowest index wins ties
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv[u], o, 64);
+      const int oi = __shfl_xor(bi[u], o, 64);
+      if (ov > bv[u] || (ov == bv[u] && oi < bi[u])) { bv[u] = ov; bi[u] = oi; }
+    }
+    const int o = tid + 512 * u, b = o >> 4;
+    if (o < NB * 256 && (o & 15) == 0 && b < p.batch) {
+      p.amax_val[(long)b * p.amax_stride + blockIdx.x] = bv[u];
+      p.amax_idx[(long)b * p.amax_stride + blockIdx.x] = bi[u];
+    }
+  }
+}
+
+template <int CH>
+static void launch_logits(const DecGemmParams& p, hipStream_t s) {
+  const int nb = (p.batch + 15) / 16;
+  const dim3 grid(decode_gemm_grid(p.N, 0));
+  const size_t lds = (size_t)2 * 8 * nb * 256 * 4;
+  switch (nb) {
+    case 1: hipLaunchKernelGGL((decode_logits_kernel<1, CH>), grid, dim3(512), lds, s, p); break;
+    case 2: hipLaunchKernelGGL((decode_logits_kernel<2, CH>), grid, dim3(512), lds, s, p); break;
+    case 3: hipLaunchKernelGGL((decode_logits_kernel<3, CH>), grid, dim3(512), lds, s, p); break;
+    default: hipLaunchKernelGGL((decode_logits_kernel<4, CH>), grid, dim3(512), lds, s, p); break;
+  }
+}
+// register-resident activations: k-steps per wave x clip blocks x (hi, lo) x 4 VGPRs
+bool decode_logits_resident_ok(int K) { return K % 128 == 0 && (K / 32 + 7) / 8 <= 3; }
+
+int decode_gemm_grid(int N, int rt) {
+  if (rt == 0) return std::min((N + 15) / 16, 256); return (N + 16 * rt - 1) / (16 * rt); }
 
 template <int RT>
 static void launch_nb(const DecGemmParams& p, hipStream_t s) {
@@ -474,6 +593,14 @@ static void launch_nb(const DecGemmParams& p, hipStream_t s) {
 void launch_decode_gemm(const DecGemmParams& p, hipStream_t s) {
   if (p.K % 128 != 0) { fprintf(stderr, "[ax_whisper] launch_decode_gemm: unsupported K=%d\n", p.K); abort(); }
   const int rt = p.rt;
+  if (rt == 0) {  // vocabulary projection with register-resident activations
+    if (p.epilogue != GEPI_LOGITS || !decode_logits_resident_ok(p.K) || p.batch > 64) { fprintf(stderr, "[ax_whisper] launch_decode_gemm: rt 0 is the vocabulary projection (K <= 768)\n"); abort(); }
+    const int ch = (p.K / 32 + 7) / 8;
+    if (ch <= 1) launch_logits<1>(p, s);
+    else if (ch == 2) launch_logits<2>(p, s);
+    else launch_logits<3>(p, s);
+    return;
+  }
   if (rt == 4) launch_nb<4>(p, s);
   else if (rt == 2) launch_nb<2>(p, s);
   else launch_nb<1>(p, s);

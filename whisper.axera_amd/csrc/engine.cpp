@@ -755,7 +755,9 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
   }
   ln(dec_ln_w_, dec_ln_b_);
   DecGemmParams p = base(tok_emb_packed_, nullptr, cfg_.n_vocab, d, d_act_[0], d_act_[1], GEPI_LOGITS);
-  p.rt = kLogitsRT;
+  static const bool resident_off = [] { const char* e = getenv("AX_WHISPER_LOGITS_RT"); return e != nullptr; }();
+  const int vocab_rt = (!resident_off && decode_logits_resident_ok(d)) ? 0 : kLogitsRT;
+  p.rt = vocab_rt;
   p.amax_val = d_amax_val_; p.amax_idx = d_amax_idx_; p.amax_stride = n_amax_part_;
   p.skip_before_step = 3; p.logits_dump = d_logits; p.logits_dump_stride = logits_stride;
   gemm(p, [&](DecGemmParams& q, int b0) {
@@ -763,7 +765,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     if (q.logits_dump) q.logits_dump += (long)b0 * logits_stride;
   });
   AdvanceParams a{};
-  a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = decode_gemm_grid(cfg_.n_vocab, kLogitsRT); a.amax_stride = n_amax_part_;
+  a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = decode_gemm_grid(cfg_.n_vocab, vocab_rt); a.amax_stride = n_amax_part_;
   a.state = d_state_; a.tok = d_tok_; a.done = d_done_; a.n_out = d_nout_; a.out_ids = d_out_ids_; a.batch = batch;
   a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.sot = d_sot_;
   a.forced = d_forced; a.n_forced = n_forced; a.argmax_dump = d_argmax;
