@@ -142,7 +142,7 @@ def main():
     ms_attn = eng.bench("decode_attn", B, 224, iters) / iters
     step_gbs = (w_bytes + c_bytes + s_bytes) / (ms_step * 1e-3) / 1e9
     attn_gbs = (c_bytes + s_bytes) / (ms_attn * 1e-3) / 1e9
-    fam = "gemv_kernel" if small_batch else "decode_gemm_kernel"
+    fam = "gemv_kernel" if small_batch else "decode_gemm_kernel"  # PMC family: clip-block GEMMs + vocabulary projection
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     pmc = json.load(open(pmc_path)).get(f"{args.model}_b{B}", {}) if os.path.exists(pmc_path) else {}
 
@@ -175,8 +175,21 @@ def main():
                     "traffic": pmc_traffic("decode_persistent_kernel"), "launch_ms": round(launch_s * 1e3, 3),
                     "bytes_per_launch": int(launch_bytes), "us_per_decode_step": round(launch_s * 1e6 / max(n_steps, 1), 2),
                     "launch_per_phase_path": graph_path}
-    else:
+    elif small_batch:
         roofline = dict({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}, **graph_path)
+    else:
+        # 5+ clips: the step is dominated by decode_attention_kernel (cross + self attention, one workgroup per
+        # (clip, head)), which streams every clip's K/V once per step: algorithmic bytes = B * (55.3 MB cross +
+        # (t+1) * 36.9 KB self) at t = 224 (the mid-utterance step this leg replays), over 2 launches per layer.
+        n_attn = 2 * dims["dec_layers"]
+        roofline = {"kernel": "decode_attention_kernel (self + cross attention of one decoder step, %d launches)" % n_attn,
+                    "bound": "hbm", "achieved": round(attn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(attn_gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("decode_attention_kernel"),
+                    "avg_launch_us": round(ms_attn * 1e3 / n_attn, 3), "bytes_per_launch": int((c_bytes + s_bytes) / n_attn),
+                    "share_of_decode_step": round(ms_attn / ms_step, 3),
+                    "decode_step": graph_path["decode_step"],
+                    "linear_layers": {k: graph_path[k] for k in ("kernel", "achieved", "frac", "traffic", "launches_per_decode_step",
+                                                                "avg_launch_us", "bytes_per_launch")}}
 
     # ---- the other two stages against their own rooflines: encoder = MFMA-bound, front-end = HBM-bound
     enc_flop = {"tiny": 40.48e9, "small": 386.63e9, "turbo": 2313.09e9}.get(args.model)

@@ -15,8 +15,12 @@ from collections import defaultdict
 def family(name):
     if "gemv1_kernel" in name or "gemv_kernel" in name:
         return "gemv_kernel"  # the single-clip register kernel and the LDS kernel are one family (decode linears, <= 4 clips)
+    if "decode_cgemm_kernel" in name or "decode_logits_kernel" in name:
+        return "decode_gemm_kernel"  # batched decode linear layers: clip-block GEMMs + vocabulary projection (5+ clips)
+    if "bf16_kernel" in name and "gemm" in name:
+        return "gemm_bf16_kernel"  # encoder GEMM, all three tile shapes
     for f in ("decode_persistent_kernel", "decode_gemm_kernel", "decode_attention_kernel", "act_prep_kernel", "advance_kernel",
-              "gemm_bf16_kernel", "encoder_attention_kernel", "layernorm_bf16_kernel", "stft_mel_kernel", "mel_normalize_kernel"):
+              "encoder_attention_kernel", "layernorm_bf16_kernel", "stft_mel_kernel", "mel_normalize_kernel"):
         if f in name:
             return f
     return None
