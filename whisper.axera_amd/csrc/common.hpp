@@ -169,6 +169,9 @@ struct DecAttnParams {
   int cap_blocks;             // allocated 64-key blocks per (slot, head): 24 cross, 7 self
   const DecState* state;
   bf16* out_hi; bf16* out_lo; int nbs; // n_split == 1 only: normalised output as a fragment-major bf16 pair instead of partials
+  // fused query projection (batched cross-attention): q = Wq[head rows] . LayerNorm(x[b]) + bq computed by the
+  // (clip, head) workgroup itself while its first K/V block is in flight; wq == nullptr: q is read from `q`
+  const float* x; const float* ln_w; const float* ln_b; const bf16* wq; const float* bq;
 };
 void launch_decode_attention(const DecAttnParams& p, hipStream_t s);
 

@@ -391,17 +391,20 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t], f.l, acc[t], 0, 0, 0);
       }
     };
-    Frag f0, f1, f2, f3;  // four k-steps in flight per wave
-    if (wave < KS) load(f0, wave);
-    if (wave + 8 < KS) load(f1, wave + 8);
-    if (wave + 16 < KS) load(f2, wave + 16);
-    if (wave + 24 < KS) load(f3, wave + 24);
-    for (int ks = wave; ks < KS; ks += 32) {
-      mma(f0);
-      if (ks + 32 < KS) load(f0, ks + 32);
-      if (ks + 8 < KS) { mma(f1); if (ks + 40 < KS) load(f1, ks + 40); }
-      if (ks + 16 < KS) { mma(f2); if (ks + 48 < KS) load(f2, ks + 48); }
-      if (ks + 24 < KS) { mma(f3); if (ks + 56 < KS) load(f3, ks + 56); }
+    // eight k-steps in flight per wave (96 VGPRs at RT = 1): K = 5120 is 20 k-steps per wave, i.e. 3 dependent round
+    // trips instead of 5 with four
+    constexpr int DEPTH = 8;
+    Frag f[DEPTH];
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i)
+      if (wave + 8 * i < KS) load(f[i], wave + 8 * i);
+    for (int ks = wave; ks < KS; ks += 8 * DEPTH) {
+#pragma unroll
+      for (int i = 0; i < DEPTH; ++i)
+        if (ks + 8 * i < KS) {
+          mma(f[i]);
+          if (ks + 8 * (i + DEPTH) < KS) load(f[i], ks + 8 * (i + DEPTH));
+        }
     }
   }
 

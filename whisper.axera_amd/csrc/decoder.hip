@@ -47,6 +47,11 @@ void launch_embed(const bf16* tok_emb, const float* pos, const int* tok, const D
 }
 
 // ------------------------------------------------------------------------------- decode attention
+// FUSE_Q: the workgroup computes its own 64 query values, q = Wq[head*64 .. +64][:] . LayerNorm(x[b]) + bq (fp32 FMA on
+// bf16 weights, export_onnx.py:221-230), instead of reading them from a preceding GEMM launch: the 98 KB of weight rows
+// come from L2 (the 64 clips of a head share them) while the first K/V block is already in flight, and a decoder
+// layer loses one dependent launch.
+template <bool FUSE_Q>
 __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, int cap_blocks) {
   __shared__ float s_part[4][kPartStride];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,8 +75,77 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
   };
   if (blk < blk_cap_end) load_block(blk);
   float qv[64];
+  if constexpr (FUSE_Q) {
+    __shared__ __attribute__((aligned(16))) float s_act[1024];
+    __shared__ float s_q[64];
+    __shared__ float s_red[8];
+    const int d = p.d_model;  // <= 1024, multiple of 32
+    const float* xr = p.x + (long)b * d;
+    float xv[4], gg[4], bb[4];
 #pragma unroll
-  for (int c = 0; c < 64; ++c) qv[c] = qp[c];
+    for (int e = 0; e < 4; ++e) {
+      const int c = tid + 256 * e;
+      xv[e] = c < d ? xr[c] : 0.f;
+      gg[e] = c < d ? p.ln_w[c] : 0.f;
+      bb[e] = c < d ? p.ln_b[c] : 0.f;
+    }
+    // the first weight chunks of this lane's row: 4 lanes share a row, lane j takes the 16-byte chunks j, j+4, ...
+    const int qrow = tid >> 2, qj = tid & 3;
+    const bf16* wr = p.wq + (long)(head * 64 + qrow) * d;
+    const int nch = d >> 3;  // 16-byte chunks per row
+    u32x4 wc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int c = qj + 4 * i; wc[i] = c < nch ? *reinterpret_cast<const u32x4*>(wr + c * 8) : u32x4{0u, 0u, 0u, 0u}; }
+    const float bq = p.bq[head * 64 + qrow];
+    float s1 = (xv[0] + xv[1]) + (xv[2] + xv[3]);
+    s1 = wave_sum(s1);
+    if (lane == 0) s_red[wave] = s1;
+    __syncthreads();
+    const float mean = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float t = tid + 256 * e < d ? xv[e] - mean : 0.f; s2 += t * t; }
+    s2 = wave_sum(s2);
+    if (lane == 0) s_red[4 + wave] = s2;
+    __syncthreads();
+    const float rstd = rsqrtf(((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])) / d + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int c = tid + 256 * e; if (c < d) s_act[c] = (xv[e] - mean) * rstd * gg[e] + bb[e]; }
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f;
+    for (int c0 = 0; c0 < nch; c0 += 32) {  // 8 chunks of this lane per pass
+      u32x4 cur[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cur[i] = wc[i];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int c = c0 + 32 + qj + 4 * i; wc[i] = c < nch ? *reinterpret_cast<const u32x4*>(wr + c * 8) : u32x4{0u, 0u, 0u, 0u}; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + qj + 4 * i;
+        if (c < nch) {
+          const float4 y0 = *reinterpret_cast<const float4*>(s_act + c * 8), y1 = *reinterpret_cast<const float4*>(s_act + c * 8 + 4);
+          a0 = fmaf(__uint_as_float(cur[i][0] << 16), y0.x, a0);
+          a1 = fmaf(__uint_as_float(cur[i][0] & 0xffff0000u), y0.y, a1);
+          a0 = fmaf(__uint_as_float(cur[i][1] << 16), y0.z, a0);
+          a1 = fmaf(__uint_as_float(cur[i][1] & 0xffff0000u), y0.w, a1);
+          a0 = fmaf(__uint_as_float(cur[i][2] << 16), y1.x, a0);
+          a1 = fmaf(__uint_as_float(cur[i][2] & 0xffff0000u), y1.y, a1);
+          a0 = fmaf(__uint_as_float(cur[i][3] << 16), y1.z, a0);
+          a1 = fmaf(__uint_as_float(cur[i][3] & 0xffff0000u), y1.w, a1);
+        }
+      }
+    }
+    float acc = a0 + a1;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (qj == 0) s_q[qrow] = acc + bq;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 64; ++c) qv[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_q[c])));
+  } else {
+#pragma unroll
+    for (int c = 0; c < 64; ++c) qv[c] = qp[c];
+  }
 
   const int n_keys = p.n_keys >= 0 ? p.n_keys : p.state->step + 1;
   const int blk_end = min((n_keys + 63) >> 6, blk_cap_end);
@@ -160,7 +234,12 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
 }
 
 void launch_decode_attention(const DecAttnParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(decode_attention_kernel, dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);
+  if (p.wq) {
+    if (p.d_model > 1024 || p.d_model % 32 != 0 || p.n_split != 1) { fprintf(stderr, "[ax_whisper] fused query projection: d_model %d, n_split %d unsupported\n", p.d_model, p.n_split); abort(); }
+    hipLaunchKernelGGL(decode_attention_kernel<true>, dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);
+  } else {
+    hipLaunchKernelGGL(decode_attention_kernel<false>, dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);
+  }
 }
 
 // ------------------------------------------------------------------------------- weight preparation

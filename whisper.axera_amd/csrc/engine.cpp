@@ -77,8 +77,8 @@ Engine::Engine(const std::string& model_type, const std::string& model_path, con
   {  // batched decode as clip-block GEMMs with LayerNorm prologue / residual epilogue (enqueue_decode_step_batched)
     const char* e = getenv("AX_WHISPER_BATCHED_LN");
     const int d = cfg_.n_text_state;
-    // measured on MI355X: faster for d_model 768 at 16-64 clips (+2..8 %); slower for 1280 (-3 %: without split-K the
-    // 5120-deep mlp.2 is 20 dependent k-steps per wave on 80-320 workgroups), which keeps the split-K sequence
+    // measured on MI355X: faster for d_model 768 at 16-64 clips (+2..8 %); slower for 1280 at 16-32 clips (-3..6 %, also
+    // with eight k-steps in flight per wave) and equal at 64, which keeps the split-K sequence
     batched_ln_ = !(e && e[0] == '0') && d % 128 == 0 && d <= 1024;
     cfg_.ints["batched_ln"] = batched_ln_ ? 1 : 0;
   }
@@ -698,6 +698,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     c.d_model = d; c.n_ctx_pad = Tc; c.state = d_state_;
     return c;
   };
+  static const bool fuse_cq = [] { const char* e = getenv("AX_WHISPER_FUSE_CQ"); return !(e && e[0] == '0'); }();
   auto cgo = [&](const DecCGemmParams& c) { if (step_mask_ & 1) launch_decode_cgemm(c, s); };
   const int n_blk = (batch + 15) / 16;
   // two row tiles per workgroup where one would make more workgroups than can be resident at once
@@ -719,10 +720,19 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
       c = cgemm(wq.w_o, w.b_o, d, d, GEPI_RESID, 1);
       c.a_hi = d_att_[0]; c.a_lo = d_att_[1]; c.out = d_xdec_;
       cgo(c);
-      c = cgemm(wq.w_cq, w.b_cq, d, d, GEPI_STORE, 1);
-      c.x = d_xdec_; c.ln_w = w.cross_ln_w; c.ln_b = w.cross_ln_b; c.out = d_qdec_;
-      cgo(c);
-      attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64);
+      if (fuse_cq) {  // the cross-attention workgroups project their own queries (decode_attention_kernel<true>)
+        DecAttnParams a{};
+        a.k = ck; a.v = cv; a.kv_batch_stride = cross_stride; a.part = nullptr; a.n_split = 1;
+        a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = cfg_.n_audio_ctx; a.cap_blocks = t_pad_ / 64; a.state = d_state_;
+        a.out_hi = d_att_[0]; a.out_lo = d_att_[1]; a.nbs = nbs_;
+        a.x = d_xdec_; a.ln_w = w.cross_ln_w; a.ln_b = w.cross_ln_b; a.wq = w.w_cq; a.bq = w.b_cq;
+        if (step_mask_ & 2) launch_decode_attention(a, s);
+      } else {
+        c = cgemm(wq.w_cq, w.b_cq, d, d, GEPI_STORE, 1);
+        c.x = d_xdec_; c.ln_w = w.cross_ln_w; c.ln_b = w.cross_ln_b; c.out = d_qdec_;
+        cgo(c);
+        attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64);
+      }
       c = cgemm(wq.w_co, w.b_co, d, d, GEPI_RESID, 1);
       c.a_hi = d_att_[0]; c.a_lo = d_att_[1]; c.out = d_xdec_;
       cgo(c);
