@@ -88,3 +88,26 @@ def test_batched_greedy_end_to_end(engine, micro_case):
             i = next(i for i in range(12) if ids[i] != got[b][i])
             srt = np.sort(lg[i])
             assert srt[-1] - srt[-2] < 4e-2, (b, i, ids, got[b])
+
+
+def test_more_than_64_clips_agree_with_single_path(built_lib, micro_case):
+    """70 clips: the clip-block GEMMs span 5 clip blocks in one launch, the vocabulary projection runs as two launches
+    (64 + 6 clips); clips on both sides of the boundary must match the 1-clip path."""
+    B = 70
+    mels = _mels(7)
+    e = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=B)
+    try:
+        e.encode_mel(np.stack([mels[b % 7] for b in range(B)]))
+        forced = np.tile(np.arange(20, 28, dtype=np.int32), (B, 1))
+        lg_b, am_b = e.decode_forced(B, forced)
+        for b in (0, 15, 16, 63, 64, 69):
+            e.encode_mel(mels[b % 7])
+            lg_1, am_1 = e.decode_forced(1, forced[:1])
+            err = np.abs(lg_b[b] - lg_1[0]).max()
+            print("clip", b, "batched(70) vs single logits diff", err)
+            assert err < 1e-3
+            srt = np.sort(lg_1[0], axis=1)
+            for s in range(lg_1.shape[1]):
+                assert am_b[b, s] == am_1[0, s] or srt[s, -1] - srt[s, -2] < 2e-3
+    finally:
+        e.close()
