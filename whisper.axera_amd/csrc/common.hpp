@@ -213,7 +213,7 @@ struct DecCGemmParams {
 };
 void launch_decode_cgemm(const DecCGemmParams& p, hipStream_t s);
 int decode_gemm_grid(int N, int rt);
-bool decode_logits_resident_ok(int K);  // rt == 0 (one workgroup per CU, activations in registers) supports this K
+bool decode_logits_resident_ok(int K, int batch);  // rt == 0 (one workgroup per CU, activations in registers) supports this shape
 void launch_act_prep(float* x, const float* g, const float* be, bf16* hi, bf16* lo, int batch, int K, bool do_ln, int nbs,
                      const float* part, int n_part, int part_batch, const float* part_bias, hipStream_t s);
 void launch_pack_weight_frag(const bf16* w, bf16* wp, int N, int K, hipStream_t s);

@@ -565,15 +565,16 @@ static void launch_logits(const DecGemmParams& p, hipStream_t s) {
   const int nb = (p.batch + 15) / 16;
   const dim3 grid(decode_gemm_grid(p.N, 0));
   const size_t lds = (size_t)2 * 8 * nb * 256 * 4;
-  switch (nb) {
-    case 1: hipLaunchKernelGGL((decode_logits_kernel<1, CH>), grid, dim3(512), lds, s, p); break;
-    case 2: hipLaunchKernelGGL((decode_logits_kernel<2, CH>), grid, dim3(512), lds, s, p); break;
-    case 3: hipLaunchKernelGGL((decode_logits_kernel<3, CH>), grid, dim3(512), lds, s, p); break;
-    default: hipLaunchKernelGGL((decode_logits_kernel<4, CH>), grid, dim3(512), lds, s, p); break;
-  }
+  if (nb == 1) hipLaunchKernelGGL((decode_logits_kernel<1, CH>), grid, dim3(512), lds, s, p);
+  if constexpr (CH * 2 <= 15) { if (nb == 2) hipLaunchKernelGGL((decode_logits_kernel<2, CH>), grid, dim3(512), lds, s, p); }
+  if constexpr (CH * 3 <= 15) { if (nb == 3) hipLaunchKernelGGL((decode_logits_kernel<3, CH>), grid, dim3(512), lds, s, p); }
+  if constexpr (CH * 4 <= 15) { if (nb >= 4) hipLaunchKernelGGL((decode_logits_kernel<4, CH>), grid, dim3(512), lds, s, p); }
 }
-// register-resident activations: k-steps per wave x clip blocks x (hi, lo) x 4 VGPRs
-bool decode_logits_resident_ok(int K) { return K % 128 == 0 && (K / 32 + 7) / 8 <= 3; }
+// register-resident activations: k-steps per wave x clip blocks x (hi, lo) x 4 VGPRs (at most 15 x 8 = 120)
+bool decode_logits_resident_ok(int K, int batch) {
+  const int ch = (K / 32 + 7) / 8, nb = (std::min(batch, 64) + 15) / 16;
+  return K % 128 == 0 && ch <= 5 && ch * nb <= 15;
+}
 
 int decode_gemm_grid(int N, int rt) {
   if (rt == 0) return std::min((N + 15) / 16, 256); return (N + 16 * rt - 1) / (16 * rt); }
@@ -597,11 +598,14 @@ void launch_decode_gemm(const DecGemmParams& p, hipStream_t s) {
   if (p.K % 128 != 0) { fprintf(stderr, "[ax_whisper] launch_decode_gemm: unsupported K=%d\n", p.K); abort(); }
   const int rt = p.rt;
   if (rt == 0) {  // vocabulary projection with register-resident activations
-    if (p.epilogue != GEPI_LOGITS || !decode_logits_resident_ok(p.K) || p.batch > 64) { fprintf(stderr, "[ax_whisper] launch_decode_gemm: rt 0 is the vocabulary projection (K <= 768)\n"); abort(); }
-    const int ch = (p.K / 32 + 7) / 8;
-    if (ch <= 1) launch_logits<1>(p, s);
-    else if (ch == 2) launch_logits<2>(p, s);
-    else launch_logits<3>(p, s);
+    if (p.epilogue != GEPI_LOGITS || !decode_logits_resident_ok(p.K, p.batch) || p.batch > 64) { fprintf(stderr, "[ax_whisper] launch_decode_gemm: rt 0 is the vocabulary projection with register-resident activations (K %d, batch %d unsupported)\n", p.K, p.batch); abort(); }
+    switch ((p.K / 32 + 7) / 8) {
+      case 1: launch_logits<1>(p, s); break;
+      case 2: launch_logits<2>(p, s); break;
+      case 3: launch_logits<3>(p, s); break;
+      case 4: launch_logits<4>(p, s); break;
+      default: launch_logits<5>(p, s); break;
+    }
     return;
   }
   if (rt == 4) launch_nb<4>(p, s);

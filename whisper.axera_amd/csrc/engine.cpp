@@ -766,7 +766,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
   ln(dec_ln_w_, dec_ln_b_);
   DecGemmParams p = base(tok_emb_packed_, nullptr, cfg_.n_vocab, d, d_act_[0], d_act_[1], GEPI_LOGITS);
   static const bool resident_off = [] { const char* e = getenv("AX_WHISPER_LOGITS_RT"); return e != nullptr; }();
-  const int vocab_rt = (!resident_off && decode_logits_resident_ok(d)) ? 0 : kLogitsRT;
+  const int vocab_rt = (!resident_off && decode_logits_resident_ok(d, batch)) ? 0 : kLogitsRT;
   p.rt = vocab_rt;
   p.amax_val = d_amax_val_; p.amax_idx = d_amax_idx_; p.amax_stride = n_amax_part_;
   p.skip_before_step = 3; p.logits_dump = d_logits; p.logits_dump_stride = logits_stride;
