@@ -374,8 +374,27 @@ __global__ __launch_bounds__(512) void gemm256sq_bf16_kernel(GemmParams p) {
     const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
     const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
     const int nt = p.n_tiles, mt = (p.M + BM3 - 1) / BM3;
-    n0 = p.n_begin + (wg % nt) * BN3;
-    const int rest = wg / nt;
+    // Wide launches (the cross-K/V projection: 36-40 column tiles, 14-26 MB of weights) walk the columns in groups of
+    // 8 tiles: an XCD sweeps its A panels against ONE group (3 MB of weights, which stay in its 4 MB L2) before it moves
+    // to the next, instead of streaming all the weights past every panel (5.7 GB fetched per launch at 64 clips).
+    constexpr int G = 8;
+    int nl, rest;
+    if (nt <= G) {
+      nl = wg % nt;
+      rest = wg / nt;
+    } else {
+      const int panels = mt * p.batch, full = nt / G, in_full = full * G * panels;
+      if (wg < in_full) {
+        const int g = wg / (G * panels), within = wg % (G * panels);
+        rest = within / G;
+        nl = g * G + within % G;
+      } else {
+        const int gl = nt - full * G, w2 = wg - in_full;
+        rest = w2 / gl;
+        nl = full * G + w2 % gl;
+      }
+    }
+    n0 = p.n_begin + nl * BN3;
     m0 = (rest % mt) * BM3;
     bz = rest / mt;
   }
