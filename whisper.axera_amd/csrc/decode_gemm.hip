@@ -13,6 +13,9 @@
 //   weights: 16-byte loads, 4 lanes cover 64 contiguous bytes of a row per k-step, k-steps unrolled so the
 //   whole 128-byte line is requested back to back; activations come from L2 (bf16 pairs written by the
 //   producer: act_prep_kernel / attention / the GELU epilogue).
+// Three kernels: decode_cgemm_kernel (clip blocks of 16, LayerNorm prologue / residual epilogue: the default sequence
+// for d_model <= 1024), decode_logits_kernel (vocabulary projection with register-resident activations) and
+// decode_gemm_kernel + act_prep_kernel (64 clips per workgroup, split-K partials: d_model > 1024 and the fallbacks).
 // Epilogues mirror decode_gemv.hip: bias, GELU (writes the bf16 pair), residual add, q + KV-cache append,
 // vocabulary argmax partials (first max wins, Whisper.cpp:42-45).
 #include "common.hpp"

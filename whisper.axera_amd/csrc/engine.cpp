@@ -20,7 +20,8 @@ namespace axw {
       throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);       \
   } while (0)
 
-// weight-row tiles per wave of the batched vocabulary projection (16 rows each per workgroup); AX_WHISPER_LOGITS_RT overrides (1, 2, 4)
+// Launch-per-row-block form of the batched vocabulary projection (used where the register-resident form does not
+// fit, and for A/B runs when AX_WHISPER_LOGITS_RT is set): weight-row tiles of 16 rows per workgroup, 1, 2 (default) or 4
 static int logits_rt() {
   static const int v = [] {
     const char* e = getenv("AX_WHISPER_LOGITS_RT");
@@ -29,7 +30,6 @@ static int logits_rt() {
   }();
   return v;
 }
-#define kLogitsRT logits_rt()
 
 static int dtype_code(const std::string& d) { return d == "F32" ? 0 : d == "BF16" ? 1 : 2; }
 
@@ -437,7 +437,7 @@ void Engine::ensure_capacity(int batch) {
   d_part_cross_ = (float*)A((size_t)B * H * split_cross_ * 66 * 4, true);
   GemvParams lp{};
   lp.N = cfg_.n_vocab; lp.K = d;
-  n_amax_part_ = std::max(gemv_grid(lp), decode_gemm_grid(cfg_.n_vocab, kLogitsRT));
+  n_amax_part_ = std::max(gemv_grid(lp), decode_gemm_grid(cfg_.n_vocab, logits_rt()));
   d_amax_val_ = (float*)A((size_t)n_amax_part_ * B * 4, true);
   d_amax_idx_ = (int*)A((size_t)n_amax_part_ * B * 4, true);
   d_tok_ = (int*)A((size_t)B * 4, true);
@@ -766,7 +766,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
   ln(dec_ln_w_, dec_ln_b_);
   DecGemmParams p = base(tok_emb_packed_, nullptr, cfg_.n_vocab, d, d_act_[0], d_act_[1], GEPI_LOGITS);
   static const bool resident_off = [] { const char* e = getenv("AX_WHISPER_LOGITS_RT"); return e != nullptr; }();
-  const int vocab_rt = (!resident_off && decode_logits_resident_ok(d, batch)) ? 0 : kLogitsRT;
+  const int vocab_rt = (!resident_off && decode_logits_resident_ok(d, batch)) ? 0 : logits_rt();
   p.rt = vocab_rt;
   p.amax_val = d_amax_val_; p.amax_idx = d_amax_idx_; p.amax_stride = n_amax_part_;
   p.skip_before_step = 3; p.logits_dump = d_logits; p.logits_dump_stride = logits_stride;

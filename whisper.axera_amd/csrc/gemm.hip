@@ -8,13 +8,16 @@
 // overlapping time-major rows: A row t = 3 consecutive input frames, lda = stride*C_in),
 // every nn.Linear of the encoder blocks and the per-decoder-layer cross K/V projections.
 //
-// Tiling (wave64): 128x128 output tile, BK = 64, 256 threads = 4 waves in 2x2, each wave a
+// Three tile shapes share one design and are chosen per launch by how many tiles it has (launch_one): 128x128
+// (4 waves, this comment), 256x128 (8 waves, 3-stage ring) and 256x256 (8 waves, 128x64 per wave) further down.
+// Tiling of the smallest (wave64): 128x128 output tile, BK = 64, 256 threads = 4 waves in 2x2, each wave a
 // 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs). A and W tiles are staged by LDS-DMA
 // (global_load_lds, no VGPR round trip) with an XOR swizzle of the 16-byte chunks (chunk ^ ((row>>1)&7)),
 // applied on the source address, which makes every ds_read_b128 fragment read conflict-free; k-tile t+1
-// streams into the other LDS buffer while k-tile t is multiplied (one drain + barrier per k-tile). Epilogues write the layouts the consumers want (V^T for the encoder attention, the
-// blocked K / row-major V of the decoder's cross-attention) so no transposition kernel exists;
-// where the consumer wants M contiguous the MFMA operands are swapped so lanes run along M.
+// streams into the other LDS buffer while k-tile t is multiplied (one drain + barrier per k-tile). Epilogues write
+// the layouts the consumers want (V^T for the encoder attention, the blocked K / row-major V of the decoder's
+// cross-attention) so no transposition kernel exists; where the consumer wants M contiguous the MFMA operands are
+// swapped so lanes run along M. Row-major outputs leave through LDS (gemm_epilogue): 16-byte row accesses.
 #include "common.hpp"
 
 namespace axw {
