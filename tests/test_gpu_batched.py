@@ -111,3 +111,48 @@ def test_more_than_64_clips_agree_with_single_path(built_lib, micro_case):
                 assert am_b[b, s] == am_1[0, s] or srt[s, -1] - srt[s, -2] < 2e-3
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("model_type,seed", [("w512", 21), ("w1024", 22), ("w1280", 23)])
+def test_model_widths_batched_and_single_vs_oracle(built_lib, oracle_mod, tmp_path, model_type, seed):
+    """The widths of Whisper base / medium / large at reduced depth: every width-dependent instantiation of the batched
+    kernels (LayerNorm-prologue GEMM with 2, 4 and 5 k-steps per wave, register-resident vocabulary projection, the
+    split-K sequence at 1280) and of the 1-clip path, teacher-forced logits against the oracle (bf16 policy)."""
+    from conftest import ModelCase
+    from make_model_goldens_inputs import demo_mel, synth_mel
+
+    case = ModelCase(tmp_path, model_type, seed)
+    nm = case.dims["n_mels"]
+    B, n = 20, 6
+    mels = [demo_mel(nm)] + [synth_mel(50 + i, nm, 3000 if i % 2 else 1200 + 11 * i) for i in range(1, B)]
+    check = (0, 7, 19)
+    forced = np.zeros((B, n), dtype=np.int32)
+    refs = {}
+    for b in check:
+        ck, cv = case.oracle_bf16.encoder(mels[b])
+        ids = case.oracle_bf16.greedy(ck, cv, "zh", max_new=n)
+        ids = (ids + [0] * n)[:n]
+        _, lg = case.oracle_bf16.greedy(ck, cv, "zh", max_new=n, forced=ids, want_logits=True)
+        forced[b], refs[b] = ids, lg
+    for b in range(B):
+        if b not in refs:
+            forced[b] = forced[0]
+    e = built_lib.Whisper(model_type, case.root, "zh", device=0, max_batch=B)
+    try:
+        for batch in (B, 6):  # two clip blocks (one ragged) / one
+            e.encode_mel(np.stack(mels[:batch]))
+            logits, am = e.decode_forced(batch, forced[:batch])
+            for b in [c for c in check if c < batch]:
+                err = np.abs(logits[b] - refs[b]).max(axis=1)
+                print(f"{model_type} batch {batch} clip {b}: logits err {err.max():.3e}")
+                assert err.max() < 2e-2
+                srt = np.sort(refs[b], axis=1)
+                for s in range(refs[b].shape[0]):
+                    assert am[b, s] == int(refs[b][s].argmax()) or srt[s, -1] - srt[s, -2] < 2 * err[s] + 1e-3
+        e.encode_mel(mels[7])
+        lg1, _ = e.decode_forced(1, forced[7:8])
+        err1 = np.abs(lg1[0] - refs[7]).max()
+        print(f"{model_type} single clip: logits err {err1:.3e}")
+        assert err1 < 2e-2
+    finally:
+        e.close()

@@ -31,6 +31,10 @@ DIMS = {
     "mini":   dict(n_mels=80,  d=256,  heads=4,  enc_layers=2,  dec_layers=3,  n_vocab=51865, n_langs=99),
     # turbo-shaped front half at reduced width: 128 mels, 100 languages (adds yue), n_vocab 51866, shallow decoder
     "miniturbo": dict(n_mels=128, d=256, heads=4, enc_layers=3, dec_layers=2, n_vocab=51866, n_langs=100),
+    # full widths of base / medium / large at reduced depth: every width-dependent kernel instantiation, cheap oracle
+    "w512":   dict(n_mels=80,  d=512,  heads=8,  enc_layers=1,  dec_layers=2,  n_vocab=51865, n_langs=99),
+    "w1024":  dict(n_mels=80,  d=1024, heads=16, enc_layers=1,  dec_layers=2,  n_vocab=51865, n_langs=99),
+    "w1280":  dict(n_mels=128, d=1280, heads=20, enc_layers=1,  dec_layers=2,  n_vocab=51866, n_langs=100),
 }
 
 N_AUDIO_CTX = 1500
