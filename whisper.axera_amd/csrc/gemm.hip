@@ -112,8 +112,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&accw
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n) = v;
           } else {
             bf16x4 o;
+            if constexpr (EPI == EPI_BIAS_GELU_BF16) {
+              const f32x2_t g0 = gelu_erf_fast2(f32x2_t{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2_t{v[2], v[3]});
+              o[0] = (bf16)g0[0]; o[1] = (bf16)g0[1]; o[2] = (bf16)g1[0]; o[3] = (bf16)g1[1];
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16)(EPI == EPI_BIAS_GELU_BF16 ? gelu_erf_fast(v[e]) : v[e]);
+              for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+            }
             bf16* dst;
             if constexpr (EPI == EPI_QKV) {  // Q (n < d) or K (d <= n < 2d), both bf16 [m][d]
               dst = n < d ? reinterpret_cast<bf16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * d + n
