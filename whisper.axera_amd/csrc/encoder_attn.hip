@@ -18,12 +18,13 @@
 // Work per (clip, layer): 4*T^2*64*H flops = 6.9 GFLOP (small); HBM: Q,K,V read once per
 // 128-row block (K,V stay in ONE L2 across the 12 blocks of a head: XCD-aware block order), O written once.
 #include "common.hpp"
+#include <type_traits>
 
 namespace axw {
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + 16 * (chunk ^ ((row >> 1) & 7)); }
 
-__global__ __launch_bounds__(256) void encoder_attention_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+__global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                                 const bf16* __restrict__ VT, bf16* __restrict__ O, int T,
                                                                 int t_pad, int d_model, int n_head) {
   __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
@@ -89,8 +90,12 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const bf16* __re
 
   const float sc = 0.125f * 1.44269504088896340736f;  // (64^-0.25)^2 * log2(e)
 
-  // One 64-key tile out of LDS: scores, online softmax, P.V  (kt only selects the tail mask)
-  auto process_tile = [&](int kt) {
+  // One 64-key tile out of LDS: scores, online softmax, P.V. TAIL (a compile-time tag) masks the keys >= T: only the
+  // last tile has any, and as a run-time test the compiler evaluated the 32 compare/select pairs on every tile.
+  // The raw MFMA scores stay unscaled: exp2(s*sc - m*sc) is one FMA per element into v_exp, the running maximum is
+  // kept in raw-score units (sc > 0).
+  auto process_tile = [&](int kt, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     // ---- S^T = K Q^T : sacc[kb][e] = score(key = kt*64 + kb*32 + (e&3) + 8*(e>>2) + 4h, query = lane r)
     f32x16 sacc[2];
 #pragma unroll
@@ -105,30 +110,28 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const bf16* __re
     }
     // ---- online softmax (fp32, base-2)
     float mt = -INFINITY;
-    const bool tail = (kt + 1) * 64 > T;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float v = sacc[kb][e] * sc;
-        if (tail) {
-          int key = kt * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (key >= T) v = -INFINITY;
+        if constexpr (TAIL) {
+          const int key = kt * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= T) sacc[kb][e] = -INFINITY;
         }
-        sacc[kb][e] = v;
-        mt = fmaxf(mt, v);
+        mt = fmaxf(mt, sacc[kb][e]);
       }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    const float m_new = fmaxf(m_run, mt);  // raw-score units; every tile has at least one unmasked key
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
     m_run = m_new;
+    const float m_sc = m_new * sc;
     float ls = 0.f;
     bf16x8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float pv = __builtin_amdgcn_exp2f(sacc[kb][e] - m_new);
+        float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], sc, -m_sc));
         ls += pv;
         pf[kb][e >> 3][e & 7] = (bf16)pv;
       }
@@ -159,12 +162,12 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const bf16* __re
   // hipcc keep them in scratch memory and serialise every load).
   for (int kt = 0; kt + 1 < nkt; ++kt) {
     load_tile(kt + 1);
-    process_tile(kt);
+    process_tile(kt, std::false_type{});
     __syncthreads();
     store_tile();
     __syncthreads();
   }
-  process_tile(nkt - 1);
+  process_tile(nkt - 1, std::true_type{});  // t_pad - T < 64: only the last tile holds padded keys
 
   const float l = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l;
