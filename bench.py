@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the MI355X Whisper hot path (BASELINE.json: RTF on a 30 s clip + clips/s).
+"""bench.py — headline benchmark of the MI355X Whisper hot path (BASELINE.json: RTF on a 30 s clip + clips/s at batch).
 
 A "step" is one pass of the whole hot path over one batch of synthetic 30 s clips that are already
 resident in HBM: log-mel front-end -> encoder -> greedy decode (4 SOT steps + up to 444 tokens; with
 synthetic weights eot practically never wins, so every clip runs the full 448-step context) -> ids.
-Default workload = BASELINE.json configs[1]: Whisper-small bf16, 1 GPU, batch 1.
 
-    python bench.py                                  # N=1, batch 1
-    python bench.py --batch 64                       # configs[2]
-    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8   # one rank per GPU, weak scaling
+    python bench.py                      # N=1: BASELINE configs[1] (Whisper-small, batch 1) as the headline value,
+                                         #      plus a "batch64" object = configs[2] timed in the same run
+    python bench.py --batch 64           # configs[2] as the headline value
+    python bench.py --gpus 8             # configs[4]: spawns 8 ranks (one per GPU, RCCL), 64 clips per GPU
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8     # the same, launched by the driver
 
-Prints ONE JSON line (rank 0). `roofline` is for the dominant kernel family of the decode loop,
-`cpu_baseline` is the CPU oracle ("port") timed on this box's host cores on one clip of the same workload.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts `python -m torch.distributed.run` as a CHILD
+process before anything in this process has touched a GPU, relays its single JSON line and exits with its code.
+
+Prints ONE JSON line (rank 0). `roofline` is for the dominant kernel of the timed region, `cpu_baseline` is the CPU
+oracle ("port") timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,14 +30,50 @@ for p in (ROOT, os.path.join(ROOT, "whisper.axera_amd", "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16/fp16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
+N_SAMP = 480000  # 30 s at 16 kHz
+PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU (weak scaling); 0 = 1 at N=1, 64 at N>1")
+    ap.add_argument("--model", default="small")
+    ap.add_argument("--max-new", type=int, default=0, help="0 = until eot or context (444 ids)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch64", action="store_true", help="N=1, batch 1 only: skip the batch-64 leg")
+    ap.add_argument("--model-dir", default=os.environ.get("AXW_BENCH_MODEL_DIR", "/tmp/axw_bench_models"))
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------- N > 1: spawn the ranks
+def spawn_ranks(args) -> int:
+    """Start one rank per GPU as children of this process (which has not touched a GPU) and relay rank 0's line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in r.stdout.splitlines():
+        if l not in lines:
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return r.returncode if r.returncode != 0 or lines else 1
+
+
+# ------------------------------------------------------------------------------------------- algorithmic work
 def decode_step_bytes(dims, batch, step, s=2):
-    """weights once per step + cross-KV + self-KV per clip, element size s (bf16)."""
+    """weights once per step + cross-KV + self-KV per clip, element size s."""
     d, L, nv = dims["d"], dims["dec_layers"], dims["n_vocab"]
     weights = s * (L * 14 * d * d + nv * d)
     cross = batch * s * 2 * L * 1500 * d
@@ -39,99 +81,37 @@ def decode_step_bytes(dims, batch, step, s=2):
     return weights, cross, self_kv
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1, help="clips per GPU (weak scaling)")
-    ap.add_argument("--model", default="small")
-    ap.add_argument("--max-new", type=int, default=0, help="0 = until eot or context (444 ids)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--model-dir", default=os.environ.get("AXW_BENCH_MODEL_DIR", "/tmp/axw_bench_models"))
-    args = ap.parse_args()
+def load_pmc(model, B):
+    path = os.path.join(ROOT, PMC_FILE)
+    if not os.path.exists(path):
+        return {}, None
+    return json.load(open(path)).get(f"{model}_b{B}", {}), PMC_FILE
 
-    import torch
-    import torch.distributed as dist
 
-    import modelgen
-    import whisper_axera_amd as wa
+class RehearsalEngine:
+    """AXW_BENCH_REHEARSAL=1 (CPU tests of the N>1 plumbing only): no GPU, no engine — ids are a function of the clip."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    # AXW_BENCH_FORCE_DIST=1: run the RCCL group, the barriers and the result gather even with one rank (a rehearsal of
-    # the N>1 code path on a one-GPU box)
-    use_dist = world > 1 or os.environ.get("AXW_BENCH_FORCE_DIST") == "1"
-    saved_stdout = None
-    if use_dist:
-        # RCCL prints a version banner on stdout when its communicator is created; stdout must carry the ONE JSON
-        # line only, so everything until then goes to stderr (file-descriptor level: the banner comes from C code)
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    def run(self, clips, max_new):
+        return [[int(abs(float(c[:16].sum())) * 1e3) % 50000 + i for i in range(5 + (k % 3))] for k, c in enumerate(clips)]
 
-    def barrier():
-        if use_dist:
-            dist.barrier(device_ids=[local_rank])
 
-    # ---- synthetic-weight model directory (no weights exist in the reference or this image)
-    dims = modelgen.DIMS[args.model]
-    mdir = os.path.join(args.model_dir, args.model)
-    if local_rank == 0 and not os.path.exists(os.path.join(mdir, f"{args.model}.safetensors")):
-        modelgen.write_model_dir(args.model_dir, args.model, dims, seed=0,
-                                 tiktoken_path=os.path.join(ROOT, "tests", "golden", "multilingual.tiktoken"))
+def timed_steps(one_step, steps, warmup, sync, barrier):
+    for _ in range(warmup):
+        one_step()
     barrier()
-
-    B = args.batch
-    eng = wa.Whisper(args.model, args.model_dir, "zh", device=local_rank, max_batch=B)
-    stream = torch.cuda.current_stream(dev)
-    eng.set_stream(stream.cuda_stream)
-
-    n_samp = 480000
-    clips = np.stack([modelgen.synth_clip(rank * B + i, n_samp) for i in range(B)])
-    d_pcm = torch.from_numpy(clips).to(dev)
-    torch.cuda.synchronize(dev)
-
-    from whisper_axera_amd import dp
-
-    def one_step():
-        ids = eng.run_device_tokens(d_pcm.data_ptr(), n_samp, [n_samp] * B, max_new=args.max_new)
-        if use_dist:  # the ONE collective of the path: result gather over RCCL/xGMI
-            dp.gather_ids(ids, B, device=dev)
-        return ids
-
-    for _ in range(args.warmup):
-        ids = one_step()
-    barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
-    stage = {"frontend_ms": 0.0, "encoder_ms": 0.0, "decode_ms": 0.0, "steps": 0}
-    for _ in range(args.steps):
+    for _ in range(steps):
         ids = one_step()
-        tm = eng.timings()
-        for k in stage:
-            stage[k] += tm[k]
-    torch.cuda.synchronize(dev)
+    sync()
     barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    return time.perf_counter() - t0, ids
 
-    ms_per_step = dt / args.steps * 1e3
-    clips_per_s = world * B * args.steps / dt
-    n_tok = float(np.mean([len(r) for r in ids]))
-    dec_steps = stage["steps"] / args.steps
 
-    # ---- roofline of the dominant kernel of the timed region.
+def roofline_for(eng, dims, model, B, dec_steps, decode_ms_per_step, dtype_bytes=2):
+    """Roofline of the dominant kernel of a B-clip step, measured live with hipEvents on the engine's stream."""
     iters = 50
-    w_bytes, c_bytes, s_bytes = decode_step_bytes(dims, B, 224)
+    w_bytes, c_bytes, s_bytes = decode_step_bytes(dims, B, 224, dtype_bytes)
     small_batch = B <= 4
     persistent = B == 1 and eng.L.AX_WHISPER_GetConfigInt(eng.h, b"persistent_decode") == 1
     n_launch = (dims["dec_layers"] * 6 + 1) * ((B + 3) // 4 if small_batch else (B + 63) // 64)
@@ -142,16 +122,15 @@ def main():
     ms_attn = eng.bench("decode_attn", B, 224, iters) / iters
     step_gbs = (w_bytes + c_bytes + s_bytes) / (ms_step * 1e-3) / 1e9
     attn_gbs = (c_bytes + s_bytes) / (ms_attn * 1e-3) / 1e9
-    fam = "gemv_kernel" if small_batch else "decode_gemm_kernel"  # PMC family: clip-block GEMMs + vocabulary projection
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    pmc = json.load(open(pmc_path)).get(f"{args.model}_b{B}", {}) if os.path.exists(pmc_path) else {}
+    fam = "gemv_kernel" if small_batch else "decode_gemm_kernel"  # PMC family: linear layers + vocabulary projection
+    pmc, pmc_src = load_pmc(model, B)
 
-    def pmc_traffic(name):  # HBM bytes per launch from rocprofv3 --pmc passes (recipe in profiles/README.md)
+    def traffic(name):  # HBM bytes per launch from rocprofv3 --pmc passes of this command (recipe: profiles/README.md)
         rec = pmc.get(name)
         return rec["hbm_bytes_per_launch"] if rec else None
 
     graph_path = {"kernel": f"{fam}{'/gemv1_kernel' if small_batch else ''} (decode linear layers, all shapes)",
-                  "achieved": round(fam_gbs, 1), "frac": round(fam_gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(fam),
+                  "achieved": round(fam_gbs, 1), "frac": round(fam_gbs / HBM_PEAK_GBS, 4), "traffic": traffic(fam),
                   "launches_per_decode_step": n_launch, "avg_launch_us": round(per_launch_s * 1e6, 3),
                   "bytes_per_launch": int(w_bytes / n_launch),
                   "decode_step": {"ms": round(ms_step, 4), "algorithmic_GBs": round(step_gbs, 1),
@@ -164,89 +143,326 @@ def main():
         # weights + cross-K/V every step, the vocabulary projection on the steps whose logits are used (all but the
         # 3 SOT steps), self-K/V of the t+1 cached keys. Duration: hipEvents on the engine's stream around the
         # launch (Engine::run_tokens, stage "decode"), averaged over the timed clips.
-        d_, L_, nv_ = dims["d"], dims["dec_layers"], dims["n_vocab"]
+        d_, L_, nv_, s_ = dims["d"], dims["dec_layers"], dims["n_vocab"], dtype_bytes
         n_steps = int(round(dec_steps))
-        launch_bytes = n_steps * (2 * L_ * 14 * d_ * d_ + 2 * 2 * L_ * 1500 * d_) + max(n_steps - 3, 0) * 2 * nv_ * d_ \
-            + sum(2 * 2 * L_ * (t + 1) * d_ for t in range(n_steps))
-        launch_s = stage["decode_ms"] / args.steps * 1e-3
+        launch_bytes = n_steps * (s_ * L_ * 14 * d_ * d_ + s_ * 2 * L_ * 1500 * d_) + max(n_steps - 3, 0) * s_ * nv_ * d_ \
+            + sum(s_ * 2 * L_ * (t + 1) * d_ for t in range(n_steps))
+        launch_s = decode_ms_per_step * 1e-3
         gbs = launch_bytes / launch_s / 1e9
-        roofline = {"kernel": "decode_persistent_kernel (the whole greedy loop of one clip: %d decoder steps in one launch)" % n_steps,
-                    "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic("decode_persistent_kernel"), "launch_ms": round(launch_s * 1e3, 3),
-                    "bytes_per_launch": int(launch_bytes), "us_per_decode_step": round(launch_s * 1e6 / max(n_steps, 1), 2),
-                    "launch_per_phase_path": graph_path}
+        roof = {"kernel": "decode_persistent_kernel (the whole greedy loop of one clip: %d decoder steps in one launch)" % n_steps,
+                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "traffic": traffic("decode_persistent_kernel"), "launch_ms": round(launch_s * 1e3, 3),
+                "bytes_per_launch": int(launch_bytes), "us_per_decode_step": round(launch_s * 1e6 / max(n_steps, 1), 2),
+                "launch_per_phase_path": graph_path}
     elif small_batch:
-        roofline = dict({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}, **graph_path)
+        roof = dict({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}, **graph_path)
     else:
         # 5+ clips: the step is dominated by decode_attention_kernel (cross + self attention, one workgroup per
         # (clip, head)), which streams every clip's K/V once per step: algorithmic bytes = B * (55.3 MB cross +
         # (t+1) * 36.9 KB self) at t = 224 (the mid-utterance step this leg replays), over 2 launches per layer.
         n_attn = 2 * dims["dec_layers"]
-        roofline = {"kernel": "decode_attention_kernel (self + cross attention of one decoder step, %d launches)" % n_attn,
-                    "bound": "hbm", "achieved": round(attn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(attn_gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("decode_attention_kernel"),
-                    "avg_launch_us": round(ms_attn * 1e3 / n_attn, 3), "bytes_per_launch": int((c_bytes + s_bytes) / n_attn),
-                    "share_of_decode_step": round(ms_attn / ms_step, 3),
-                    "decode_step": graph_path["decode_step"],
-                    "linear_layers": {k: graph_path[k] for k in ("kernel", "achieved", "frac", "traffic", "launches_per_decode_step",
-                                                                "avg_launch_us", "bytes_per_launch")}}
+        roof = {"kernel": "decode_attention_kernel (self + cross attention of one decoder step, %d launches)" % n_attn,
+                "bound": "hbm", "achieved": round(attn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(attn_gbs / HBM_PEAK_GBS, 4), "traffic": traffic("decode_attention_kernel"),
+                "avg_launch_us": round(ms_attn * 1e3 / n_attn, 3), "bytes_per_launch": int((c_bytes + s_bytes) / n_attn),
+                "share_of_decode_step": round(ms_attn / ms_step, 3),
+                "decode_step": graph_path["decode_step"],
+                "linear_layers": {k: graph_path[k] for k in ("kernel", "achieved", "frac", "traffic", "launches_per_decode_step",
+                                                            "avg_launch_us", "bytes_per_launch")}}
+    roof["traffic_source"] = (f"{pmc_src}: static, rocprofv3 --pmc passes of this command on the same build (not collected in "
+                              "this run)") if pmc_src and roof.get("traffic") is not None else None
+    return roof
 
-    # ---- the other two stages against their own rooflines: encoder = MFMA-bound, front-end = HBM-bound
-    enc_flop = {"tiny": 40.48e9, "small": 386.63e9, "turbo": 2313.09e9}.get(args.model)
+
+def stage_rooflines(eng, dims, model, B):
+    """The other two stages against their own rooflines: encoder = MFMA-bound; the front-end is a
+    brute-force 400-point DFT per frame (fp32 FMA-bound at batch, launch latency at one clip), its bytes are tiny."""
+    enc_flop = {"tiny": 40.48e9, "small": 386.63e9, "turbo": 2313.09e9}.get(model)
     ms_enc = eng.bench("encoder", B, 0, 5) / 5
     ms_fe = eng.bench("frontend", B, 0, 10) / 10
-    stages = {"frontend": {"ms": round(ms_fe, 4), "GBs": round(B * (4 * n_samp + 2 * dims["n_mels"] * 3000) / (ms_fe * 1e-3) / 1e9, 1),
-                           "bound": "hbm"}}
+    fe_flop = B * 3001 * (2 * 400 * 201 * 2 + 2 * 201 * dims["n_mels"])
+    stages = {"frontend": {"ms": round(ms_fe, 4), "GBs": round(B * (4 * N_SAMP + 2 * dims["n_mels"] * 3000) / (ms_fe * 1e-3) / 1e9, 1),
+                           "fp32_TFLOPs": round(fe_flop / (ms_fe * 1e-3) / 1e12, 2),
+                           "bound": "fp32 FMA (direct DFT) at batch, launch latency at one clip"}}
     if enc_flop:
         tf = enc_flop * B / (ms_enc * 1e-3) / 1e12
         stages["encoder"] = {"ms": round(ms_enc, 3), "TFLOPs": round(tf, 1), "bound": "mfma", "peak": MFMA_BF16_PEAK_TF,
                              "frac": round(tf / MFMA_BF16_PEAK_TF, 4)}
+    return stages
+
+
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, dims, mdir, clip, gpu_ids, dec_steps):
+    """The CPU oracle ("port") on this box's host cores, one clip of the headline workload, bounded to ~20 s:
+    all-core figure (the reported value) + a single-thread figure + the front-end alone."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+
+    import modelgen
+    import oracle
+
+    ncpu = os.cpu_count() or 1
+    threads = min(ncpu, 32)
+    weights = modelgen.read_safetensors(os.path.join(mdir, f"{args.model}.safetensors"))
+    cfg = modelgen.make_config(args.model, dims)
+    orc = oracle.Oracle(cfg, weights, bf16_policy=True, threads=threads)
+    max_new = args.max_new if args.max_new > 0 else 444
+    cpu_new = min(max_new, 96)  # bounded sample: full front-end + encoder, 4 + 96 decoder steps
+    t1 = time.perf_counter()
+    cpu_ids = orc.transcribe(clip, "zh", max_new=cpu_new)
+    t_cpu = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    mel, _, _ = oracle.log_mel(clip, dims["n_mels"])
+    t_fe_all = time.perf_counter() - t2
+    ck, cv = orc.encoder(mel)
+    t_enc = time.perf_counter() - t2
+    t_dec_step = max(t_cpu - t_enc, 1e-9) / (4 + len(cpu_ids))
+    t_full = t_enc + t_dec_step * dec_steps
+    agree = 0
+    for a, b in zip(cpu_ids, gpu_ids):
+        if a != b:
+            break
+        agree += 1
+    out = {"value": round(1.0 / t_full, 5), "unit": "clips/s", "cores": threads, "kind": "port",
+           "cpu_model": cpu_model_string(), "host_cores": ncpu,
+           "sample": f"clip 0: front-end + encoder measured ({t_enc:.2f} s) + {4 + len(cpu_ids)} decoder "
+                     f"steps measured ({t_dec_step * 1e3:.1f} ms/step) scaled to {dec_steps:.0f} steps; "
+                     f"CPU oracle (bf16 policy), {threads} OpenMP threads of {ncpu}",
+           "ids_agree_prefix": f"{agree}/{len(cpu_ids)}"}
+    # single thread: the front-end in full; the encoder from 1- and 2-layer copies of the model (linear in depth);
+    # 4 + 4 decoder steps of the full-depth decoder
+    orc.L.orc_set_threads(1)
+    t3 = time.perf_counter()
+    oracle.log_mel(clip, dims["n_mels"])
+    t_fe1 = time.perf_counter() - t3
+    enc_t = []
+    for nl in (1, 2):
+        c2 = dict(cfg, n_audio_layer=nl, n_text_layer=1)
+        o2 = oracle.Oracle(c2, weights, bf16_policy=True, threads=1)
+        t4 = time.perf_counter()
+        o2.encoder(mel)
+        enc_t.append(time.perf_counter() - t4)
+    per_layer = max(enc_t[1] - enc_t[0], 1e-9)
+    L_e, L_d = dims["enc_layers"], dims["dec_layers"]
+    # one cross-K/V projection pair (2 of the 2*L_d GEMMs) is inside both samples: 2*1500*d*d MACs each ~ 1/9.4 of a layer
+    d = dims["d"]
+    layer_flop = 2 * (4 * 1500 * d * d + 2 * dims["heads"] * 1500 * 1500 * 64 + 2 * 1500 * d * 4 * d)
+    ckv_t = per_layer * (2 * 2 * 1500 * d * d) / layer_flop
+    t_enc1 = enc_t[0] + per_layer * (L_e - 1) + ckv_t * (L_d - 1)
+    sk, sv = orc.new_self_cache()
+    sot = orc.sot_seq("zh")
+    t5 = time.perf_counter()
+    for i in range(8):
+        orc.decoder_step(sot[i] if i < 4 else 1000 + i, i, ck, cv, sk, sv, want_logits=i >= 3)
+    t_step1 = (time.perf_counter() - t5) / 8
+    t_full1 = t_fe1 + t_enc1 + t_step1 * dec_steps
+    out["single_thread"] = {"value": round(1.0 / t_full1, 5), "unit": "clips/s", "cores": 1,
+                            "sample": f"front-end measured ({t_fe1 * 1e3:.1f} ms); encoder extrapolated from 1- and 2-layer "
+                                      f"runs ({enc_t[0]:.2f} s, {enc_t[1]:.2f} s -> {t_enc1:.1f} s for {L_e} layers); 8 decoder "
+                                      f"steps measured ({t_step1 * 1e3:.1f} ms/step) scaled to {dec_steps:.0f} steps"}
+    fe = {"port_all_cores_ms": round(t_fe_all * 1e3, 2), "port_1_thread_ms": round(t_fe1 * 1e3, 2)}
+    if oracle.ref_lib() is not None:  # the reference's own librosa.h front-end, compiled by oracle/Makefile `ref`
+        t6 = time.perf_counter()
+        oracle.log_mel(clip, dims["n_mels"], use_ref=True)
+        fe["reference_1_thread_ms"] = round((time.perf_counter() - t6) * 1e3, 2)
+    out["frontend_only"] = fe
+    orc.L.orc_set_threads(min(ncpu, 16))
+    return out
+
+
+# ------------------------------------------------------------------------------------------- one rank
+def run_rank(args) -> int:
+    import numpy as np
+
+    import modelgen
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+              f"(python bench.py --gpus {args.gpus} does it by itself)", file=sys.stderr)
+        return 2
+    rehearsal = os.environ.get("AXW_BENCH_REHEARSAL") == "1"  # CPU test of the N>1 plumbing: gloo, no GPU, no engine
+    backend = "gloo" if rehearsal else os.environ.get("AXW_BENCH_BACKEND", "nccl")
+    # AXW_BENCH_ONE_DEVICE=1: every rank uses GPU 0 (a rehearsal of N ranks with real engines on a one-GPU box; gloo)
+    dev_index = 0 if os.environ.get("AXW_BENCH_ONE_DEVICE") == "1" else local_rank
+    # AXW_BENCH_FORCE_DIST=1: run the process group, the barriers and the result gather even with one rank
+    use_dist = world > 1 or os.environ.get("AXW_BENCH_FORCE_DIST") == "1"
+    B = args.batch if args.batch > 0 else (1 if world == 1 else 64)
+    dims = modelgen.DIMS[args.model]
+
+    import torch
+    import torch.distributed as dist
+
+    saved_stdout = None
+    if use_dist:
+        # RCCL prints a version banner on stdout when its communicator is created; stdout must carry the ONE JSON
+        # line only, so everything until then goes to stderr (file-descriptor level: the banner comes from C code)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = None
+    if not rehearsal:
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else None  # where the gathered rows live
+
+    def barrier():
+        if use_dist:
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
+
+    def sync():
+        if dev is not None:
+            torch.cuda.synchronize(dev)
+
+    from whisper_axera_amd import dp
+
+    clips = np.stack([modelgen.synth_clip(rank * B + i, N_SAMP) for i in range(B)])
+    out = {}
+    rc = 0
+    if rehearsal:
+        eng = RehearsalEngine()
+
+        def one_step():
+            ids = eng.run(clips, args.max_new)
+            return dp.gather_ids(ids, B, device=None) if use_dist else ids
+
+        dt, ids = timed_steps(one_step, args.steps, args.warmup, sync, barrier)
+        stage, dec_steps, n_tok = {}, 0, float(np.mean([len(r) for r in ids]))
+    else:
+        import whisper_axera_amd as wa
+
+        # ---- synthetic-weight model directory (no weights exist in the reference or this image)
+        mdir = os.path.join(args.model_dir, args.model)
+        if local_rank == 0 and not os.path.exists(os.path.join(mdir, f"{args.model}.safetensors")):
+            modelgen.write_model_dir(args.model_dir, args.model, dims, seed=0,
+                                     tiktoken_path=os.path.join(ROOT, "tests", "golden", "multilingual.tiktoken"))
+        barrier()
+        eng = wa.Whisper(args.model, args.model_dir, "zh", device=dev_index, max_batch=B)
+        stream = torch.cuda.current_stream(dev)
+        eng.set_stream(stream.cuda_stream)
+        d_pcm = torch.from_numpy(clips).to(dev)
+        sync()
+        stage = {"frontend_ms": 0.0, "encoder_ms": 0.0, "decode_ms": 0.0, "steps": 0}
+        gathered = {}
+
+        def one_step():
+            ids = eng.run_device_tokens(d_pcm.data_ptr(), N_SAMP, [N_SAMP] * B, max_new=args.max_new)
+            tm = eng.timings()
+            for k in stage:
+                stage[k] += tm[k]
+            if use_dist:  # the ONE collective of the path: result gather over RCCL/xGMI (SURVEY §8e)
+                gathered["ids"] = dp.gather_ids(ids, B, device=coll_dev)
+            return ids
+
+        for _ in range(args.warmup):
+            one_step()
+        for k in stage:
+            stage[k] = 0
+        dt, ids = timed_steps(one_step, args.steps, 0, sync, barrier)
+        if use_dist and len(gathered["ids"]) != world * B:
+            print(f"bench.py: gathered {len(gathered['ids'])} id rows, expected {world * B}", file=sys.stderr)
+            rc = 3
+        n_tok = float(np.mean([len(r) for r in ids]))
+        dec_steps = stage["steps"] / args.steps
+
+    if use_dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    clips_per_s = world * B * args.steps / dt
+    dtype = "bf16"
 
     out = {
         "metric": "clips_per_sec (30 s clips, greedy decode, whisper-%s)" % args.model,
         "value": round(clips_per_s, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"whisper-{args.model} bf16, batch {B}/GPU, 30 s synthetic 16 kHz clips resident in HBM, "
+        "dtype": dtype, "data": "synthetic",
+        "config": {"workload": f"whisper-{args.model} {dtype}, batch {B}/GPU, 30 s synthetic 16 kHz clips resident in HBM, "
                                f"greedy decode {n_tok:.0f} ids/clip ({dec_steps:.0f} decoder steps)",
-                   "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}", "weights": "seeded synthetic"},
+                   "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}", "weights": "seeded synthetic",
+                   "collective": (f"{backend} all_gather of int32 [count, ids] rows, once per step" if use_dist else "none")},
         "rtf": round(dt / args.steps / (B * 30.0), 6),
-        "stage_ms": {k: round(v / args.steps, 3) for k, v in stage.items() if k != "steps"},
-        "roofline": roofline,
-        "stage_rooflines": stages,
     }
+    if rehearsal:
+        out["data"] = "REHEARSAL (AXW_BENCH_REHEARSAL=1): no GPU and no engine ran — plumbing test of the N>1 path only"
+        out["value"] = None
+        out["gathered_rows"] = len(ids)
+    else:
+        out["stage_ms"] = {k: round(v / args.steps, 3) for k, v in stage.items() if k != "steps"}
+        if rank == 0:
+            out["roofline"] = roofline_for(eng, dims, args.model, B, dec_steps, stage["decode_ms"] / args.steps)
+            out["stage_rooflines"] = stage_rooflines(eng, dims, args.model, B)
+            # SURVEY §8(d) defines RTF on the host-pointer call (H2D of the PCM and D2H of the ids included): same
+            # engine, same clips, through AX_WHISPER_RunPCMBatchTokens. Never `value`.
+            hsteps = max(1, min(args.steps, 5))
+            host_clips = [clips[i] for i in range(B)]
+            eng.run_tokens_batch(host_clips, max_new=args.max_new)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(hsteps):
+                eng.run_tokens_batch(host_clips, max_new=args.max_new)
+            th = (time.perf_counter() - t0) / hsteps
+            out["host_pcm"] = {"rtf": round(th / (B * 30.0), 6), "clips_per_s": round(B / th, 4), "ms_per_step": round(th * 1e3, 3),
+                               "what": "AX_WHISPER_RunPCMBatchTokens: PCM in host memory, H2D + D2H inside the timed call"}
+        eng.close()
+        sync()
+        # ---- the other half of the headline metric ("clips/s at batch"), in the same run: configs[2], batch 64
+        if rank == 0 and world == 1 and B == 1 and not args.no_batch64 and args.model == "small":
+            import whisper_axera_amd as wa
+            B2 = 64
+            clips2 = np.stack([modelgen.synth_clip(i, N_SAMP) for i in range(B2)])
+            d_pcm2 = torch.from_numpy(clips2).to(dev)
+            eng2 = wa.Whisper(args.model, args.model_dir, "zh", device=dev_index, max_batch=B2)
+            eng2.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            st2 = {"frontend_ms": 0.0, "encoder_ms": 0.0, "decode_ms": 0.0, "steps": 0}
 
-    # ---- CPU baseline: the oracle ("port") on this box's host cores, one clip of the same workload
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle
+            def step2():
+                r = eng2.run_device_tokens(d_pcm2.data_ptr(), N_SAMP, [N_SAMP] * B2, max_new=args.max_new)
+                tm = eng2.timings()
+                for k in st2:
+                    st2[k] += tm[k]
+                return r
 
-        threads = min(os.cpu_count() or 1, 32)
-        weights = modelgen.read_safetensors(os.path.join(mdir, f"{args.model}.safetensors"))
-        orc = oracle.Oracle(modelgen.make_config(args.model, dims), weights, bf16_policy=True, threads=threads)
-        max_new = args.max_new if args.max_new > 0 else 444
-        cpu_new = min(max_new, 96)  # bounded sample: full front-end + encoder, 4 + 96 decoder steps
-        t1 = time.perf_counter()
-        cpu_ids = orc.transcribe(clips[0], "zh", max_new=cpu_new)
-        t_cpu = time.perf_counter() - t1
-        # scale the decode part to the GPU's step count: measure encoder and decode separately
-        t2 = time.perf_counter()
-        mel, _, _ = oracle.log_mel(clips[0], dims["n_mels"])
-        ck, cv = orc.encoder(mel)
-        t_enc = time.perf_counter() - t2
-        t_dec_step = max(t_cpu - t_enc, 1e-9) / (4 + len(cpu_ids))
-        t_full = t_enc + t_dec_step * dec_steps
-        agree = 0
-        for a, b in zip(cpu_ids, ids[0]):
-            if a != b:
-                break
-            agree += 1
-        out["cpu_baseline"] = {"value": round(1.0 / t_full, 5), "unit": "clips/s", "cores": threads, "kind": "port",
-                               "sample": f"clip 0: front-end + encoder measured ({t_enc:.2f} s) + {4 + len(cpu_ids)} decoder "
-                                         f"steps measured ({t_dec_step * 1e3:.1f} ms/step) scaled to {dec_steps:.0f} steps; "
-                                         f"CPU oracle (bf16 policy), {threads} OpenMP threads of {os.cpu_count()}",
-                               "ids_agree_prefix": f"{agree}/{len(cpu_ids)}"}
-    eng.close()
+            step2()
+            for k in st2:
+                st2[k] = 0
+            n2 = max(1, min(args.steps, 5))
+            dt2, ids2 = timed_steps(step2, n2, 0, sync, lambda: None)
+            out["batch64"] = {
+                "value": round(B2 * n2 / dt2, 3), "unit": "clips/s", "steps": n2, "ms_per_step": round(dt2 / n2 * 1e3, 2),
+                "rtf": round(dt2 / n2 / (B2 * 30.0), 7),
+                "config": {"workload": f"whisper-{args.model} {dtype}, batch {B2}, 30 s synthetic clips resident in HBM, greedy decode "
+                                       f"{float(np.mean([len(r) for r in ids2])):.0f} ids/clip ({st2['steps'] / n2:.0f} decoder steps)"},
+                "stage_ms": {k: round(v / n2, 3) for k, v in st2.items() if k != "steps"},
+                "roofline": roofline_for(eng2, dims, args.model, B2, st2["steps"] / n2, st2["decode_ms"] / n2),
+                "stage_rooflines": stage_rooflines(eng2, dims, args.model, B2),
+                "clip0_ids_equal_batch1": ids2[0] == ids[0]}
+            eng2.close()
+        # ---- CPU baseline: the oracle ("port") on this box's host cores, one clip of the same workload
+        if rank == 0 and not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, dims, mdir, clips[0], ids[0], dec_steps)
+
     if use_dist:
         dist.destroy_process_group()
     sys.stdout.flush()
@@ -255,7 +471,18 @@ def main():
         os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)  # nothing in this process has imported torch or touched a GPU
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

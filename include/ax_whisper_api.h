@@ -99,7 +99,12 @@ AX_WHISPER_API int AX_WHISPER_DecodeForced(AX_WHISPER_HANDLE handle, int batch, 
 /** Greedy decode over the slots filled by EncodeMel (same loop as RunPCM*). */
 AX_WHISPER_API int AX_WHISPER_DecodeGreedy(AX_WHISPER_HANDLE handle, int batch, int max_new,
                                            int32_t* ids, int* n_ids);
-/** Stage timings of the last Run* call, ms (hipEvent): [0] front-end, [1] encoder,
+/** The same loop over a RAGGED batch: max_new_clip[b] (host, may be NULL; <= 0: none) caps the ids of clip b, so
+ *  clips leave the loop at different steps the way real utterances reach eot at different steps
+ *  (Whisper.cpp:219-222). A finished clip keeps its slot but no longer streams its K/V. */
+AX_WHISPER_API int AX_WHISPER_DecodeGreedyRagged(AX_WHISPER_HANDLE handle, int batch, int max_new,
+                                                 const int* max_new_clip, int32_t* ids, int* n_ids);
+/** Stage timings of the last Run* / DecodeGreedy* call, ms (hipEvent): [0] front-end, [1] encoder,
  *  [2] decode loop, [3] whole call (wall), [4] decode steps executed. */
 AX_WHISPER_API int AX_WHISPER_GetTimings(AX_WHISPER_HANDLE handle, float* out5);
 /** Time `iters` launches of one named piece on the handle's stream with hipEvents; returns

@@ -27,3 +27,41 @@ def test_bench_peaks_are_the_dense_figures():
 
     assert bench.HBM_PEAK_GBS == 8000.0       # MI355X_MICROARCH.md: HBM3E ~8 TB/s
     assert bench.MFMA_BF16_PEAK_TF == 2500.0  # dense bf16 (the 5 PF headline includes 2:1 sparsity)
+
+
+def _run_bench(extra_args, extra_env):
+    import json
+    import subprocess
+
+    env = dict(os.environ, AXW_BENCH_REHEARSAL="1", **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        if k not in extra_env:
+            env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra_args, capture_output=True, text=True,
+                       env=env, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, [json.loads(l) for l in lines], r.stderr
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus 2` (the driver's command shape) must run TWO ranks and gather both shards: the
+    rehearsal mode swaps the engine for a stand-in and RCCL for gloo, everything else is the code the GPU run uses."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "3"], {})
+    assert rc == 0, err
+    assert len(lines) == 1, "stdout must carry exactly ONE JSON line"
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 6 and j["config"]["parallelism"] == "dp2"
+    assert j["gathered_rows"] == 6 and j["scaling"] == "weak"
+    assert j["value"] is None and "REHEARSAL" in j["data"]  # a rehearsal can never be mistaken for a measurement
+
+
+def test_bench_default_batch_is_64_per_gpu_beyond_one_gpu():
+    import bench
+
+    a = bench.parse_args(["--gpus", "8"])
+    assert a.batch == 0  # resolved per rank: 1 at N=1 (configs[1]), 64/GPU at N>1 (configs[4]: 8 x 64 = 512)
+
+
+def test_bench_rejects_a_rank_count_that_differs_from_gpus():
+    rc, lines, err = _run_bench(["--gpus", "4"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and not lines and "--gpus 4" in err

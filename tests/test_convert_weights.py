@@ -84,3 +84,47 @@ def test_converter_through_gpu_matches_transformers(built_lib, tmp_path):
     print("GPU vs live transformers logits err", err)
     assert err < 5e-2
     e.close()
+
+
+def test_converter_refuses_to_invent_a_vocabulary(tmp_path):
+    """A real checkpoint converted without its vocabulary would transcribe garbage silently."""
+    import convert_weights
+
+    m = _hf_model()
+    w = convert_weights.hf_to_openai_names(m.state_dict())
+    with pytest.raises(ValueError, match="tiktoken"):
+        convert_weights.write_model(w, "hfmicro", str(tmp_path), tiktoken_path=None)
+    with pytest.raises(FileNotFoundError):
+        convert_weights.write_model(w, "hfmicro", str(tmp_path), tiktoken_path=str(tmp_path / "nope.tiktoken"))
+
+
+def test_converter_reads_sharded_hf_checkpoints(tmp_path):
+    import json
+
+    import convert_weights
+    import modelgen
+
+    m = _hf_model()
+    sd = {k: v.float().numpy() for k, v in m.state_dict().items()}
+    names = sorted(sd)
+    half = len(names) // 2
+    shards = {"model-00001-of-00002.safetensors": names[:half], "model-00002-of-00002.safetensors": names[half:]}
+    for fn, ks in shards.items():
+        modelgen.write_safetensors(str(tmp_path / fn), {k: sd[k] for k in ks}, dtype="F32")
+    json.dump({"weight_map": {k: fn for fn, ks in shards.items() for k in ks}}, open(tmp_path / "model.safetensors.index.json", "w"))
+    got = convert_weights.read_hf_checkpoint(str(tmp_path))
+    assert sorted(got) == names and all(np.array_equal(got[k], sd[k]) for k in names)
+    a = convert_weights.hf_to_openai_names(got)
+    b = convert_weights.hf_to_openai_names(m.state_dict())
+    assert all(np.array_equal(a[k], b[k]) for k in b)
+    with pytest.raises(FileNotFoundError):
+        convert_weights.read_hf_checkpoint(str(tmp_path / "empty"))
+
+
+def test_f16_safetensors_round_trip(tmp_path):
+    import modelgen
+
+    x = {"a": np.linspace(-3, 3, 77, dtype=np.float32).reshape(7, 11)}
+    modelgen.write_safetensors(str(tmp_path / "t.safetensors"), x, dtype="F16")
+    back = modelgen.read_safetensors(str(tmp_path / "t.safetensors"))
+    assert np.array_equal(back["a"], x["a"].astype(np.float16).astype(np.float32))

@@ -1,0 +1,184 @@
+"""GPU: the BASELINE.json configurations at their STATED workload (these were only builder-run before).
+
+  configs[2]  Whisper-small, batch 64, 30 s clips     -> test_config2_small_batch64
+  configs[3]  Whisper-turbo (d 1280, 32+4 layers, 128 mels), batch 16 -> test_config3_turbo_batch16
+  a14         exact logit ties: every decode path returns the LOWER index (Whisper.cpp:42-45)
+  a15         per-clip exit from the greedy loop (Whisper.cpp:219-222) at batch: a ragged batch
+
+The oracle side (bf16 policy) costs CPU-seconds per clip, so it checks 3 clips per configuration — first, one at a
+clip-block boundary, last — and every other clip is checked against the 1-clip path of the same engine."""
+import os
+
+import numpy as np
+import pytest
+import torch  # noqa: F401
+
+from conftest import ModelCase, assert_ids_equal_or_tie, load_demo_pcm
+
+pytestmark = pytest.mark.gpu
+
+
+def _clips(B, n_samp=480000):
+    import modelgen
+
+    return [modelgen.synth_clip(i, n_samp) for i in range(B)]
+
+
+def _batch_vs_single_and_oracle(e, case, oracle_mod, clips, n_new, oracle_clips, n_mels):
+    """ids of a B-clip greedy run: (1) oracle_clips vs the bf16-policy oracle, (2) EVERY clip vs the 1-clip path of the
+    same engine; a difference is accepted only as a numerical tie, measured on teacher-forced logits of both sides."""
+    B = len(clips)
+    got = e.run_tokens_batch(clips, max_new=n_new)
+    assert len(got) == B and all(len(g) == n_new for g in got)
+    mels = np.stack([e.compute_mel(c) for c in clips])
+    # (2) the 1-clip path (persistent launch), clip by clip
+    single = []
+    for b in range(B):
+        e.encode_mel(mels[b])
+        single.append(e.decode_greedy(1, max_new=n_new)[0])
+    e.encode_mel(mels)
+    forced = np.array(single, dtype=np.int32)
+    lg_b, am_b = e.decode_forced(B, forced)  # batched path, teacher-forced with the 1-clip path's ids
+    n_diff = 0
+    for b in range(B):
+        steps = [s for s in range(n_new) if am_b[b, s] != single[b][s]]
+        if not steps and got[b] == single[b]:
+            continue
+        n_diff += 1
+        e.encode_mel(mels[b])
+        lg_1, _ = e.decode_forced(1, forced[b:b + 1])
+        for s in steps:
+            err = float(np.abs(lg_b[b, s] - lg_1[0, s]).max())
+            srt = np.sort(lg_1[0, s])
+            assert srt[-1] - srt[-2] < 2 * err + 1e-4, ("clip", b, "step", s, srt[-1] - srt[-2], err)
+        if got[b] != single[b]:  # the greedy runs part ways exactly at a tied step
+            i = next(i for i in range(n_new) if got[b][i] != single[b][i])
+            assert i in steps, ("clip", b, "diverges at", i, "without a tie", steps)
+    print(f"B={B}: {B - n_diff}/{B} clips identical to the 1-clip path")
+    assert n_diff <= max(1, B // 16)
+    # (1) the oracle
+    for b in oracle_clips:
+        mel, _, _ = oracle_mod.log_mel(clips[b], n_mels)
+        ck, cv = case.oracle_bf16.encoder(mel)
+        ids, lg = case.oracle_bf16.greedy(ck, cv, "zh", max_new=n_new, want_logits=True)
+        agree = assert_ids_equal_or_tie(e, mel, got[b], ids, lg, f"clip {b} vs oracle", batch_mels=mels, slot=b)
+        print(f"B={B} clip {b}: {agree}/{len(ids)} ids equal to the bf16-policy oracle")
+    return got
+
+
+@pytest.fixture(scope="module")
+def small_case(tmp_path_factory, oracle_mod):
+    return ModelCase(tmp_path_factory.mktemp("models_small_cfg"), "small", 0)
+
+
+def test_config2_small_batch64(built_lib, oracle_mod, small_case):
+    B = 64
+    e = built_lib.Whisper("small", small_case.root, "zh", device=0, max_batch=B)
+    try:
+        _batch_vs_single_and_oracle(e, small_case, oracle_mod, _clips(B), 16, oracle_clips=(0, 16, 63), n_mels=80)
+    finally:
+        e.close()
+
+
+def test_ragged_batch_leaves_the_loop_clip_by_clip(built_lib, small_case):
+    """Clips end at 20 / 60 / 140 ids (per-clip budgets stand in for per-clip eot: synthetic weights never emit it):
+    ids of every clip equal the uniform run's prefix, and the step time drops once clips have left (their K/V is no
+    longer streamed) — the uniform run pays for 64 clips over all 144 steps."""
+    B = 64
+    e = built_lib.Whisper("small", small_case.root, "zh", device=0, max_batch=B)
+    try:
+        from make_model_goldens_inputs import demo_mel, synth_mel
+
+        mels = np.stack([demo_mel(80) if b % 5 == 0 else synth_mel(200 + b, 80, 3000 if b % 3 else 2000) for b in range(B)])
+        e.encode_mel(mels)
+        e.decode_greedy(B, max_new=140)  # captures the step graph: keep that out of the timed runs
+        uniform = e.decode_greedy(B, max_new=140)
+        t_uniform = e.timings()["decode_ms"]
+        budget = [20 if b % 3 == 0 else (60 if b % 3 == 1 else 140) for b in range(B)]
+        ragged = e.decode_greedy(B, max_new=140, max_new_clip=budget)
+        t_ragged = e.timings()["decode_ms"]
+        for b in range(B):
+            assert len(uniform[b]) == 140 and ragged[b] == uniform[b][: budget[b]], b
+        print(f"decode of 64 clips: uniform 140 ids {t_uniform:.1f} ms, ragged 20/60/140 ids {t_ragged:.1f} ms")
+        # K/V bytes of the ragged run = (22*24 + 21*64 + 21*144) / (64*144) = 0.53 of the uniform run's; linear layers unchanged
+        assert t_ragged < 0.85 * t_uniform
+        # a clip whose budget is spent at once, beside clips that run on; and budgets above max_new are capped by it
+        again = e.decode_greedy(B, max_new=30, max_new_clip=[1 if b == 7 else 400 for b in range(B)])
+        assert again[7] == uniform[7][:1] and all(again[b] == uniform[b][:30] for b in range(B) if b != 7)
+    finally:
+        e.close()
+
+
+def test_config3_turbo_batch16(built_lib, oracle_mod, tmp_path_factory):
+    """Full-size large-v3-turbo dims (d 1280, 20 heads, 32 encoder + 4 decoder layers, 128 mels, 51866 ids, 100
+    languages), batch 16; dtype as DESIGN.md §2 states for configs[3]."""
+    case = ModelCase(tmp_path_factory.mktemp("models_turbo_cfg"), "turbo", 3)
+    B = 16
+    e = built_lib.Whisper("turbo", case.root, "zh", device=0, max_batch=B)
+    try:
+        assert (e.n_mels, e.n_vocab, e.n_text_state, e.n_text_layer) == (128, 51866, 1280, 4)
+        _batch_vs_single_and_oracle(e, case, oracle_mod, _clips(B), 12, oracle_clips=(0, 15), n_mels=128)
+    finally:
+        e.close()
+
+
+# ------------------------------------------------------------------------------------------------ exact ties (a14)
+def _tied_model(tmp_path, base_case, src_row, dup_rows, name):
+    """A copy of the micro model whose embedding rows dup_rows are bit-copies of row src_row: with the tied output
+    projection (logits = token_embedding . ln(x), export_onnx.py:364-385) those logits are bit-equal at every step."""
+    import modelgen
+
+    w = dict(base_case.weights)
+    emb = w["decoder.token_embedding.weight"].copy()
+    for r in dup_rows:
+        emb[r] = emb[src_row]
+    w["decoder.token_embedding.weight"] = emb
+    root = str(tmp_path / name)
+    modelgen.write_model_dir(root, "micro", base_case.dims, weights=w)
+    return root, w
+
+
+@pytest.mark.parametrize("mode,batch", [("persistent", 1), ("graph", 1), ("gemv", 3), ("mfma", 6), ("mfma", 20)])
+def test_exact_logit_tie_returns_the_lower_index(built_lib, oracle_mod, micro_case, tmp_path, monkeypatch, mode, batch):
+    """std::max_element (Whisper.cpp:42-45) returns the FIRST maximum. Three different argmax merges exist here (per
+    workgroup partials + advance_kernel; the register-resident vocabulary projection; the persistent launch's in-kernel
+    merge): each must return the lowest index among bit-equal maxima, wherever the tied rows fall — the same 16-row
+    block, neighbouring blocks, different workgroups, below and above the original winner."""
+    import oracle
+
+    if mode == "graph":
+        monkeypatch.setenv("AX_WHISPER_DECODE", "graph")
+    mel = oracle.log_mel(load_demo_pcm(), 80)[0]
+    ck, cv = micro_case.oracle_bf16.encoder(mel)
+    base_ids = micro_case.oracle_bf16.greedy(ck, cv, "zh", max_new=3)
+    win = base_ids[0]
+    assert 2000 < win < 49000
+    variants = {
+        "same_block_above": [win + 1],
+        "next_block_above": [win + 16, win + 17],
+        "far_above": [win + 9000],
+        "just_below": [win - 1],
+        "far_below_and_above": [win - 1999, win + 3000],
+    }
+    mels = np.stack([mel] * batch)
+    for name, dups in variants.items():
+        root, w = _tied_model(tmp_path, micro_case, win, dups, f"{mode}{batch}_{name}")
+        want_first = min([win] + dups)
+        orc = oracle.Oracle(micro_case.cfg, w, bf16_policy=True)
+        ok, ov = orc.encoder(mel)
+        ref = orc.greedy(ok, ov, "zh", max_new=4)
+        assert ref[0] == want_first  # the oracle's argmax is first-max-wins too (orc_argmax)
+        e = built_lib.Whisper("micro", root, "zh", device=0, max_batch=batch)
+        try:
+            assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_decode") == (1 if mode == "persistent" else 0) or batch > 1
+            e.encode_mel(mels)
+            got = e.decode_greedy(batch, max_new=4)
+            lg, am = e.decode_forced(batch, np.array([ref] * batch, dtype=np.int32))
+            for b in range(batch):
+                tied = lg[b, 0, [win] + dups]
+                assert np.all(tied == tied[0]), (name, b, tied)  # bit-equal logits
+                assert lg[b, 0].max() == tied[0]                 # ... and they are the maximum
+                assert am[b, 0] == want_first, (name, b, am[b, 0], want_first)
+                assert got[b][0] == want_first, (name, b, got[b], ref)
+        finally:
+            e.close()

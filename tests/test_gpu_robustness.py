@@ -131,3 +131,56 @@ def test_wav_ingest_formats(built_lib, micro_case, tmp_path):
     _write_wav(p, st, fmt="int16")
     assert e.run(p) == e.run(mono)
     e.close()
+
+
+@pytest.mark.parametrize("batch", [1, 3, 6])
+def test_non_finite_and_huge_audio_never_faults(built_lib, micro_case, batch):
+    """an all-NaN logits row left the argmax at its 'no candidate' index, which was then fed back as a token
+    and indexed the embedding table far out of bounds. Batch 1 = the persistent launch, 3 = the VALU GEMV path,
+    6 = the MFMA path. NaN / Inf samples are refused at the ABI (-1); a finite 1e20-amplitude tone overflows the power
+    spectrum on the device and must decode to SOMETHING (ids inside the vocabulary), not fault."""
+    e = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=batch)
+    n = 48000
+    t = np.arange(n, dtype=np.float32) / 16000
+    good = load_demo_pcm()[:n]
+    want_good = e.run_tokens(good, max_new=6)
+    for bad_value in (np.nan, np.inf, -np.inf):
+        bad = good.copy()
+        bad[1234] = bad_value
+        clips = [bad if b == batch - 1 else good for b in range(batch)]
+        with pytest.raises(RuntimeError, match="non-finite"):
+            e.run_tokens_batch(clips, max_new=6)
+    huge = (1e20 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    clips = [huge if b == batch - 1 else good for b in range(batch)]
+    out = e.run_tokens_batch(clips, max_new=6)
+    assert all(0 <= i < e.n_vocab for row in out for i in row)
+    for b in range(batch - 1):
+        assert out[b] == want_good  # the poisoned clip does not leak into its neighbours
+    # device-resident PCM bypasses the host check: NaN audio must still decode without a fault (an all-NaN logits row
+    # gives id 0, what std::max_element returns, Whisper.cpp:42-45)
+    nanclip = np.full(n, np.nan, dtype=np.float32)
+    d = torch.from_numpy(np.stack([nanclip if b == batch - 1 else good for b in range(batch)])).cuda()
+    out = e.run_device_tokens(d.data_ptr(), n, [n] * batch, max_new=6)
+    assert all(0 <= i < e.n_vocab for i in out[batch - 1])
+    for b in range(batch - 1):
+        assert out[b] == want_good
+    # the handle is still healthy
+    assert e.run_tokens(good, max_new=6) == want_good
+    e.close()
+
+
+def test_failed_inits_do_not_leak_device_memory(built_lib, micro_case, tmp_path):
+    """A constructor that throws half way (weights uploaded, then a bad tensor) must free what it allocated."""
+    import modelgen
+
+    w = dict(micro_case.weights)
+    w["decoder.ln.bias"] = np.ones(64, dtype=np.float32)  # loaded last: everything before it is already on the device
+    modelgen.write_model_dir(str(tmp_path), "micro", micro_case.dims, weights=w)
+    L = built_lib.load_library()
+    assert L.AX_WHISPER_Init(b"micro", str(tmp_path).encode(), b"zh") is None
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(6):
+        assert L.AX_WHISPER_Init(b"micro", str(tmp_path).encode(), b"zh") is None
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 16 << 20, (free0, free1)

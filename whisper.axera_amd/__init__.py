@@ -46,6 +46,7 @@ SYMBOLS = {
     "AX_WHISPER_GetCrossKV": (C.c_int, [C.c_void_p, C.c_int, fp, fp]),
     "AX_WHISPER_DecodeForced": (C.c_int, [C.c_void_p, C.c_int, ip, C.c_int, fp, ip]),
     "AX_WHISPER_DecodeGreedy": (C.c_int, [C.c_void_p, C.c_int, C.c_int, ip, C.POINTER(C.c_int)]),
+    "AX_WHISPER_DecodeGreedyRagged": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), ip, C.POINTER(C.c_int)]),
     "AX_WHISPER_GetTimings": (C.c_int, [C.c_void_p, fp]),
     "AX_WHISPER_Bench": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, fp]),
 }
@@ -207,10 +208,14 @@ class Whisper:
                                                    logits.ctypes.data_as(fp) if want_logits else None, am.ctypes.data_as(ip)), "DecodeForced")
         return logits, am
 
-    def decode_greedy(self, batch: int, max_new: int = 0):
+    def decode_greedy(self, batch: int, max_new: int = 0, max_new_clip=None):
         ids = np.zeros((batch, self.n_text_ctx), dtype=np.int32)
         n = (C.c_int * batch)()
-        self._check(self.L.AX_WHISPER_DecodeGreedy(self.h, batch, max_new, ids.ctypes.data_as(ip), n), "DecodeGreedy")
+        if max_new_clip is None:
+            self._check(self.L.AX_WHISPER_DecodeGreedy(self.h, batch, max_new, ids.ctypes.data_as(ip), n), "DecodeGreedy")
+        else:
+            mc = (C.c_int * batch)(*[int(x) for x in max_new_clip])
+            self._check(self.L.AX_WHISPER_DecodeGreedyRagged(self.h, batch, max_new, mc, ids.ctypes.data_as(ip), n), "DecodeGreedyRagged")
         return [ids[b, : n[b]].tolist() for b in range(batch)]
 
     def timings(self):

@@ -198,8 +198,13 @@ AX_WHISPER_API int AX_WHISPER_DecodeForced(AX_WHISPER_HANDLE handle, int batch, 
 }
 
 AX_WHISPER_API int AX_WHISPER_DecodeGreedy(AX_WHISPER_HANDLE handle, int batch, int max_new, int32_t* ids, int* n_ids) {
+  return AX_WHISPER_DecodeGreedyRagged(handle, batch, max_new, nullptr, ids, n_ids);
+}
+
+AX_WHISPER_API int AX_WHISPER_DecodeGreedyRagged(AX_WHISPER_HANDLE handle, int batch, int max_new, const int* max_new_clip,
+                                                 int32_t* ids, int* n_ids) {
   if (!handle || !ids || !n_ids) return -1;
-  return guarded(handle, [&](Engine& e) { e.decode_greedy(batch, max_new, ids, n_ids); });
+  return guarded(handle, [&](Engine& e) { e.decode_greedy(batch, max_new, max_new_clip, ids, n_ids); });
 }
 
 AX_WHISPER_API int AX_WHISPER_GetTimings(AX_WHISPER_HANDLE handle, float* out5) {

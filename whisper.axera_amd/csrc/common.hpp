@@ -191,6 +191,7 @@ struct DecAttnParams {
   int n_keys;                 // fixed key count (cross) or -1: state->step + 1 (self)
   int cap_blocks;             // allocated 64-key blocks per (slot, head): 24 cross, 7 self
   const DecState* state;
+  const int* done;            // optional device [B]: clips whose flag is set are skipped (greedy loop past their eot)
   bf16* out_hi; bf16* out_lo; int nbs; // n_split == 1 only: normalised output as a fragment-major bf16 pair instead of partials
   // fused query projection (batched cross-attention): q = Wq[head rows] . LayerNorm(x[b]) + bq computed by the
   // (clip, head) workgroup itself while its first K/V block is in flight; wq == nullptr: q is read from `q`
@@ -244,7 +245,8 @@ void launch_pack_weight_frag(const bf16* w, bf16* wp, int N, int K, hipStream_t 
 struct AdvanceParams {
   const float* amax_val; const int* amax_idx; int n_part; int amax_stride;
   DecState* state; int* tok; int* done; int* n_out; int* out_ids; int batch;
-  int n_ctx, eot, max_new;
+  int n_ctx, eot, max_new, n_vocab;
+  const int* max_new_clip;    // optional device [B]: per-clip id budget (a ragged batch), capped by max_new
   const int* sot;             // device [4]
   const int* forced; int n_forced;   // teacher forcing (device [B][n_forced]) or nullptr
   int* argmax_dump;           // optional [B][n_forced+1]

@@ -507,13 +507,17 @@ __global__ __launch_bounds__(1024) void advance_kernel(AdvanceParams p) {
         const int oi = __shfl_xor(idx, o, 64);
         if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
       }
+      // no logit compared greater than -inf (all NaN / -inf: non-finite audio): std::max_element returns index 0
+      // (Whisper.cpp:42-45); never let the "no candidate" index reach the embedding lookup below
+      if ((unsigned)idx >= (unsigned)p.n_vocab) idx = 0;
       tok = p.tok[b];
       const int gi = s - 3;
       if (p.forced) {
         if (gi < p.n_forced) tok = p.forced[(long)b * p.n_forced + gi];
       } else if (!p.done[b]) {
         const int n_out = p.n_out[b];
-        if (idx == p.eot || s + 1 >= p.n_ctx || n_out >= p.max_new) {
+        const int max_new = p.max_new_clip ? min(p.max_new_clip[b], p.max_new) : p.max_new;
+        if (idx == p.eot || s + 1 >= p.n_ctx || n_out >= max_new) {
           if (lane == 0) { p.done[b] = 1; atomicAdd(&p.state->n_done, 1); }
         } else {
           if (lane == 0) { p.out_ids[(long)b * p.n_ctx + n_out] = idx; p.n_out[b] = n_out + 1; }

@@ -635,6 +635,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
       int best_idx = am_i[0];
       for (int w2 = 1; w2 < NPW; ++w2)
         if (am_v[w2] > cv || (am_v[w2] == cv && am_i[w2] < best_idx)) { cv = am_v[w2]; best_idx = am_i[w2]; }
+      // no logit compared greater than -inf (all NaN / -inf: non-finite audio): std::max_element returns index 0
+      // (Whisper.cpp:42-45); never let the "no candidate" index reach the embedding lookup
+      if ((unsigned)best_idx >= (unsigned)p.n_vocab) best_idx = 0;
       wg_barrier();  // B5: am_v/am_i are free again
       const int gi = step - 3;
       if (p.forced) {
@@ -946,6 +949,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
       int best_idx = am_i[0];
       for (int w2 = 1; w2 < NPW; ++w2)
         if (am_v[w2] > cv || (am_v[w2] == cv && am_i[w2] < best_idx)) { cv = am_v[w2]; best_idx = am_i[w2]; }
+      if ((unsigned)best_idx >= (unsigned)p.n_vocab) best_idx = 0;  // as in the pollers' copy of this merge
       wg_barrier();  // B5
       const int gi = step - 3;
       if (p.forced) {

@@ -56,6 +56,10 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
   __shared__ float s_part[4][kPartStride];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int split = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  // A clip that has reached its eot keeps its slot in the batch but streams no K/V any more (the reference stops each
+  // utterance at its own eot, Whisper.cpp:219-222). Its stale attention output feeds linear layers whose results
+  // nobody reads: rows of different clips never mix, and advance_kernel re-seeds x[b] from the embedding every step.
+  if (p.done && p.done[b]) return;
   const int bps = (cap_blocks + p.n_split - 1) / p.n_split;
   const int blk_begin = split * bps, blk_cap_end = min(cap_blocks, blk_begin + bps);
 

@@ -36,6 +36,18 @@ static int dtype_code(const std::string& d) { return d == "F32" ? 0 : d == "BF16
 // ------------------------------------------------------------------------------ construction
 Engine::Engine(const std::string& model_type, const std::string& model_path, const std::string& language, int device,
                int max_batch) {
+  try {
+    construct(model_type, model_path, language, device, max_batch);
+  } catch (...) {
+    // the destructor of a partially constructed object never runs: a failed Init (missing / corrupt weights, shape
+    // mismatch, out of memory) must give back the stream, the events, the pinned buffers and every weight already uploaded
+    destroy();
+    throw;
+  }
+}
+
+void Engine::construct(const std::string& model_type, const std::string& model_path, const std::string& language, int device,
+                       int max_batch) {
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
     throw std::runtime_error("no HIP device visible: the MI355X engine has no CPU fallback");
@@ -46,6 +58,7 @@ Engine::Engine(const std::string& model_type, const std::string& model_path, con
   if (device >= n_dev) throw std::runtime_error("HIP device ordinal out of range");
   device_ = device;
   HIP_CHECK(hipSetDevice(device_));
+  device_set_ = true;
   HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   for (auto& e : ev_) HIP_CHECK(hipEventCreate(&e));
 
@@ -87,14 +100,19 @@ Engine::Engine(const std::string& model_type, const std::string& model_path, con
   HIP_CHECK(hipStreamSynchronize(own_stream_));
 }
 
-Engine::~Engine() {
+Engine::~Engine() { destroy(); }
+
+void Engine::destroy() {
+  if (!device_set_) return;  // nothing was created
   (void)hipSetDevice(device_);
   (void)hipDeviceSynchronize();
   free_slot_buffers();  // also destroys the captured step graphs
   for (void* p : allocs_) (void)hipFree(p);
-  if (h_poll_) (void)hipHostFree(h_poll_);
-  for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
-  if (own_stream_) (void)hipStreamDestroy(own_stream_);
+  allocs_.clear();
+  if (load_stage_) { (void)hipFree(load_stage_); load_stage_ = nullptr; }
+  if (h_poll_) { (void)hipHostFree(h_poll_); h_poll_ = nullptr; }
+  for (auto& e : ev_) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  if (own_stream_) { (void)hipStreamDestroy(own_stream_); own_stream_ = nullptr; }
 }
 
 void* Engine::dalloc(size_t bytes, bool zero) {
@@ -103,8 +121,12 @@ void* Engine::dalloc(size_t bytes, bool zero) {
   if (zero) {
     // the engine's streams are non-blocking (not ordered against the null stream): finish the fill before any
     // kernel on them can touch the buffer
-    HIP_CHECK(hipMemset(p, 0, std::max<size_t>(bytes, 256)));
-    HIP_CHECK(hipDeviceSynchronize());
+    hipError_t e = hipMemset(p, 0, std::max<size_t>(bytes, 256));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+      (void)hipFree(p);
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " zero-filling a device buffer");
+    }
   }
   return p;
 }
@@ -191,7 +213,8 @@ void Engine::load_weights(const std::string& path) {
   note("decoder.token_embedding.weight");
   note("encoder.conv2.weight");
   note("encoder.blocks.0.mlp.0.weight");
-  void* stage = dalloc(max_bytes);
+  load_stage_ = dalloc(max_bytes);  // a member: freed by destroy() when a later tensor throws
+  void* const stage = load_stage_;
 
   auto check = [&](const std::string& n, std::vector<int64_t> shape) -> const TensorView& {
     const TensorView& t = st.get(n);
@@ -364,6 +387,7 @@ void Engine::load_weights(const std::string& path) {
   tok_emb_packed_ = pack(tok_emb_, cfg_.n_vocab, d);
   HIP_CHECK(hipStreamSynchronize(s));
   HIP_CHECK(hipFree(stage));
+  load_stage_ = nullptr;
 
   // front-end constants: DFT twiddles (double -> f32), periodic Hann (librosa.h:81), mel basis
   std::vector<float> tw(2 * kNFFT), win(kNFFT);
@@ -443,6 +467,7 @@ void Engine::ensure_capacity(int batch) {
   d_tok_ = (int*)A((size_t)B * 4, true);
   d_done_ = (int*)A((size_t)B * 4, true);
   d_nout_ = (int*)A((size_t)B * 4, true);
+  d_max_new_clip_ = (int*)A((size_t)B * 4, true);
   d_out_ids_ = (int*)A((size_t)B * Tc * 4, true);
   d_state_ = (DecState*)A(sizeof(DecState), true);
   cap_ = B;
@@ -452,7 +477,19 @@ void Engine::ensure_capacity(int batch) {
 void Engine::upload_pcm(const float* const* pcm, const int* n_samples, int batch) {
   for (int b = 0; b < batch; ++b) {
     const int n = (int)std::min<long>(n_samples[b], pcm_stride_);
-    memcpy(h_pcm_ + (size_t)b * pcm_stride_, pcm[b], (size_t)n * 4);  // pcm_data is copied, not retained (api.cpp:151-152)
+    // pcm_data is copied, not retained (api.cpp:151-152). The ABI asks for samples in [-1, 1] (ax_whisper_api.h:89 of the
+    // reference); NaN / Inf samples turn every mel value, hence every logit, into NaN: refuse them here (-1 at the ABI)
+    // instead of decoding garbage. Finite out-of-range samples pass through as they do in the reference.
+    float* dst = h_pcm_ + (size_t)b * pcm_stride_;
+    const float* src = pcm[b];
+    unsigned bad = 0;
+    for (int i = 0; i < n; ++i) {
+      uint32_t u;
+      memcpy(&u, src + i, 4);
+      bad |= ((u & 0x7f800000u) == 0x7f800000u);
+      memcpy(dst + i, &u, 4);
+    }
+    if (bad) throw std::runtime_error("clip " + std::to_string(b) + ": non-finite PCM sample (NaN or Inf)");
     HIP_CHECK(hipMemcpyAsync(d_pcm_ + (size_t)b * pcm_stride_, h_pcm_ + (size_t)b * pcm_stride_, (size_t)n * 4,
                              hipMemcpyHostToDevice, stream()));
   }
@@ -532,8 +569,15 @@ void Engine::run_encoder(int batch) {
 }
 
 // ------------------------------------------------------------------------------ decoder
-void Engine::reset_decode_state(int batch) {
+void Engine::reset_decode_state(int batch, const int* max_new_clip) {
   hipStream_t s = stream();
+  {  // per-clip id budgets (a ragged batch); without them every clip gets the whole context
+    std::vector<int> mn(batch, cfg_.n_text_ctx);
+    if (max_new_clip)
+      for (int b = 0; b < batch; ++b) mn[b] = max_new_clip[b] > 0 ? max_new_clip[b] : cfg_.n_text_ctx;
+    HIP_CHECK(hipMemcpyAsync(d_max_new_clip_, mn.data(), (size_t)batch * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));  // mn is a stack vector
+  }
   HIP_CHECK(hipMemsetAsync(d_state_, 0, sizeof(DecState), s));
   HIP_CHECK(hipMemsetAsync(d_done_, 0, (size_t)batch * 4, s));
   HIP_CHECK(hipMemsetAsync(d_nout_, 0, (size_t)batch * 4, s));
@@ -567,6 +611,7 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
     DecAttnParams a{};
     a.q = d_qdec_; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = part; a.n_split = n_split;
     a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
+    a.done = d_forced ? nullptr : d_done_;
     if (step_mask_ & 2) launch_decode_attention(a, s);
   };
 
@@ -628,7 +673,7 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
   AdvanceParams a{};
   a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = gemv_grid(p); a.amax_stride = n_amax_part_;
   a.state = d_state_; a.tok = d_tok_; a.done = d_done_; a.n_out = d_nout_; a.out_ids = d_out_ids_; a.batch = batch;
-  a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.sot = d_sot_;
+  a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.n_vocab = cfg_.n_vocab; a.max_new_clip = d_max_new_clip_; a.sot = d_sot_;
   a.forced = d_forced; a.n_forced = n_forced; a.argmax_dump = d_argmax;
   a.tok_emb = tok_emb_; a.pos = dec_pos_; a.x = d_xdec_; a.d_model = d;
   if (step_mask_ & 4) launch_advance(a, s);
@@ -679,6 +724,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     DecAttnParams a{};
     a.q = d_qdec_; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = nullptr; a.n_split = 1;
     a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
+    a.done = d_forced ? nullptr : d_done_;
     a.out_hi = d_att_[0]; a.out_lo = d_att_[1]; a.nbs = nbs_;
     if (step_mask_ & 2) launch_decode_attention(a, s);
   };
@@ -724,6 +770,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
         DecAttnParams a{};
         a.k = ck; a.v = cv; a.kv_batch_stride = cross_stride; a.part = nullptr; a.n_split = 1;
         a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = cfg_.n_audio_ctx; a.cap_blocks = t_pad_ / 64; a.state = d_state_;
+        a.done = d_forced ? nullptr : d_done_;
         a.out_hi = d_att_[0]; a.out_lo = d_att_[1]; a.nbs = nbs_;
         a.x = d_xdec_; a.ln_w = w.cross_ln_w; a.ln_b = w.cross_ln_b; a.wq = w.w_cq; a.bq = w.b_cq;
         if (step_mask_ & 2) launch_decode_attention(a, s);
@@ -777,7 +824,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
   AdvanceParams a{};
   a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = decode_gemm_grid(cfg_.n_vocab, vocab_rt); a.amax_stride = n_amax_part_;
   a.state = d_state_; a.tok = d_tok_; a.done = d_done_; a.n_out = d_nout_; a.out_ids = d_out_ids_; a.batch = batch;
-  a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.sot = d_sot_;
+  a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.n_vocab = cfg_.n_vocab; a.max_new_clip = d_max_new_clip_; a.sot = d_sot_;
   a.forced = d_forced; a.n_forced = n_forced; a.argmax_dump = d_argmax;
   a.tok_emb = tok_emb_; a.pos = dec_pos_; a.x = d_xdec_; a.d_model = d;
   if (step_mask_ & 4) launch_advance(a, s);
@@ -805,9 +852,10 @@ hipGraphExec_t Engine::step_graph(int batch, int max_new) {
 }
 
 // Whisper.cpp:207-222. Returns the number of decoder steps executed.
-int Engine::greedy_loop(int batch, int max_new) {
+int Engine::greedy_loop(int batch, int max_new, const int* max_new_clip) {
   const int Tc = cfg_.n_text_ctx;
   if (max_new <= 0 || max_new > Tc - 4) max_new = Tc - 4;
+  if (batch == 1 && max_new_clip && max_new_clip[0] > 0) max_new = std::min(max_new, max_new_clip[0]);
   if (batch == 1 && persistent_ok_) {
     const int steps = run_persistent(max_new, nullptr, 0, nullptr, nullptr);
     if (steps >= 0) return steps;
@@ -815,7 +863,7 @@ int Engine::greedy_loop(int batch, int max_new) {
     persistent_ok_ = false;
     cfg_.ints["persistent_decode"] = 0;
   }
-  reset_decode_state(batch);
+  reset_decode_state(batch, max_new_clip);
   hipGraphExec_t g = step_graph(batch, max_new);
   hipStream_t s = stream();
   const int total = std::min(Tc, 4 + max_new);
@@ -1037,11 +1085,19 @@ void Engine::decode_forced(int batch, const int32_t* forced, int n_forced, float
   if (d_logits) (void)hipFree(d_logits);
 }
 
-void Engine::decode_greedy(int batch, int max_new, int32_t* ids, int* n_ids) {
+void Engine::decode_greedy(int batch, int max_new, const int* max_new_clip, int32_t* ids, int* n_ids) {
   HIP_CHECK(hipSetDevice(device_));
   if (batch < 1 || batch > cap_) throw std::runtime_error("decode_greedy: batch exceeds the encoded slots");
-  greedy_loop(batch, max_new);
+  hipStream_t s = stream();
+  HIP_CHECK(hipEventRecord(ev_[2], s));
+  const int steps = greedy_loop(batch, max_new, max_new_clip);
   fetch_ids(batch, ids, n_ids);
+  HIP_CHECK(hipEventRecord(ev_[3], s));
+  HIP_CHECK(hipEventSynchronize(ev_[3]));
+  timings[0] = timings[1] = 0.f;
+  (void)hipEventElapsedTime(&timings[2], ev_[2], ev_[3]);
+  timings[3] = timings[2];
+  timings[4] = (float)steps;
 }
 
 float Engine::bench(const std::string& what, int batch, int arg, int iters) {

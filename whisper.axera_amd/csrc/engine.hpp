@@ -46,7 +46,8 @@ class Engine {
   void encode_mel(const float* mel, int batch);
   void get_cross_kv(int slot, float* k_out, float* v_out);
   void decode_forced(int batch, const int32_t* forced, int n_forced, float* logits, int32_t* argmax_ids);
-  void decode_greedy(int batch, int max_new, int32_t* ids, int* n_ids);
+  // max_new_clip: optional host [batch] per-clip id budgets (<= 0: none), each capped by max_new
+  void decode_greedy(int batch, int max_new, const int* max_new_clip, int32_t* ids, int* n_ids);
   float bench(const std::string& what, int batch, int arg, int iters);
 
   void set_stream(hipStream_t s) { user_stream_ = s; }
@@ -62,6 +63,8 @@ class Engine {
     float *b_qkv, *b_o, *b_fc1, *b_fc2;
   };
 
+  void construct(const std::string& model_type, const std::string& model_path, const std::string& language, int device, int max_batch);
+  void destroy();  // idempotent: the destructor's work, also run when the constructor throws
   hipStream_t stream() const { return user_stream_ ? user_stream_ : own_stream_; }
   void* dalloc(size_t bytes, bool zero = false);
   void load_config(const std::string& dir, const std::string& type, const std::string& language);
@@ -72,13 +75,13 @@ class Engine {
   void upload_pcm(const float* const* pcm, const int* n_samples, int batch);
   void run_frontend(const float* d_pcm, int stride, const int* n_samples, int batch, bool want_ref_layout);
   void run_encoder(int batch);
-  void reset_decode_state(int batch);
+  void reset_decode_state(int batch, const int* max_new_clip = nullptr);
   void enqueue_decode_step(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits, long logits_stride,
                            int* d_argmax);
   void enqueue_decode_step_batched(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits,
                                    long logits_stride, int* d_argmax);
   hipGraphExec_t step_graph(int batch, int max_new);
-  int greedy_loop(int batch, int max_new);
+  int greedy_loop(int batch, int max_new, const int* max_new_clip = nullptr);
   // batch 1: the whole loop as one persistent launch (decode_persistent.hip); returns steps run, -1 if it gave up
   int run_persistent(int max_new, const int* d_forced, int n_forced, float* d_logits, int* d_argmax);
   void fetch_ids(int batch, int32_t* ids, int* n_ids);
@@ -90,6 +93,8 @@ class Engine {
   std::string effective_lang_;
   std::mutex mu_;
   int device_ = 0;
+  bool device_set_ = false;
+  void* load_stage_ = nullptr;  // staging buffer of load_weights
   hipStream_t own_stream_ = nullptr, user_stream_ = nullptr;
   std::vector<void*> allocs_;       // weights + constants (freed at destruction)
   std::vector<void*> slot_allocs_;  // capacity-dependent buffers
@@ -123,7 +128,7 @@ class Engine {
   bf16 *d_act_[2] = {nullptr, nullptr}, *d_att_[2] = {nullptr, nullptr}, *d_hidp_[2] = {nullptr, nullptr};
   float* d_part_ = nullptr;
   float* d_amax_val_ = nullptr; int* d_amax_idx_ = nullptr; int n_amax_part_ = 0;
-  int *d_tok_ = nullptr, *d_done_ = nullptr, *d_nout_ = nullptr, *d_out_ids_ = nullptr;
+  int *d_tok_ = nullptr, *d_done_ = nullptr, *d_nout_ = nullptr, *d_out_ids_ = nullptr, *d_max_new_clip_ = nullptr;
   DecState* d_state_ = nullptr;
   int* h_poll_ = nullptr;  // pinned
   int split_self_ = 2, split_cross_ = 6;

@@ -161,33 +161,14 @@ struct TensorView {
 class SafeTensors {
  public:
   explicit SafeTensors(const std::string& path) {
-    fd_ = open(path.c_str(), O_RDONLY);
-    if (fd_ < 0) throw std::runtime_error("cannot open weights file " + path);
-    struct stat st; fstat(fd_, &st); size_ = (size_t)st.st_size;
-    base_ = (const uint8_t*)mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
-    if (base_ == MAP_FAILED) { close(fd_); throw std::runtime_error("mmap failed for " + path); }
-    if (size_ < 8) throw std::runtime_error("weights file too small");
-    uint64_t hl; memcpy(&hl, base_, 8);
-    if (8 + hl > size_) throw std::runtime_error("bad safetensors header length");
-    std::string hdr((const char*)base_ + 8, (size_t)hl);
-    JsonValue j = JsonParser(hdr).parse();
-    const uint8_t* data0 = base_ + 8 + hl;
-    for (auto& kv : j.obj) {
-      if (kv.first == "__metadata__") continue;
-      TensorView t;
-      t.dtype = kv.second.at("dtype").as_str();
-      for (auto& d : kv.second.at("shape").arr) t.shape.push_back(d.as_int());
-      auto& off = kv.second.at("data_offsets").arr;
-      size_t s = (size_t)off.at(0).as_int(), e = (size_t)off.at(1).as_int();
-      if (e < s || 8 + hl + e > size_) throw std::runtime_error("tensor '" + kv.first + "' out of file bounds");
-      t.data = data0 + s; t.nbytes = e - s;
-      size_t es = t.dtype == "F32" ? 4 : (t.dtype == "BF16" || t.dtype == "F16") ? 2 : 0;
-      if (!es) throw std::runtime_error("tensor '" + kv.first + "': unsupported dtype " + t.dtype);
-      if ((size_t)t.numel() * es != t.nbytes) throw std::runtime_error("tensor '" + kv.first + "': size mismatch");
-      tensors_[kv.first] = t;
+    try {
+      parse(path);
+    } catch (...) {
+      release();  // a throwing constructor never runs the destructor: give the mapping and the descriptor back here
+      throw;
     }
   }
-  ~SafeTensors() { if (base_ && base_ != MAP_FAILED) munmap((void*)base_, size_); if (fd_ >= 0) close(fd_); }
+  ~SafeTensors() { release(); }
   SafeTensors(const SafeTensors&) = delete;
   bool has(const std::string& n) const { return tensors_.count(n) != 0; }
   const TensorView& get(const std::string& n) const {
@@ -197,6 +178,46 @@ class SafeTensors {
   }
 
  private:
+  void release() {
+    if (base_ && base_ != MAP_FAILED) munmap((void*)base_, size_);
+    base_ = nullptr;
+    if (fd_ >= 0) close(fd_);
+    fd_ = -1;
+  }
+  void parse(const std::string& path) {
+    fd_ = open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) throw std::runtime_error("cannot open weights file " + path);
+    struct stat st;
+    if (fstat(fd_, &st) != 0) throw std::runtime_error("cannot stat weights file " + path);
+    size_ = (size_t)st.st_size;
+    if (size_ < 8) throw std::runtime_error("weights file too small");
+    base_ = (const uint8_t*)mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+    if (base_ == MAP_FAILED) { base_ = nullptr; throw std::runtime_error("mmap failed for " + path); }
+    uint64_t hl; memcpy(&hl, base_, 8);
+    if (hl > size_ - 8) throw std::runtime_error("bad safetensors header length");  // no 8 + hl: it can wrap
+    std::string hdr((const char*)base_ + 8, (size_t)hl);
+    JsonValue j = JsonParser(hdr).parse();
+    const uint8_t* data0 = base_ + 8 + hl;
+    const size_t data_bytes = size_ - 8 - (size_t)hl;
+    for (auto& kv : j.obj) {
+      if (kv.first == "__metadata__") continue;
+      TensorView t;
+      t.dtype = kv.second.at("dtype").as_str();
+      for (auto& d : kv.second.at("shape").arr) {
+        if (d.as_int() < 0) throw std::runtime_error("tensor '" + kv.first + "': negative dimension");
+        t.shape.push_back(d.as_int());
+      }
+      auto& off = kv.second.at("data_offsets").arr;
+      if (off.at(0).as_int() < 0 || off.at(1).as_int() < 0) throw std::runtime_error("tensor '" + kv.first + "': negative offset");
+      size_t s = (size_t)off.at(0).as_int(), e = (size_t)off.at(1).as_int();
+      if (e < s || e > data_bytes) throw std::runtime_error("tensor '" + kv.first + "' out of file bounds");
+      t.data = data0 + s; t.nbytes = e - s;
+      size_t es = t.dtype == "F32" ? 4 : (t.dtype == "BF16" || t.dtype == "F16") ? 2 : 0;
+      if (!es) throw std::runtime_error("tensor '" + kv.first + "': unsupported dtype " + t.dtype);
+      if ((size_t)t.numel() * es != t.nbytes) throw std::runtime_error("tensor '" + kv.first + "': size mismatch");
+      tensors_[kv.first] = t;
+    }
+  }
   int fd_ = -1; size_t size_ = 0; const uint8_t* base_ = nullptr;
   std::map<std::string, TensorView> tensors_;
 };
@@ -252,7 +273,7 @@ inline bool load_wav(const std::string& path, WavData& out, std::string& err) {
     uint32_t len = u32(p + 4);
     if (!memcmp(d.data() + p, "fmt ", 4) && p + 8 + 16 <= d.size()) {
       fmt = u16(p + 8); ch = u16(p + 10); rate = u32(p + 12); bits = u16(p + 22);
-      if (fmt == 0xFFFE && len >= 26) fmt = u16(p + 8 + 24);  // WAVE_FORMAT_EXTENSIBLE sub-format
+      if (fmt == 0xFFFE && len >= 26 && p + 8 + 26 <= d.size()) fmt = u16(p + 8 + 24);  // WAVE_FORMAT_EXTENSIBLE sub-format
     } else if (!memcmp(d.data() + p, "data", 4)) {
       data_off = p + 8; data_len = std::min<size_t>(len, d.size() - data_off); break;
     }
@@ -260,6 +281,7 @@ inline bool load_wav(const std::string& path, WavData& out, std::string& err) {
   }
   if (!data_off || ch < 1 || !(fmt == 1 || fmt == 3)) { err = "unsupported WAV (need PCM or IEEE float)"; return false; }
   int bps = bits / 8;
+  if (bits % 8 != 0) { err = "unsupported bit depth"; return false; }
   if (!((fmt == 1 && (bps == 1 || bps == 2 || bps == 3 || bps == 4)) || (fmt == 3 && bps == 4))) { err = "unsupported bit depth"; return false; }
   size_t frames = data_len / ((size_t)bps * ch);
   out.sample_rate = rate; out.channels = ch; out.mono.resize(frames);

@@ -45,8 +45,9 @@ static bool wav_frames(const char* path, long* frames) {
       fseek(f, (long)(len - 16 + (len & 1)), SEEK_CUR);
     } else if (!memcmp(c, "data", 4)) {
       fclose(f);
-      if (!ch || !bits) return false;
-      *frames = (long)len / (ch * bits / 8);
+      const int frame_bytes = ch * (bits / 8);  // 0 for a bit depth below 8: not a format load_wav accepts either
+      if (frame_bytes <= 0) return false;
+      *frames = (long)len / frame_bytes;
       return true;
     } else {
       fseek(f, (long)(len + (len & 1)), SEEK_CUR);

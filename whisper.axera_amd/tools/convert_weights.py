@@ -1,7 +1,7 @@
 """Weight converters: real checkpoints -> the model directory libax_whisper.so loads.
 
-    python convert_weights.py --openai small.pt       --model_type small --model_path ./models
-    python convert_weights.py --hf openai/whisper-small-dir --model_type small --model_path ./models [--tiktoken multilingual.tiktoken]
+    python convert_weights.py --openai small.pt       --model_type small --model_path ./models --tiktoken multilingual.tiktoken
+    python convert_weights.py --hf openai/whisper-small-dir --model_type small --model_path ./models --tiktoken multilingual.tiktoken
 
 The reference obtains its weights through ``whisper.load_model(name)`` inside model_convert/export_onnx.py:508 and
 bakes them into NPU blobs; here the same tensors are written once as ``{type}.safetensors`` (openai-whisper
@@ -68,7 +68,33 @@ def dims_from_weights(w: dict) -> dict:
                 n_vocab=n_vocab, n_langs=n_vocab - 51765 - 1)  # 51865 -> 99 languages, 51866 -> 100
 
 
+def read_hf_checkpoint(path: str) -> dict:
+    """A transformers checkpoint: one .safetensors file, a directory with model.safetensors, or a directory with a
+    sharded checkpoint (model.safetensors.index.json -> weight_map of shard files)."""
+    import json
+
+    if path.endswith(".safetensors"):
+        return modelgen.read_safetensors(path)
+    single, index = os.path.join(path, "model.safetensors"), os.path.join(path, "model.safetensors.index.json")
+    if os.path.exists(single):
+        return modelgen.read_safetensors(single)
+    if os.path.exists(index):
+        shards = sorted(set(json.load(open(index))["weight_map"].values()))
+        sd = {}
+        for sh in shards:
+            sd.update(modelgen.read_safetensors(os.path.join(path, sh)))
+        return sd
+    raise FileNotFoundError(f"{path}: neither model.safetensors nor model.safetensors.index.json")
+
+
 def write_model(weights: dict, model_type: str, model_path: str, dtype: str = "BF16", tiktoken_path: str | None = None) -> str:
+    """tiktoken_path is REQUIRED for a real checkpoint: {type}-tokens.txt must carry the vocabulary the model was
+    trained with (the reference's exporter writes it from the tokenizer, export_onnx.py:391-417)."""
+    if not tiktoken_path:
+        raise ValueError("convert_weights needs the vocabulary: pass --tiktoken multilingual.tiktoken "
+                         "(the reference ships it as python/assets/multilingual.tiktoken)")
+    if not os.path.exists(tiktoken_path):
+        raise FileNotFoundError(f"vocabulary file {tiktoken_path} does not exist")
     dims = dims_from_weights(weights)
     expect = {n: s for n, s, _ in modelgen.tensor_names(dims)}
     missing = [n for n in expect if n not in weights and n != "encoder.positional_embedding"]
@@ -87,8 +113,8 @@ def main():
     src.add_argument("--hf", help="directory or .safetensors of a transformers Whisper model")
     ap.add_argument("--model_type", "-t", required=True)
     ap.add_argument("--model_path", "-p", required=True)
-    ap.add_argument("--dtype", default="BF16", choices=["BF16", "F32"])
-    ap.add_argument("--tiktoken", default=None, help="multilingual.tiktoken vocabulary for {type}-tokens.txt")
+    ap.add_argument("--dtype", default="BF16", choices=["BF16", "F16", "F32"])
+    ap.add_argument("--tiktoken", required=True, help="multilingual.tiktoken vocabulary for {type}-tokens.txt")
     a = ap.parse_args()
     if a.openai:
         import torch
@@ -97,8 +123,7 @@ def main():
         sd = ck.get("model_state_dict", ck)
         w = {k: v.float().numpy() for k, v in sd.items()}
     else:
-        path = a.hf if a.hf.endswith(".safetensors") else os.path.join(a.hf, "model.safetensors")
-        w = hf_to_openai_names(modelgen.read_safetensors(path))
+        w = hf_to_openai_names(read_hf_checkpoint(a.hf))
     print(write_model(w, a.model_type, a.model_path, a.dtype, a.tiktoken))
 
 

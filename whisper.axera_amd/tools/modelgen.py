@@ -180,6 +180,8 @@ def write_safetensors(path: str, tensors: Dict[str, np.ndarray], dtype: str = "B
         a = np.ascontiguousarray(arr, dtype=np.float32)
         if dtype == "BF16":
             raw = (bf16_round(a).view(np.uint32) >> np.uint32(16)).astype(np.uint16).tobytes()
+        elif dtype == "F16":  # the dtype openai's and HF's Whisper checkpoints are published in
+            raw = a.astype(np.float16).tobytes()
         elif dtype == "F32":
             raw = a.tobytes()
         else:
@@ -221,11 +223,14 @@ def read_safetensors(path: str) -> Dict[str, np.ndarray]:
 
 
 def write_tokens(path: str, tiktoken_path: str | None) -> None:
-    """``{type}-tokens.txt``: lines ``<base64> <rank>`` (export_onnx.py:391-417). With no
-    vocabulary file at hand a synthetic one is written (rank i -> the bytes of ``t{i} ``)."""
+    """``{type}-tokens.txt``: lines ``<base64> <rank>`` (export_onnx.py:391-417). ``tiktoken_path=None`` writes a
+    synthetic vocabulary (rank i -> the bytes of ``t{i} ``) — for synthetic-weight models only; a path that does not
+    exist is an error (a real checkpoint with a made-up vocabulary would transcribe garbage without a warning)."""
     import base64
 
-    if tiktoken_path and os.path.exists(tiktoken_path):
+    if tiktoken_path is not None and not os.path.exists(tiktoken_path):
+        raise FileNotFoundError(f"vocabulary file {tiktoken_path} does not exist")
+    if tiktoken_path:
         with open(tiktoken_path) as src, open(path, "w") as dst:
             for line in src:
                 if line.strip():
@@ -249,6 +254,8 @@ def write_model_dir(root: str, model_type: str, dims: dict | None = None, seed: 
     write_tokens(os.path.join(d, f"{model_type}-tokens.txt"), tiktoken_path)
     if weights is None:
         weights = synth_weights(dims, seed, bf16=(dtype == "BF16"))
+        if dtype == "F16":  # synthetic fp16 model: weights exactly representable in fp16 (both sides hold equal values)
+            weights = {k: v.astype(np.float16).astype(np.float32) for k, v in weights.items()}
     write_safetensors(os.path.join(d, f"{model_type}.safetensors"), weights, dtype)
     return d
 
