@@ -50,6 +50,21 @@ AX_WHISPER_API int AX_WHISPER_RunPCM(AX_WHISPER_HANDLE handle, float* pcm_data, 
  *  utterance slots to allocate (<=0: env AX_WHISPER_MAX_BATCH, else 1; grows on demand). */
 AX_WHISPER_API AX_WHISPER_HANDLE AX_WHISPER_InitEx(const char* model_type, const char* model_path,
                                                    const char* language, int device, int max_batch);
+/** One engine per device behind ONE handle (utterance-level data parallelism, SURVEY 8e: the reference is one
+ *  utterance at a time, Whisper.cpp:186-239). devices: n_devices HIP ordinals; NULL / n_devices <= 0: the list in env
+ *  AX_WHISPER_DEVICES ("0,1,4" or "all"), else every visible device. Weights are replicated; RunPCMBatch /
+ *  RunPCMBatchTokens split a batch into contiguous blocks of ceil(batch / devices) clips, run every block on its
+ *  device from its own host thread and return when all have finished (no collective: each device copies its ids
+ *  back itself). Every other entry point uses the first device. The legacy AX_WHISPER_Init does the same when
+ *  AX_WHISPER_DEVICES is set, so existing callers need no source change. NULL on failure. */
+AX_WHISPER_API AX_WHISPER_HANDLE AX_WHISPER_InitMulti(const char* model_type, const char* model_path,
+                                                      const char* language, const int* devices, int n_devices,
+                                                      int max_batch_per_device);
+/** HIP devices this process can see (0 when there is none): lets a host program that links only this C ABI
+ *  (whisper_srv) create one handle per device. */
+AX_WHISPER_API int AX_WHISPER_VisibleDeviceCount(void);
+/** Engines (devices) behind the handle; -1 for a NULL handle. */
+AX_WHISPER_API int AX_WHISPER_GetDeviceCount(AX_WHISPER_HANDLE handle);
 /** Integer config value by the key names of {type}_config.json (n_mels, n_vocab, eot, ...),
  *  plus "sot_seq0".."sot_seq3". Returns INT32_MIN for an unknown key. */
 AX_WHISPER_API int AX_WHISPER_GetConfigInt(AX_WHISPER_HANDLE handle, const char* key);

@@ -184,3 +184,38 @@ def test_failed_inits_do_not_leak_device_memory(built_lib, micro_case, tmp_path)
         assert L.AX_WHISPER_Init(b"micro", str(tmp_path).encode(), b"zh") is None
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 16 << 20, (free0, free1)
+
+
+def test_multi_device_handle_shards_a_batch(built_lib, micro_case, monkeypatch):
+    """AX_WHISPER_InitMulti: one engine per listed device behind one handle, RunPCMBatch* split into contiguous blocks
+    (csrc/multi_device.hpp). A one-GPU box lists its device twice (test hook) so that two real engines, two worker
+    threads and the join run for real; the sharding rule itself is covered on the CPU by tests/test_multi_device.py."""
+    import modelgen
+
+    L = built_lib.load_library()
+    assert L.AX_WHISPER_VisibleDeviceCount() >= 1
+    one = built_lib.Whisper("micro", micro_case.root, "zh", devices=[0], max_batch=3)
+    assert one.n_devices == 1
+    clips = [load_demo_pcm()] + [modelgen.synth_clip(i, 60000 + 7000 * i) for i in range(1, 7)]
+    want = one.run_tokens_batch(clips, max_new=8)
+    want_text = one.run_batch(clips[:3])
+    one.close()
+    with pytest.raises(RuntimeError, match="listed twice"):
+        built_lib.Whisper("micro", micro_case.root, "zh", devices=[0, 0])
+    with pytest.raises(RuntimeError, match="not visible|out of range"):
+        built_lib.Whisper("micro", micro_case.root, "zh", devices=[0, 99])
+    monkeypatch.setenv("AX_WHISPER_ALLOW_DUPLICATE_DEVICES", "1")
+    e = built_lib.Whisper("micro", micro_case.root, "zh", devices=[0, 0, 0], max_batch=3)
+    try:
+        assert e.n_devices == 3 and e.L.AX_WHISPER_GetConfigInt(e.h, b"n_devices") == 3
+        assert e.run_tokens_batch(clips, max_new=8) == want            # 7 clips -> blocks of 3, 3, 1
+        assert e.run_tokens_batch(clips[:2], max_new=8) == want[:2]    # fewer clips than devices: one clip each
+        assert e.run_tokens(clips[4], max_new=8) == want[4]
+        assert e.run_batch(clips[:3]) == want_text
+        bad = [c.copy() for c in clips]
+        bad[5][100] = np.nan                                            # lives in the second device's block
+        with pytest.raises(RuntimeError, match="device worker 1.*non-finite"):
+            e.run_tokens_batch(bad, max_new=8)
+        assert e.run_tokens_batch(clips, max_new=8) == want            # every worker was joined; the handle is intact
+    finally:
+        e.close()

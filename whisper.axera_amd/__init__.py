@@ -30,6 +30,9 @@ _lib = None
 SYMBOLS = {
     "AX_WHISPER_Init": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_char_p]),
     "AX_WHISPER_InitEx": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
+    "AX_WHISPER_InitMulti": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_int]),
+    "AX_WHISPER_GetDeviceCount": (C.c_int, [C.c_void_p]),
+    "AX_WHISPER_VisibleDeviceCount": (C.c_int, []),
     "AX_WHISPER_Uninit": (None, [C.c_void_p]),
     "AX_WHISPER_RunFile": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "AX_WHISPER_RunPCM": (C.c_int, [C.c_void_p, fp, C.c_int, C.POINTER(C.c_void_p)]),
@@ -94,15 +97,24 @@ def _f32(a):
 class Whisper:
     """Mirror of the reference's ``Whisper`` (python/whisper.py:54-99, cpp/src/Whisper.hpp:28-59)."""
 
-    def __init__(self, model_type: str, model_path: str, language: str = "zh", device: int = -1, max_batch: int = 0):
+    def __init__(self, model_type: str, model_path: str, language: str = "zh", device: int = -1, max_batch: int = 0, devices=None):
+        """devices: a list of HIP ordinals (or "all") -> one engine per device behind this handle (AX_WHISPER_InitMulti)."""
         self.L = load_library()
-        self.h = self.L.AX_WHISPER_InitEx(model_type.encode(), model_path.encode(), language.encode(), device, max_batch)
+        if devices is not None:
+            if devices == "all":
+                self.h = self.L.AX_WHISPER_InitMulti(model_type.encode(), model_path.encode(), language.encode(), None, 0, max_batch)
+            else:
+                arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+                self.h = self.L.AX_WHISPER_InitMulti(model_type.encode(), model_path.encode(), language.encode(), arr, len(devices), max_batch)
+        else:
+            self.h = self.L.AX_WHISPER_InitEx(model_type.encode(), model_path.encode(), language.encode(), device, max_batch)
         if not self.h:
             raise RuntimeError("AX_WHISPER_Init failed: " + (self.L.AX_WHISPER_LastError(None) or b"").decode())
         g = lambda k: self.L.AX_WHISPER_GetConfigInt(self.h, k.encode())
         self.n_mels, self.n_vocab, self.n_text_ctx = g("n_mels"), g("n_vocab"), g("n_text_ctx")
         self.n_text_layer, self.n_text_state, self.eot = g("n_text_layer"), g("n_text_state"), g("eot")
         self.sot_seq = [g(f"sot_seq{i}") for i in range(4)]
+        self.n_devices = self.L.AX_WHISPER_GetDeviceCount(self.h)
 
     def close(self):
         if getattr(self, "h", None):

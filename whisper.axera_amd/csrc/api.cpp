@@ -13,58 +13,85 @@
 #include <climits>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "engine.hpp"
 #include "host_io.hpp"
+#include "multi_device.hpp"
 
 using axw::Engine;
 
 namespace {
 thread_local std::string g_init_error;
 struct Handle {
-  Engine* engine = nullptr;
+  axw::DeviceGroup<Engine> group;  // one engine per device; the legacy entry points create exactly one
   std::string last_error;
+  std::mutex err_mu;
+  void set_error(const std::string& e) {
+    std::lock_guard<std::mutex> lk(err_mu);
+    last_error = e;
+  }
 };
 inline Handle* H(AX_WHISPER_HANDLE h) { return static_cast<Handle*>(h); }
 
+// f(primary engine) under that engine's mutex; exceptions become -1 + last_error
 template <typename F>
 int guarded(AX_WHISPER_HANDLE handle, F&& f) {
   Handle* h = H(handle);
-  if (!h || !h->engine) return -1;
-  std::lock_guard<std::mutex> lock(h->engine->mutex());
+  if (!h || h->group.size() == 0) return -1;
   try {
-    f(*h->engine);
+    Engine& e = h->group.primary();
+    std::lock_guard<std::mutex> lock(e.mutex());
+    f(e);
     return 0;
   } catch (const std::exception& e) {
-    h->last_error = e.what();
+    h->set_error(e.what());
     fprintf(stderr, "[ax_whisper] %s\n", e.what());
     return -1;
   } catch (...) {
-    h->last_error = "unknown error";
+    h->set_error("unknown error");
     return -1;
   }
 }
-}  // namespace
 
-extern "C" {
-
-AX_WHISPER_API AX_WHISPER_HANDLE AX_WHISPER_InitEx(const char* model_type, const char* model_path, const char* language,
-                                                   int device, int max_batch) {
-  if (!model_type || !model_path || !language) {
-    g_init_error = "null argument";
-    return nullptr;
-  }
+// f(device group): the sharded entry points; every shard locks its own engine (multi_device.hpp)
+template <typename F>
+int guarded_group(AX_WHISPER_HANDLE handle, F&& f) {
+  Handle* h = H(handle);
+  if (!h || h->group.size() == 0) return -1;
   try {
-    Handle* h = new Handle();
-    try {
-      h->engine = new Engine(model_type, model_path, language, device, max_batch);
-    } catch (...) {
-      delete h;  // the reference leaks here (ax_whisper_api.cpp:49-53)
-      throw;
-    }
-    return h;
+    f(h->group);
+    return 0;
+  } catch (const std::exception& e) {
+    h->set_error(e.what());
+    fprintf(stderr, "[ax_whisper] %s\n", e.what());
+    return -1;
+  } catch (...) {
+    h->set_error("unknown error");
+    return -1;
+  }
+}
+
+AX_WHISPER_HANDLE init_devices(const char* model_type, const char* model_path, const char* language,
+                               const std::vector<int>& devices, int max_batch) {
+  std::unique_ptr<Handle> h(new Handle());
+  const int G = (int)devices.size();
+  std::vector<std::unique_ptr<Engine>> engines(G);
+  // engines load side by side (one host thread per device): each uploads its own replica of the weights
+  axw::run_sharded(G, G, [&](int w, int, int) {
+    engines[w].reset(new Engine(model_type, model_path, language, devices[w], max_batch));
+  });
+  for (auto& e : engines) h->group.add(std::move(e));
+  return h.release();  // a throw above destroys every engine already built (the reference leaks: ax_whisper_api.cpp:49-53)
+}
+
+template <typename F>
+AX_WHISPER_HANDLE init_guarded(F&& f) {
+  try {
+    return f();
   } catch (const std::exception& e) {
     g_init_error = e.what();
     fprintf(stderr, "[ax_whisper] init failed: %s\n", e.what());
@@ -75,15 +102,75 @@ AX_WHISPER_API AX_WHISPER_HANDLE AX_WHISPER_InitEx(const char* model_type, const
   }
 }
 
+int visible_devices() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    throw std::runtime_error("no HIP device visible: the MI355X engine has no CPU fallback");
+  return n;
+}
+}  // namespace
+
+extern "C" {
+
+AX_WHISPER_API AX_WHISPER_HANDLE AX_WHISPER_InitMulti(const char* model_type, const char* model_path, const char* language,
+                                                      const int* devices, int n_devices, int max_batch_per_device) {
+  if (!model_type || !model_path || !language) {
+    g_init_error = "null argument";
+    return nullptr;
+  }
+  return init_guarded([&]() -> AX_WHISPER_HANDLE {
+    const int n_vis = visible_devices();
+    std::vector<int> devs;
+    if (devices && n_devices > 0) {
+      // test hook: AX_WHISPER_ALLOW_DUPLICATE_DEVICES=1 lets a one-GPU box run several engines (the sharding, the
+      // worker threads, the join) against real devices; production lists must name each device once
+      const char* dup = getenv("AX_WHISPER_ALLOW_DUPLICATE_DEVICES");
+      if (dup && dup[0] == '1') {
+        for (int i = 0; i < n_devices; ++i) {
+          if (devices[i] < 0 || devices[i] >= n_vis) throw std::runtime_error("device ordinal out of range");
+          devs.push_back(devices[i]);
+        }
+      } else {
+        std::string list;
+        for (int i = 0; i < n_devices; ++i) list += (i ? "," : "") + std::to_string(devices[i] < 0 ? n_vis : devices[i]);
+        devs = axw::parse_device_list(list, n_vis);  // range + duplicate checks
+      }
+    } else {
+      const char* e = getenv("AX_WHISPER_DEVICES");
+      devs = axw::parse_device_list(e ? e : "all", n_vis);
+    }
+    return init_devices(model_type, model_path, language, devs, max_batch_per_device);
+  });
+}
+
+AX_WHISPER_API AX_WHISPER_HANDLE AX_WHISPER_InitEx(const char* model_type, const char* model_path, const char* language,
+                                                   int device, int max_batch) {
+  if (!model_type || !model_path || !language) {
+    g_init_error = "null argument";
+    return nullptr;
+  }
+  // device < 0 and AX_WHISPER_DEVICES set ("all" or "0,1,..."): the unchanged callers of the legacy Init (whisper_cli,
+  // a reference-side application) get one engine per listed device without a source change
+  if (device < 0 && getenv("AX_WHISPER_DEVICES")) return AX_WHISPER_InitMulti(model_type, model_path, language, nullptr, 0, max_batch);
+  return init_guarded([&]() -> AX_WHISPER_HANDLE { return init_devices(model_type, model_path, language, {device}, max_batch); });
+}
+
 AX_WHISPER_API AX_WHISPER_HANDLE AX_WHISPER_Init(const char* model_type, const char* model_path, const char* language) {
   return AX_WHISPER_InitEx(model_type, model_path, language, -1, 0);
 }
 
 AX_WHISPER_API void AX_WHISPER_Uninit(AX_WHISPER_HANDLE handle) {
+  delete H(handle);  // NULL-safe (ax_whisper_api.cpp:69-74); the group destroys its engines
+}
+
+AX_WHISPER_API int AX_WHISPER_VisibleDeviceCount(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+AX_WHISPER_API int AX_WHISPER_GetDeviceCount(AX_WHISPER_HANDLE handle) {
   Handle* h = H(handle);
-  if (!h) return;
-  delete h->engine;
-  delete h;
+  return h ? h->group.size() : -1;
 }
 
 AX_WHISPER_API int AX_WHISPER_RunPCM(AX_WHISPER_HANDLE handle, float* pcm_data, int num_samples, char** result) {
@@ -98,12 +185,12 @@ AX_WHISPER_API int AX_WHISPER_RunFile(AX_WHISPER_HANDLE handle, const char* wav_
   axw::WavData wav;
   std::string err;
   if (!axw::load_wav(wav_file, wav, err)) {
-    H(handle)->last_error = "load wav failed: " + err;
+    H(handle)->set_error("load wav failed: " + err);
     fprintf(stderr, "[ax_whisper] load wav failed: %s\n", err.c_str());
     return -1;
   }
   if (wav.mono.empty()) {
-    H(handle)->last_error = "wav file holds no samples";
+    H(handle)->set_error("wav file holds no samples");
     return -1;
   }
   if (wav.sample_rate != 16000)  // the reference silently mis-transcribes (no resampler anywhere in its C++)
@@ -115,7 +202,9 @@ AX_WHISPER_API int AX_WHISPER_RunFile(AX_WHISPER_HANDLE handle, const char* wav_
 AX_WHISPER_API int AX_WHISPER_RunPCMBatchTokens(AX_WHISPER_HANDLE handle, const float* const* pcm, const int* num_samples,
                                                 int batch, int max_new, int32_t* ids, int* n_ids) {
   if (!handle || !pcm || !num_samples || !ids || !n_ids || batch < 1) return -1;
-  return guarded(handle, [&](Engine& e) { e.run_tokens(pcm, nullptr, 0, num_samples, batch, max_new, ids, n_ids); });
+  return guarded_group(handle, [&](axw::DeviceGroup<Engine>& g) {
+    g.run_tokens(pcm, num_samples, batch, max_new, g.primary().config().n_text_ctx, ids, n_ids);
+  });
 }
 
 AX_WHISPER_API int AX_WHISPER_RunDeviceBatchTokens(AX_WHISPER_HANDLE handle, const float* d_pcm, int stride,
@@ -128,12 +217,13 @@ AX_WHISPER_API int AX_WHISPER_RunPCMBatch(AX_WHISPER_HANDLE handle, const float*
                                           char** results) {
   if (!handle || !pcm || !num_samples || !results || batch < 1) return -1;
   for (int b = 0; b < batch; ++b) results[b] = nullptr;
-  return guarded(handle, [&](Engine& e) {
+  return guarded_group(handle, [&](axw::DeviceGroup<Engine>& g) {
+    Engine& e = g.primary();
     const int Tc = e.config().n_text_ctx;
     std::vector<int32_t> ids((size_t)batch * Tc);
     std::vector<int> n(batch);
-    e.run_tokens(pcm, nullptr, 0, num_samples, batch, 0, ids.data(), n.data());
-    for (int b = 0; b < batch; ++b) results[b] = strdup(e.transcript(ids.data() + (size_t)b * Tc, n[b]).c_str());
+    g.run_tokens(pcm, num_samples, batch, 0, Tc, ids.data(), n.data());
+    for (int b = 0; b < batch; ++b) results[b] = strdup(e.transcript(ids.data() + (size_t)b * Tc, n[b]).c_str());  // host only
   });
 }
 
@@ -161,8 +251,9 @@ AX_WHISPER_API int AX_WHISPER_ConvertT2S(const char* config_path, const char* te
 
 AX_WHISPER_API int AX_WHISPER_GetConfigInt(AX_WHISPER_HANDLE handle, const char* key) {
   Handle* h = H(handle);
-  if (!h || !key) return INT_MIN;
-  auto& m = h->engine->config().ints;
+  if (!h || !key || h->group.size() == 0) return INT_MIN;
+  if (!strcmp(key, "n_devices")) return h->group.size();
+  auto& m = h->group.primary().config().ints;
   auto it = m.find(key);
   return it == m.end() ? INT_MIN : (int)it->second;
 }

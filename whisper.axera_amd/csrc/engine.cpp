@@ -888,9 +888,9 @@ int Engine::greedy_loop(int batch, int max_new, const int* max_new_clip) {
 
 int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float* d_logits, int* d_argmax) {
   // The launch needs every workgroup resident at once (one per CU): two of them in flight on one GPU could each hold
-  // part of the CUs and starve the other until both give up. Handles of one process take turns.
-  static std::mutex launch_mu;
-  std::lock_guard<std::mutex> launch_lock(launch_mu);
+  // part of the CUs and starve the other until both give up. Handles of one process on one device take turns.
+  static std::mutex launch_mu[64];  // one per device: engines of different GPUs never wait for each other
+  std::lock_guard<std::mutex> launch_lock(launch_mu[device_ & 63]);
   hipStream_t s = stream();
   const int Tc = cfg_.n_text_ctx, H = cfg_.n_text_head;
   PersistParams p{};

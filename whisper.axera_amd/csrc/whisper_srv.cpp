@@ -7,10 +7,12 @@
 // content type / empty body / size % 4 != 0 / failed run. Adds GET /health.
 //
 // What is new: the reference calls one non-re-entrant handle from cpp-httplib's thread pool with
-// no lock. Here connection threads only parse requests and enqueue them; ONE
-// batcher thread drains the queue into micro-batches (up to --max_batch clips, waiting at most
-// --batch_wait_ms for stragglers) and runs them through AX_WHISPER_RunPCMBatch, which is where the
-// GPU's utterance-level data parallelism comes from under concurrent load.
+// no lock. Here connection threads only parse requests and enqueue them; one
+// batcher thread PER DEVICE (--devices all | 0,1,...; default: the one device of AX_WHISPER_Init)
+// drains the shared queue into micro-batches (up to --max_batch clips, waiting at most
+// --batch_wait_ms for stragglers) and runs them through AX_WHISPER_RunPCMBatch on its own handle:
+// utterance-level data parallelism inside a GPU (the batch) and across the GPUs of the node (the
+// batchers), with no cross-device synchronisation — an idle device simply takes the next requests.
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -73,13 +75,23 @@ static void batcher(AX_WHISPER_HANDLE model, int max_batch, int wait_ms) {
       while (!g_queue.empty() && (int)jobs.size() < max_batch) { jobs.push_back(g_queue.front()); g_queue.pop_front(); }
     }
     const int n = (int)jobs.size();
+    if (n == 0) continue;  // another device's batcher took the requests while this one waited for stragglers
     std::vector<const float*> ptrs(n);
     std::vector<int> lens(n);
     std::vector<char*> texts(n, nullptr);
     for (int i = 0; i < n; ++i) { ptrs[i] = jobs[i]->pcm.data(); lens[i] = (int)jobs[i]->pcm.size(); }
-    const int rc = AX_WHISPER_RunPCMBatch(model, ptrs.data(), lens.data(), n, texts.data());
+    int rc = AX_WHISPER_RunPCMBatch(model, ptrs.data(), lens.data(), n, texts.data());
+    std::vector<int> ok(n, rc == 0);
+    if (rc != 0 && n > 1) {
+      // one bad request (e.g. non-finite samples) must not fail the strangers batched with it: run them one by one
+      for (int i = 0; i < n; ++i) {
+        free(texts[i]);
+        texts[i] = nullptr;
+        ok[i] = AX_WHISPER_RunPCMBatch(model, &ptrs[i], &lens[i], 1, &texts[i]) == 0;
+      }
+    }
     for (int i = 0; i < n; ++i) {
-      jobs[i]->done.set_value({rc == 0 && texts[i], texts[i] ? std::string(texts[i]) : std::string()});
+      jobs[i]->done.set_value({ok[i] && texts[i], texts[i] ? std::string(texts[i]) : std::string()});
       free(texts[i]);  // the reference never frees it (WhisperHTTPServer.hpp:77-90)
     }
   }
@@ -164,7 +176,7 @@ static void serve(int fd) {
 
 int main(int argc, char** argv) {
   int port = 8080, max_batch = 16, wait_ms = 5;
-  std::string model_type = "turbo", model_path = "../models-mi355x", language = "zh";
+  std::string model_type = "turbo", model_path = "../models-mi355x", language = "zh", devices;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&](const char* lng, const char* sht, std::string& dst) -> bool {
@@ -178,7 +190,8 @@ int main(int argc, char** argv) {
     if (val("max_batch", nullptr, v)) { max_batch = std::max(1, atoi(v.c_str())); continue; }
     if (val("batch_wait_ms", nullptr, v)) { wait_ms = std::max(0, atoi(v.c_str())); continue; }
     if (val("model_type", "-t", model_type) || val("model_path", "-p", model_path) || val("language", "-l", language)) continue;
-    fprintf(stderr, "usage: %s [--port 8080] [-t model_type] [-p model_path] [-l language] [--max_batch 16] [--batch_wait_ms 5]\n", argv[0]);
+    if (val("devices", nullptr, devices)) continue;
+    fprintf(stderr, "usage: %s [--port 8080] [-t model_type] [-p model_path] [-l language] [--max_batch 16] [--batch_wait_ms 5] [--devices all|0,1,..]\n", argv[0]);
     return a == "--help" || a == "-?" ? 0 : 1;
   }
   printf("port: %d\n", port);
@@ -186,8 +199,33 @@ int main(int argc, char** argv) {
   printf("model_type: %s\n", model_type.c_str());
   printf("language: %s\n", language.c_str());
 
-  AX_WHISPER_HANDLE model = AX_WHISPER_InitEx(model_type.c_str(), model_path.c_str(), language.c_str(), -1, max_batch);
-  if (!model) { printf("init server failed!\n"); return -1; }
+  // one handle (one engine, one batcher thread) per device
+  std::vector<int> devs;
+  if (devices.empty()) {
+    devs.push_back(-1);  // AX_WHISPER_Init's default device
+  } else if (devices == "all") {
+    for (int d = 0; d < AX_WHISPER_VisibleDeviceCount(); ++d) devs.push_back(d);
+  } else {
+    size_t p = 0;
+    while (p < devices.size()) {
+      size_t q = devices.find(',', p);
+      if (q == std::string::npos) q = devices.size();
+      devs.push_back(atoi(devices.substr(p, q - p).c_str()));
+      p = q + 1;
+    }
+  }
+  std::vector<AX_WHISPER_HANDLE> models;
+  for (int d : devs) {
+    AX_WHISPER_HANDLE m = AX_WHISPER_InitEx(model_type.c_str(), model_path.c_str(), language.c_str(), d, max_batch);
+    if (!m) {
+      printf("init server failed!\n");
+      for (AX_WHISPER_HANDLE o : models) AX_WHISPER_Uninit(o);
+      return -1;
+    }
+    models.push_back(m);
+  }
+  if (models.empty()) { printf("init server failed!\n"); return -1; }
+  printf("devices: %d\n", (int)models.size());
 
   int srv = socket(AF_INET, SOCK_STREAM, 0);
   int one = 1;
@@ -200,7 +238,8 @@ int main(int argc, char** argv) {
   printf("Start server at port %d, POST binary stream to IP:%d/asr\n", port, port);
   fflush(stdout);
 
-  std::thread bt(batcher, model, max_batch, wait_ms);
+  std::vector<std::thread> bts;
+  for (AX_WHISPER_HANDLE m : models) bts.emplace_back(batcher, m, max_batch, wait_ms);
   signal(SIGPIPE, SIG_IGN);
   for (;;) {
     int fd = accept(srv, nullptr, nullptr);
@@ -210,7 +249,7 @@ int main(int argc, char** argv) {
   }
   g_stop = true;
   g_cv.notify_all();
-  bt.join();
-  AX_WHISPER_Uninit(model);
+  for (auto& t : bts) t.join();
+  for (AX_WHISPER_HANDLE m : models) AX_WHISPER_Uninit(m);
   return 0;
 }
