@@ -61,6 +61,9 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
   device_set_ = true;
   HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   for (auto& e : ev_) HIP_CHECK(hipEventCreate(&e));
+  for (auto& b : branch_stream_) HIP_CHECK(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+  for (auto& e : ev_join_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 
   const std::string dir = model_path + "/" + model_type;
   load_config(dir, model_type, language);
@@ -112,6 +115,9 @@ void Engine::destroy() {
   if (load_stage_) { (void)hipFree(load_stage_); load_stage_ = nullptr; }
   if (h_poll_) { (void)hipHostFree(h_poll_); h_poll_ = nullptr; }
   for (auto& e : ev_) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  for (auto& e : ev_join_) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  if (ev_fork_) { (void)hipEventDestroy(ev_fork_); ev_fork_ = nullptr; }
+  for (auto& b : branch_stream_) if (b) { (void)hipStreamDestroy(b); b = nullptr; }
   if (own_stream_) { (void)hipStreamDestroy(own_stream_); own_stream_ = nullptr; }
 }
 
@@ -471,6 +477,7 @@ void Engine::ensure_capacity(int batch) {
   d_out_ids_ = (int*)A((size_t)B * Tc * 4, true);
   d_state_ = (DecState*)A(sizeof(DecState), true);
   cap_ = B;
+  cfg_.ints["decode_branches"] = (B > 4 && batched_ln_) ? decode_branches(B) : 1;  // at full capacity (bench.py reads it)
 }
 
 // ------------------------------------------------------------------------------ front-end
@@ -679,6 +686,86 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
   if (step_mask_ & 4) launch_advance(a, s);
 }
 
+// Decoder layers of clips [b0, b0 + nb) as clip-block GEMMs (decode_cgemm_kernel): LayerNorm is the prologue of its
+// consumer and the residual add the epilogue of its producer, so a layer is 7 launches instead of 11
+// (AX_WHISPER_BATCHED_LN=0: the older sequence with a separate LayerNorm/bf16-pair preparation launch and split-K
+// partials). b0 is a multiple of 16: every per-clip buffer of the range starts at a whole clip block.
+void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
+  const int d = cfg_.n_text_state, H = cfg_.n_text_head, L = cfg_.n_text_layer, Tc = cfg_.n_text_ctx;
+  const long self_stride = (long)H * Tc * 64, cross_stride = (long)H * t_pad_ * 64;
+  const long frag0 = (long)(b0 / 16) * 512;  // fragment-major pair layouts: clip blocks are 512 elements apart within a k-step
+  float* x = d_xdec_ + (long)b0 * d;
+  float* qd = d_qdec_ + (long)b0 * d;
+  bf16 *att_hi = d_att_[0] + frag0, *att_lo = d_att_[1] + frag0, *hid_hi = d_hidp_[0] + frag0, *hid_lo = d_hidp_[1] + frag0;
+  const int* done = forced ? nullptr : d_done_ + b0;
+  auto cgemm = [&](const bf16* W, const float* bias, int N, int K, int epi, int rt) {
+    DecCGemmParams c{};
+    c.W = W; c.bias = bias; c.N = N; c.K = K; c.batch = nb; c.nbs = nbs_; c.epilogue = epi; c.rt = rt;
+    c.d_model = d; c.n_ctx_pad = Tc; c.state = d_state_;
+    return c;
+  };
+  static const bool fuse_cq = [] { const char* e = getenv("AX_WHISPER_FUSE_CQ"); return !(e && e[0] == '0'); }();
+  auto cgo = [&](const DecCGemmParams& c) { if (step_mask_ & 1) launch_decode_cgemm(c, s); };
+  auto attn = [&](const bf16* kc, const bf16* vc, long stride, int n_keys, int cap_blocks) {
+    DecAttnParams a{};
+    a.q = qd; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = nullptr; a.n_split = 1;
+    a.batch = nb; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
+    a.done = done;
+    a.out_hi = att_hi; a.out_lo = att_lo; a.nbs = nbs_;
+    return a;
+  };
+  const int n_blk = (nb + 15) / 16;
+  // two row tiles per workgroup where one would make more workgroups than can be resident at once
+  auto rt_for = [&](int N) { return (N / 16) * n_blk > 512 ? 2 : 1; };
+
+  for (int l = 0; l < L; ++l) {
+    const DecLayerW& w = dec_[l];
+    const DecLayerWP& wq = dec_packed_[l];
+    bf16* sk = d_self_k_ + ((size_t)l * cap_ + b0) * self_stride;
+    bf16* sv = d_self_v_ + ((size_t)l * cap_ + b0) * self_stride;
+    const bf16* ck = d_cross_k_ + ((size_t)l * cap_ + b0) * cross_stride;
+    const bf16* cv = d_cross_v_ + ((size_t)l * cap_ + b0) * cross_stride;
+    DecCGemmParams c = cgemm(wq.w_qkv, w.b_qkv, 3 * d, d, GEPI_QKV_CACHE, rt_for(3 * d));
+    c.x = x; c.ln_w = w.attn_ln_w; c.ln_b = w.attn_ln_b;
+    c.out = qd; c.k_cache = sk; c.v_cache = sv; c.kv_batch_stride = self_stride;
+    cgo(c);
+    if (step_mask_ & 2) launch_decode_attention(attn(sk, sv, self_stride, -1, Tc / 64), s);
+    c = cgemm(wq.w_o, w.b_o, d, d, GEPI_RESID, 1);
+    c.a_hi = att_hi; c.a_lo = att_lo; c.out = x;
+    cgo(c);
+    if (fuse_cq) {  // the cross-attention workgroups project their own queries (decode_attention_kernel<true>)
+      DecAttnParams a = attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64);
+      a.q = nullptr;
+      a.x = x; a.ln_w = w.cross_ln_w; a.ln_b = w.cross_ln_b; a.wq = w.w_cq; a.bq = w.b_cq;
+      if (step_mask_ & 2) launch_decode_attention(a, s);
+    } else {
+      c = cgemm(wq.w_cq, w.b_cq, d, d, GEPI_STORE, 1);
+      c.x = x; c.ln_w = w.cross_ln_w; c.ln_b = w.cross_ln_b; c.out = qd;
+      cgo(c);
+      if (step_mask_ & 2) launch_decode_attention(attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64), s);
+    }
+    c = cgemm(wq.w_co, w.b_co, d, d, GEPI_RESID, 1);
+    c.a_hi = att_hi; c.a_lo = att_lo; c.out = x;
+    cgo(c);
+    c = cgemm(wq.w_fc1, w.b_fc1, 4 * d, d, GEPI_GELU, rt_for(4 * d));
+    c.x = x; c.ln_w = w.mlp_ln_w; c.ln_b = w.mlp_ln_b; c.out_hi = hid_hi; c.out_lo = hid_lo;
+    cgo(c);
+    c = cgemm(wq.w_fc2, w.b_fc2, d, 4 * d, GEPI_RESID, 1);
+    c.a_hi = hid_hi; c.a_lo = hid_lo; c.out = x;
+    cgo(c);
+  }
+}
+
+// Branches of the batched step graph (see enqueue_decode_step_batched): 1 below 32 clips, else 2 (AX_WHISPER_DECODE_BRANCHES
+// overrides: 1, 2 or 4).
+int Engine::decode_branches(int batch) const {
+  static const int forced = [] { const char* e = getenv("AX_WHISPER_DECODE_BRANCHES"); return e ? atoi(e) : 0; }();
+  int n = forced > 0 ? forced : (batch >= 32 ? 2 : 1);
+  n = std::min(n, kMaxBranches);
+  while (n > 1 && (batch + n - 1) / n < 16) n /= 2;  // at least one whole clip block per branch
+  return std::max(n, 1);
+}
+
 // Batched variant (5+ clips): LayerNorm -> bf16 pairs (act_prep), MFMA GEMMs that read the weights once for the
 // whole batch, one attention workgroup per (clip, head) writing its output directly (no split partials).
 void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits,
@@ -735,62 +822,36 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     return p;
   };
 
-  // Clip-block GEMMs (decode_cgemm_kernel): LayerNorm is the prologue of its consumer and the residual add the
-  // epilogue of its producer, so a layer is 8 launches instead of 11 (AX_WHISPER_BATCHED_LN=0: the older sequence
-  // with a separate LayerNorm/bf16-pair preparation launch and split-K partials).
-  auto cgemm = [&](const bf16* W, const float* bias, int N, int K, int epi, int rt) {
-    DecCGemmParams c{};
-    c.W = W; c.bias = bias; c.N = N; c.K = K; c.batch = batch; c.nbs = nbs_; c.epilogue = epi; c.rt = rt;
-    c.d_model = d; c.n_ctx_pad = Tc; c.state = d_state_;
-    return c;
-  };
-  static const bool fuse_cq = [] { const char* e = getenv("AX_WHISPER_FUSE_CQ"); return !(e && e[0] == '0'); }();
-  auto cgo = [&](const DecCGemmParams& c) { if (step_mask_ & 1) launch_decode_cgemm(c, s); };
-  const int n_blk = (batch + 15) / 16;
-  // two row tiles per workgroup where one would make more workgroups than can be resident at once
-  auto rt_for = [&](int N) { return (N / 16) * n_blk > 512 ? 2 : 1; };
-
-  for (int l = 0; l < L; ++l) {
+  if (batched_ln_) {
+    // Clip-block sequence (enqueue_layers_cblock). With 32+ clips the batch runs as 2 BRANCHES of whole clip blocks that
+    // fork here and join before the vocabulary projection: inside a captured step they become parallel branches of
+    // the ONE step graph, so one branch's latency-bound chain of small GEMMs overlaps the other's bandwidth-bound
+    // attention launches (a single chain leaves the chip idle between its ~85 dependent launches).
+    const int nbr = decode_branches(batch);
+    if (nbr == 1) {
+      enqueue_layers_cblock(0, batch, s, d_forced != nullptr);
+    } else {
+      const int per = ((batch + nbr - 1) / nbr + 15) / 16 * 16;
+      HIP_CHECK(hipEventRecord(ev_fork_, s));
+      for (int i = 0; i < nbr; ++i) {
+        const int b0 = i * per, nb = std::min(per, batch - b0);
+        if (nb <= 0) break;
+        hipStream_t bs = i == 0 ? s : branch_stream_[i - 1];
+        if (i > 0) HIP_CHECK(hipStreamWaitEvent(bs, ev_fork_, 0));
+        enqueue_layers_cblock(b0, nb, bs, d_forced != nullptr);
+        if (i > 0) {
+          HIP_CHECK(hipEventRecord(ev_join_[i - 1], bs));
+          HIP_CHECK(hipStreamWaitEvent(s, ev_join_[i - 1], 0));
+        }
+      }
+    }
+  }
+  for (int l = 0; l < L && !batched_ln_; ++l) {
     const DecLayerW& w = dec_[l];
     bf16* sk = d_self_k_ + (size_t)l * cap_ * self_stride;
     bf16* sv = d_self_v_ + (size_t)l * cap_ * self_stride;
     const bf16* ck = d_cross_k_ + (size_t)l * cap_ * cross_stride;
     const bf16* cv = d_cross_v_ + (size_t)l * cap_ * cross_stride;
-    if (batched_ln_) {
-      const DecLayerWP& wq = dec_packed_[l];
-      DecCGemmParams c = cgemm(wq.w_qkv, w.b_qkv, 3 * d, d, GEPI_QKV_CACHE, rt_for(3 * d));
-      c.x = d_xdec_; c.ln_w = w.attn_ln_w; c.ln_b = w.attn_ln_b;
-      c.out = d_qdec_; c.k_cache = sk; c.v_cache = sv; c.kv_batch_stride = self_stride;
-      cgo(c);
-      attn(sk, sv, self_stride, -1, Tc / 64);
-      c = cgemm(wq.w_o, w.b_o, d, d, GEPI_RESID, 1);
-      c.a_hi = d_att_[0]; c.a_lo = d_att_[1]; c.out = d_xdec_;
-      cgo(c);
-      if (fuse_cq) {  // the cross-attention workgroups project their own queries (decode_attention_kernel<true>)
-        DecAttnParams a{};
-        a.k = ck; a.v = cv; a.kv_batch_stride = cross_stride; a.part = nullptr; a.n_split = 1;
-        a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = cfg_.n_audio_ctx; a.cap_blocks = t_pad_ / 64; a.state = d_state_;
-        a.done = d_forced ? nullptr : d_done_;
-        a.out_hi = d_att_[0]; a.out_lo = d_att_[1]; a.nbs = nbs_;
-        a.x = d_xdec_; a.ln_w = w.cross_ln_w; a.ln_b = w.cross_ln_b; a.wq = w.w_cq; a.bq = w.b_cq;
-        if (step_mask_ & 2) launch_decode_attention(a, s);
-      } else {
-        c = cgemm(wq.w_cq, w.b_cq, d, d, GEPI_STORE, 1);
-        c.x = d_xdec_; c.ln_w = w.cross_ln_w; c.ln_b = w.cross_ln_b; c.out = d_qdec_;
-        cgo(c);
-        attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64);
-      }
-      c = cgemm(wq.w_co, w.b_co, d, d, GEPI_RESID, 1);
-      c.a_hi = d_att_[0]; c.a_lo = d_att_[1]; c.out = d_xdec_;
-      cgo(c);
-      c = cgemm(wq.w_fc1, w.b_fc1, 4 * d, d, GEPI_GELU, rt_for(4 * d));
-      c.x = d_xdec_; c.ln_w = w.mlp_ln_w; c.ln_b = w.mlp_ln_b; c.out_hi = d_hidp_[0]; c.out_lo = d_hidp_[1];
-      cgo(c);
-      c = cgemm(wq.w_fc2, w.b_fc2, d, 4 * d, GEPI_RESID, 1);
-      c.a_hi = d_hidp_[0]; c.a_lo = d_hidp_[1]; c.out = d_xdec_;
-      cgo(c);
-      continue;
-    }
     ln(w.attn_ln_w, w.attn_ln_b);
     const DecLayerWP& wp = dec_packed_[l];
     DecGemmParams p = base(wp.w_qkv, w.b_qkv, 3 * d, d, d_act_[0], d_act_[1], GEPI_QKV_CACHE);

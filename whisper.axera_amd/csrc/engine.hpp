@@ -80,6 +80,8 @@ class Engine {
                            int* d_argmax);
   void enqueue_decode_step_batched(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits,
                                    long logits_stride, int* d_argmax);
+  void enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced);
+  int decode_branches(int batch) const;
   hipGraphExec_t step_graph(int batch, int max_new);
   int greedy_loop(int batch, int max_new, const int* max_new_clip = nullptr);
   // batch 1: the whole loop as one persistent launch (decode_persistent.hip); returns steps run, -1 if it gave up
@@ -96,6 +98,9 @@ class Engine {
   bool device_set_ = false;
   void* load_stage_ = nullptr;  // staging buffer of load_weights
   hipStream_t own_stream_ = nullptr, user_stream_ = nullptr;
+  static constexpr int kMaxBranches = 4;   // parallel branches of the batched step graph
+  hipStream_t branch_stream_[kMaxBranches - 1] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork_ = nullptr, ev_join_[kMaxBranches - 1] = {nullptr, nullptr, nullptr};
   std::vector<void*> allocs_;       // weights + constants (freed at destruction)
   std::vector<void*> slot_allocs_;  // capacity-dependent buffers
 
