@@ -104,8 +104,21 @@ def test_persistent_gives_up_and_falls_back(built_lib, micro_case, monkeypatch):
         got = e.run_tokens(clip, max_new=20)
         dt = time.time() - t0
         assert got == want
-        assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_decode") == 0
-        assert dt < 30.0, dt
-        assert e.run_tokens(clip, max_new=20) == want  # stays on the fallback path
+        g = lambda k: e.L.AX_WHISPER_GetConfigInt(e.h, k)
+        assert g(b"persistent_decode") == 0 and g(b"persistent_giveups") == 1
+        assert dt < 2.0, dt  # the spin limit is ~50 ms of wall clock, then one fallback decode
+        # the fast path is re-armed after 8 requests on the fallback path (it used to be lost for good)
+        monkeypatch.delenv("AX_WHISPER_PERSIST_FAULT")
+        for i in range(8):
+            assert e.run_tokens(clip, max_new=20) == want
+            assert g(b"persistent_decode") == (0 if i < 7 else 1)
+        assert e.run_tokens(clip, max_new=20) == want  # through the persistent launch again
+        assert g(b"persistent_decode") == 1 and g(b"persistent_giveups") == 1
+        # a second give-up backs off longer (32 requests)
+        monkeypatch.setenv("AX_WHISPER_PERSIST_FAULT", "1")
+        assert e.run_tokens(clip, max_new=20) == want
+        assert g(b"persistent_giveups") == 2 and g(b"persistent_decode") == 0
+        monkeypatch.delenv("AX_WHISPER_PERSIST_FAULT")
+        assert e.run_tokens(clip, max_new=20) == want
     finally:
         e.close()

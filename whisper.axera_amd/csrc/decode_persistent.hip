@@ -41,7 +41,12 @@ constexpr int PT = 1024;           // threads per workgroup, one workgroup per C
 constexpr int NPW = 8, NCW = 8;    // poller waves, compute waves
 constexpr int PL = NPW * 64;       // poller lanes
 constexpr int CT = NCW * 64;       // compute threads
-constexpr int kSpinMax = 1 << 21;  // polls before a lane gives up (~1 s; a real wait is microseconds)
+// A lane gives up on a hand-off by TIME: a real wait is microseconds, so the first kSpinFree polls (about a
+// millisecond) never read the clock; after that the 100 MHz wall clock is sampled every 256 polls and the lane gives up
+// kSpinTicks later (50 ms). A launch whose workgroups cannot all be resident (CUs taken by another process, a CU-masked
+// stream, a partitioned device) therefore costs a request ~50 ms, not a second, before the engine falls back.
+constexpr int kSpinFree = 1024;
+constexpr long long kSpinTicks = 5000000;
 constexpr int kPS = 66;            // attention partial record in LDS: m, l, o[64]
 constexpr int kRec = 80;           // cross-attention partial record as granules: o[64] (four full lines), m, l; 5-line stride
 constexpr int kCrossSplit = 3;     // cross-attention key ranges per head (8 blocks of 64 keys each = 8 compute waves)
@@ -110,7 +115,8 @@ __device__ __forceinline__ bool gather2(__amdgpu_buffer_rsrc_t rs, unsigned tag,
   int ix[NP];
 #pragma unroll
   for (int k = 0; k < NP; ++k) { ix[k] = pidx(k); ok[k] = ix[k] < 0; v[2 * k] = 0u; v[2 * k + 1] = 0u; }
-  for (int spins = 0; spins < kSpinMax; ++spins) {
+  long long t_start = 0;
+  for (int spins = 0;; ++spins) {
     bool all = true;
     u32x4 x[NP];
 #pragma unroll
@@ -122,9 +128,13 @@ __device__ __forceinline__ bool gather2(__amdgpu_buffer_rsrc_t rs, unsigned tag,
       }
     if (all) return false;
     if ((spins & 63) == 63 && *(volatile const int*)ctl) return true;  // a wave of this workgroup gave up
-    if ((spins & 1023) == 1023 && eget(err)) return true;             // another workgroup gave up: leave as well
+    if ((spins & 255) == 255 && spins >= kSpinFree) {
+      if (eget(err)) return true;                                      // another workgroup gave up: leave as well
+      const long long now = wall_clock64();
+      if (t_start == 0) t_start = now;
+      else if (now - t_start > kSpinTicks) return true;
+    }
   }
-  return true;
 }
 
 // Lane `tid` collects granules idx(k) for k < MAXG (idx < 0: none) of epoch `tag`; returns true on give-up.
@@ -134,7 +144,8 @@ __device__ __forceinline__ bool gather(const u64* buf, unsigned tag, unsigned (&
   int ix[MAXG];
 #pragma unroll
   for (int k = 0; k < MAXG; ++k) { ix[k] = idx(k); ok[k] = ix[k] < 0; v[k] = 0u; }
-  for (int spins = 0; spins < kSpinMax; ++spins) {
+  long long t_start = 0;
+  for (int spins = 0;; ++spins) {
     bool all = true;
     u64 x[MAXG];
 #pragma unroll
@@ -146,9 +157,13 @@ __device__ __forceinline__ bool gather(const u64* buf, unsigned tag, unsigned (&
       }
     if (all) return false;
     if ((spins & 63) == 63 && *(volatile const int*)ctl) return true;  // a wave of this workgroup gave up
-    if ((spins & 1023) == 1023 && eget(err)) return true;             // another workgroup gave up: leave as well
+    if ((spins & 255) == 255 && spins >= kSpinFree) {
+      if (eget(err)) return true;                                      // another workgroup gave up: leave as well
+      const long long now = wall_clock64();
+      if (t_start == 0) t_start = now;
+      else if (now - t_start > kSpinTicks) return true;
+    }
   }
-  return true;
 }
 
 
@@ -400,7 +415,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     }                                                                                                                    \
   }
 
-  int tok = p.sot[0];
+  // Launch parameters that are read once per STEP or less (token feedback, teacher forcing, dumps, results) are not
+  // kept in scalar registers for the whole launch: they are re-read from the kernel-argument segment at their use,
+  // through a pointer the compiler cannot see through (so it can neither hoist the loads out of the step loop nor
+  // keep their results live). The d_model-768 instantiation was spilling 185 scalar registers into vector lanes.
+  const __attribute__((address_space(4))) PersistParams* kargs =
+      (const __attribute__((address_space(4))) PersistParams*)__builtin_amdgcn_kernarg_segment_ptr();
+#define AXW_COLD(FIELD) ([&] { auto* kp_ = kargs; asm volatile("" : "+s"(kp_)); return kp_->FIELD; }())
+  int tok = AXW_COLD(sot)[0];
   int n_out = 0, n_done = 0, steps_run = 0;
 
   auto ca_unit_of = [&](int l) -> int {  // cross-attention unit of this workgroup in layer l, or -1
@@ -459,7 +481,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
 #pragma unroll
       for (int k = 0; k < GD; ++k) {
         const int i = el(k);
-        x[k] = i < D ? (float)p.tok_emb[(long)tok * D + i] + p.pos[(long)step * D + i] : 0.f;
+        x[k] = i < D ? (float)AXW_COLD(tok_emb)[(long)tok * D + i] + AXW_COLD(pos)[(long)step * D + i] : 0.f;
       }
       ln_prefetch(p.fl + DecArena::F_ATTN_LN_W * D, p.fl + DecArena::F_ATTN_LN_B * D);
 
@@ -580,7 +602,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_TL(7)
           AXW_LN_STAGE(y, true, fail, 0x700 + l)
           if (l + 1 < L) ln_prefetch(FL + DecArena::f_stride(D) + DecArena::F_ATTN_LN_W * D, FL + DecArena::f_stride(D) + DecArena::F_ATTN_LN_B * D);
-          else ln_prefetch(p.ln_w, p.ln_b);
+          else ln_prefetch(AXW_COLD(ln_w), AXW_COLD(ln_b));
           AXW_STAMP(12)
           AXW_TL(8)
         }
@@ -605,7 +627,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
       steps_run = step + 1;
       asm volatile("" : "+v"(tid));
       if (step < 3) {  // SOT steps: feed the next forced token, logits are discarded (Whisper.cpp:214-217)
-        tok = p.sot[step + 1];
+        tok = AXW_COLD(sot)[step + 1];
         continue;
       }
       // ---- final LayerNorm for the vocabulary projection, then merge the argmax partials of every workgroup
@@ -637,15 +659,15 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         if (am_v[w2] > cv || (am_v[w2] == cv && am_i[w2] < best_idx)) { cv = am_v[w2]; best_idx = am_i[w2]; }
       // no logit compared greater than -inf (all NaN / -inf: non-finite audio): std::max_element returns index 0
       // (Whisper.cpp:42-45); never let the "no candidate" index reach the embedding lookup
-      if ((unsigned)best_idx >= (unsigned)p.n_vocab) best_idx = 0;
+      if ((unsigned)best_idx >= (unsigned)AXW_COLD(n_vocab)) best_idx = 0;
       wg_barrier();  // B5: am_v/am_i are free again
       const int gi = step - 3;
-      if (p.forced) {
-        if (wg == 0 && tid == 0 && p.argmax_dump && gi <= p.n_forced) p.argmax_dump[gi] = best_idx;
-        if (gi < p.n_forced) tok = p.forced[gi];
+      if (AXW_COLD(forced)) {
+        if (wg == 0 && tid == 0 && AXW_COLD(argmax_dump) && gi <= AXW_COLD(n_forced)) AXW_COLD(argmax_dump)[gi] = best_idx;
+        if (gi < AXW_COLD(n_forced)) tok = AXW_COLD(forced)[gi];
       } else {
-        if (best_idx == p.eot || step + 1 >= p.n_ctx || n_out >= p.max_new) { n_done = 1; break; }
-        if (wg == 0 && tid == 0) p.out_ids[n_out] = best_idx;
+        if (best_idx == AXW_COLD(eot) || step + 1 >= AXW_COLD(n_ctx) || n_out >= AXW_COLD(max_new)) { n_done = 1; break; }
+        if (wg == 0 && tid == 0) AXW_COLD(out_ids)[n_out] = best_idx;
         ++n_out;
         tok = best_idx;
       }
@@ -852,7 +874,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         }
         // next consumer of the residual stream: the next layer's QKV rows, the vocabulary projection, or the next step
         if (l + 1 < L) ra.prefetch(w_qkv + DecArena::w_stride(D), b_qkv + DecArena::f_stride(D), D, 3 * D, wg, P, ctid, pk_qkv);
-        else if (step >= 3) ra.prefetch(p.tok_emb, nullptr, D, p.n_vocab, wg, P, ctid);
+        else if (step >= 3) ra.prefetch(AXW_COLD(tok_emb), nullptr, D, AXW_COLD(n_vocab), wg, P, ctid);
         else ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid, pk_qkv);
         kv_piece(13, 16);
         AXW_STAMP(29)
@@ -862,14 +884,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
       steps_run = step + 1;
       asm volatile("" : "+v"(ctid));
       if (step < 3) {
-        tok = p.sot[step + 1];
+        tok = AXW_COLD(sot)[step + 1];
         continue;
       }
       // ---- logits = token_embedding . ln(x)  (tied embedding, export_onnx.py:364-385) + argmax (first max wins, Whisper.cpp:42-45)
       {
         constexpr int SD = CT / LD;
         const int lane = ctid & 63, cw = __builtin_amdgcn_readfirstlane(ctid >> 6);
-        const int N = p.n_vocab;
+        const int N = AXW_COLD(n_vocab);
         const int slot = ctid / LD, j = ctid % LD;
         AXW_BARRIER_CHECK(0x900)
         wg_barrier();
@@ -886,7 +908,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         }
         float bv = -INFINITY;
         int bi = 0x7fffffff;
-        float* dump = p.logits_dump ? p.logits_dump + (long)(step - 3) * N : nullptr;
+        float* dump = AXW_COLD(logits_dump) ? AXW_COLD(logits_dump) + (long)(step - 3) * N : nullptr;
         const int r0 = ra.r0, r1 = ra.r1;
         auto consume = [&](const u32x4 (&wr)[CD], int row) {
           float acc;
@@ -901,14 +923,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           u32x4 wn[CD];
           {
             const int nrow = r0 + slot + SD;
-            rows_load<LD, CD>(wn, p.tok_emb, D, nrow < r1 ? nrow : r0, ctid);
+            rows_load<LD, CD>(wn, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid);
           }
           for (int row = r0 + slot; row < r1; row += SD) {
             u32x4 wr[CD];
 #pragma unroll
             for (int i = 0; i < CD; ++i) { wr[i] = ra.w[i]; ra.w[i] = wn[i]; }
             const int nrow = row + 2 * SD;
-            rows_load<LD, CD>(wn, p.tok_emb, D, nrow < r1 ? nrow : r0, ctid);
+            rows_load<LD, CD>(wn, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid);
             consume(wr, row);
           }
         } else {  // wide rows: one pass ahead (register budget)
@@ -917,7 +939,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
 #pragma unroll
             for (int i = 0; i < CD; ++i) wr[i] = ra.w[i];
             const int nrow = row + SD;
-            rows_load<LD, CD>(ra.w, p.tok_emb, D, nrow < r1 ? nrow : r0, ctid);
+            rows_load<LD, CD>(ra.w, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid);
             consume(wr, row);
           }
         }
@@ -949,13 +971,13 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
       int best_idx = am_i[0];
       for (int w2 = 1; w2 < NPW; ++w2)
         if (am_v[w2] > cv || (am_v[w2] == cv && am_i[w2] < best_idx)) { cv = am_v[w2]; best_idx = am_i[w2]; }
-      if ((unsigned)best_idx >= (unsigned)p.n_vocab) best_idx = 0;  // as in the pollers' copy of this merge
+      if ((unsigned)best_idx >= (unsigned)AXW_COLD(n_vocab)) best_idx = 0;  // as in the pollers' copy of this merge
       wg_barrier();  // B5
       const int gi = step - 3;
-      if (p.forced) {
-        if (gi < p.n_forced) tok = p.forced[gi];
+      if (AXW_COLD(forced)) {
+        if (gi < AXW_COLD(n_forced)) tok = AXW_COLD(forced)[gi];
       } else {
-        if (best_idx == p.eot || step + 1 >= p.n_ctx || n_out >= p.max_new) { n_done = 1; break; }
+        if (best_idx == AXW_COLD(eot) || step + 1 >= AXW_COLD(n_ctx) || n_out >= AXW_COLD(max_new)) { n_done = 1; break; }
         ++n_out;
         tok = best_idx;
       }
@@ -965,13 +987,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no LDS-DMA may still be in flight when the workgroup's LDS is released
   if (PROF) {
     __syncthreads();
-    if (tid < 64) p.prof[(long)wg * 64 + tid] = prof_acc[tid];
+    if (tid < 64) AXW_COLD(prof)[(long)wg * 64 + tid] = prof_acc[tid];
   }
   if (wg == 0 && tid == 0) {
-    p.n_out[0] = n_out;
-    p.state->step = steps_run;
-    p.state->n_done = n_done;
+    AXW_COLD(n_out)[0] = n_out;
+    AXW_COLD(state)->step = steps_run;
+    AXW_COLD(state)->n_done = n_done;
   }
+#undef AXW_COLD
 #undef AXW_BARRIER_CHECK
 #undef AXW_STAMP
 #undef AXW_TL

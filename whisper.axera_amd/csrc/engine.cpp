@@ -90,6 +90,7 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
     }
   }
   cfg_.ints["persistent_decode"] = persistent_ok_ ? 1 : 0;  // visible through AX_WHISPER_GetConfigInt
+  cfg_.ints["persistent_giveups"] = 0;
   {  // batched decode as clip-block GEMMs with LayerNorm prologue / residual epilogue (enqueue_decode_step_batched)
     const char* e = getenv("AX_WHISPER_BATCHED_LN");
     const int d = cfg_.n_text_state;
@@ -891,6 +892,30 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
   if (step_mask_ & 4) launch_advance(a, s);
 }
 
+// The persistent launch needs every workgroup resident at once; when it gives up (CUs taken by somebody else) the
+// engine serves the next `backoff` one-clip requests through the launch-per-phase path and then tries again: 8, 32,
+// 128, ... requests (capped at 4096), back to 8 after a success. The fast path is never lost for good on a shared box.
+bool Engine::persistent_usable() {
+  if (!persistent_ok_) return false;
+  if (persist_skip_ > 0) {
+    --persist_skip_;
+    if (persist_skip_ == 0) cfg_.ints["persistent_decode"] = 1;  // the next request re-arms it
+    return false;
+  }
+  return true;
+}
+void Engine::persistent_gave_up() {
+  persist_backoff_ = std::min(persist_backoff_ ? persist_backoff_ * 4 : 8, 4096);
+  persist_skip_ = persist_backoff_;
+  ++persist_giveups_;
+  cfg_.ints["persistent_decode"] = 0;
+  cfg_.ints["persistent_giveups"] = persist_giveups_;
+}
+void Engine::persistent_succeeded() {
+  persist_backoff_ = 0;
+  cfg_.ints["persistent_decode"] = 1;
+}
+
 hipGraphExec_t Engine::step_graph(int batch, int max_new) {
   const long key = ((long)batch * 1024 + max_new) * 16 + step_mask_;
   auto it = graphs_.find(key);
@@ -917,12 +942,10 @@ int Engine::greedy_loop(int batch, int max_new, const int* max_new_clip) {
   const int Tc = cfg_.n_text_ctx;
   if (max_new <= 0 || max_new > Tc - 4) max_new = Tc - 4;
   if (batch == 1 && max_new_clip && max_new_clip[0] > 0) max_new = std::min(max_new, max_new_clip[0]);
-  if (batch == 1 && persistent_ok_) {
+  if (batch == 1 && persistent_usable()) {
     const int steps = run_persistent(max_new, nullptr, 0, nullptr, nullptr);
-    if (steps >= 0) return steps;
-    // the persistent launch gave up (it needs every workgroup resident at once): use the launch-per-phase path from now on
-    persistent_ok_ = false;
-    cfg_.ints["persistent_decode"] = 0;
+    if (steps >= 0) { persistent_succeeded(); return steps; }
+    persistent_gave_up();  // this utterance (and the next few) take the launch-per-phase path
   }
   reset_decode_state(batch, max_new_clip);
   hipGraphExec_t g = step_graph(batch, max_new);
@@ -1128,9 +1151,9 @@ void Engine::decode_forced(int batch, const int32_t* forced, int n_forced, float
   if (logits) HIP_CHECK(hipMalloc((void**)&d_logits, (size_t)batch * rows * nv * 4));
   if (n_forced) HIP_CHECK(hipMemcpy(d_forced, forced, (size_t)batch * n_forced * 4, hipMemcpyHostToDevice));
   bool done = false;
-  if (batch == 1 && persistent_ok_) {
-    if (run_persistent(cfg_.n_text_ctx, d_forced, n_forced, d_logits, d_arg) >= 0) done = true;
-    else { persistent_ok_ = false; cfg_.ints["persistent_decode"] = 0; }
+  if (batch == 1 && persistent_usable()) {
+    if (run_persistent(cfg_.n_text_ctx, d_forced, n_forced, d_logits, d_arg) >= 0) { done = true; persistent_succeeded(); }
+    else persistent_gave_up();
   }
   if (!done) reset_decode_state(batch);
   for (int st = 0; !done && st < 4 + n_forced; ++st) {

@@ -141,6 +141,10 @@ class Engine {
   // persistent batch-1 decode
   bool batched_ln_ = false;         // batched decode: clip-block GEMM sequence (AX_WHISPER_BATCHED_LN=0 disables)
   bool persistent_ok_ = false;      // model shape supported and not disabled (AX_WHISPER_DECODE=graph)
+  int persist_skip_ = 0, persist_backoff_ = 0, persist_giveups_ = 0;  // re-arming after a give-up (engine.cpp)
+  bool persistent_usable();
+  void persistent_gave_up();
+  void persistent_succeeded();
   int persist_grid_ = 0;
   u64* d_gran_ = nullptr; size_t gran_bytes_ = 0;
   std::map<long, hipGraphExec_t> graphs_;  // key: batch * 1024 + max_new
