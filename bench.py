@@ -44,6 +44,8 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (weak scaling); 0 = 1 at N=1, 64 at N>1")
     ap.add_argument("--model", default="small")
     ap.add_argument("--max-new", type=int, default=0, help="0 = until eot or context (444 ids)")
+    ap.add_argument("--dtype", default="", choices=["", "bf16", "fp16"],
+                    help="16-bit storage / MFMA operand type; default: bf16, fp16 for --model turbo (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch64", action="store_true", help="N=1, batch 1 only: skip the batch-64 leg")
     ap.add_argument("--model-dir", default=os.environ.get("AXW_BENCH_MODEL_DIR", "/tmp/axw_bench_models"))
@@ -201,7 +203,7 @@ def cpu_model_string():
     return "unknown"
 
 
-def cpu_baseline(args, dims, mdir, clip, gpu_ids, dec_steps):
+def cpu_baseline(args, dims, mdir, clip, gpu_ids, dec_steps, dtype="bf16"):
     """The CPU oracle ("port") on this box's host cores, one clip of the headline workload, bounded to ~20 s:
     all-core figure (the reported value) + a single-thread figure + the front-end alone."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -214,7 +216,8 @@ def cpu_baseline(args, dims, mdir, clip, gpu_ids, dec_steps):
     threads = min(ncpu, 32)
     weights = modelgen.read_safetensors(os.path.join(mdir, f"{args.model}.safetensors"))
     cfg = modelgen.make_config(args.model, dims)
-    orc = oracle.Oracle(cfg, weights, bf16_policy=True, threads=threads)
+    policy = 2 if dtype == "fp16" else True
+    orc = oracle.Oracle(cfg, weights, bf16_policy=policy, threads=threads)
     max_new = args.max_new if args.max_new > 0 else 444
     cpu_new = min(max_new, 96)  # bounded sample: full front-end + encoder, 4 + 96 decoder steps
     t1 = time.perf_counter()
@@ -236,7 +239,7 @@ def cpu_baseline(args, dims, mdir, clip, gpu_ids, dec_steps):
            "cpu_model": cpu_model_string(), "host_cores": ncpu,
            "sample": f"clip 0: front-end + encoder measured ({t_enc:.2f} s) + {4 + len(cpu_ids)} decoder "
                      f"steps measured ({t_dec_step * 1e3:.1f} ms/step) scaled to {dec_steps:.0f} steps; "
-                     f"CPU oracle (bf16 policy), {threads} OpenMP threads of {ncpu}",
+                     f"CPU oracle ({dtype} policy), {threads} OpenMP threads of {ncpu}",
            "ids_agree_prefix": f"{agree}/{len(cpu_ids)}"}
     # single thread: the front-end in full; the encoder from 1- and 2-layer copies of the model (linear in depth);
     # 4 + 4 decoder steps of the full-depth decoder
@@ -247,7 +250,7 @@ def cpu_baseline(args, dims, mdir, clip, gpu_ids, dec_steps):
     enc_t = []
     for nl in (1, 2):
         c2 = dict(cfg, n_audio_layer=nl, n_text_layer=1)
-        o2 = oracle.Oracle(c2, weights, bf16_policy=True, threads=1)
+        o2 = oracle.Oracle(c2, weights, bf16_policy=policy, threads=1)
         t4 = time.perf_counter()
         o2.encoder(mel)
         enc_t.append(time.perf_counter() - t4)
@@ -300,6 +303,7 @@ def run_rank(args) -> int:
     use_dist = world > 1 or os.environ.get("AXW_BENCH_FORCE_DIST") == "1"
     B = args.batch if args.batch > 0 else (1 if world == 1 else 64)
     dims = modelgen.DIMS[args.model]
+    dtype = args.dtype or ("fp16" if args.model == "turbo" else "bf16")
 
     import torch
     import torch.distributed as dist
@@ -351,13 +355,16 @@ def run_rank(args) -> int:
     else:
         import whisper_axera_amd as wa
 
-        # ---- synthetic-weight model directory (no weights exist in the reference or this image)
-        mdir = os.path.join(args.model_dir, args.model)
+        # ---- synthetic-weight model directory (no weights exist in the reference or this image); the weights file's
+        #      dtype (BF16 / F16) selects the engine build
+        model_root = args.model_dir + ("_f16" if dtype == "fp16" else "")
+        mdir = os.path.join(model_root, args.model)
         if local_rank == 0 and not os.path.exists(os.path.join(mdir, f"{args.model}.safetensors")):
-            modelgen.write_model_dir(args.model_dir, args.model, dims, seed=0,
+            modelgen.write_model_dir(model_root, args.model, dims, seed=0, dtype="F16" if dtype == "fp16" else "BF16",
                                      tiktoken_path=os.path.join(ROOT, "tests", "golden", "multilingual.tiktoken"))
         barrier()
-        eng = wa.Whisper(args.model, args.model_dir, "zh", device=dev_index, max_batch=B)
+        eng = wa.Whisper(args.model, model_root, "zh", device=dev_index, max_batch=B)
+        assert eng.L.AX_WHISPER_GetConfigInt(eng.h, b"fp16") == (1 if dtype == "fp16" else 0)
         stream = torch.cuda.current_stream(dev)
         eng.set_stream(stream.cuda_stream)
         d_pcm = torch.from_numpy(clips).to(dev)
@@ -391,7 +398,6 @@ def run_rank(args) -> int:
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
     clips_per_s = world * B * args.steps / dt
-    dtype = "bf16"
 
     out = {
         "metric": "clips_per_sec (30 s clips, greedy decode, whisper-%s)" % args.model,
@@ -433,7 +439,7 @@ def run_rank(args) -> int:
             B2 = 64
             clips2 = np.stack([modelgen.synth_clip(i, N_SAMP) for i in range(B2)])
             d_pcm2 = torch.from_numpy(clips2).to(dev)
-            eng2 = wa.Whisper(args.model, args.model_dir, "zh", device=dev_index, max_batch=B2)
+            eng2 = wa.Whisper(args.model, model_root, "zh", device=dev_index, max_batch=B2)
             eng2.set_stream(torch.cuda.current_stream(dev).cuda_stream)
             st2 = {"frontend_ms": 0.0, "encoder_ms": 0.0, "decode_ms": 0.0, "steps": 0}
 
@@ -461,7 +467,7 @@ def run_rank(args) -> int:
             eng2.close()
         # ---- CPU baseline: the oracle ("port") on this box's host cores, one clip of the same workload
         if rank == 0 and not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, dims, mdir, clips[0], ids[0], dec_steps)
+            out["cpu_baseline"] = cpu_baseline(args, dims, mdir, clips[0], ids[0], dec_steps, dtype)
 
     if use_dist:
         dist.destroy_process_group()

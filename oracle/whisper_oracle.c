@@ -12,6 +12,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <immintrin.h>
 #include <stdio.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -41,8 +42,19 @@ float orc_bf16_round(float x) {
 void orc_bf16_round_array(float *x, long n) {
   for (long i = 0; i < n; ++i) x[i] = orc_bf16_round(x[i]);
 }
+/* IEEE binary16 round-to-nearest-even (F16C); overflow goes to inf exactly as the device's v_cvt_f16_f32 does */
+float orc_f16_round(float x) { return _cvtsh_ss(_cvtss_sh(x, _MM_FROUND_TO_NEAREST_INT)); }
+/* policy 1: the engine's bfloat16 build, policy 2: its IEEE-half build (same storage points, other 16-bit type) */
+static inline float round16(const orc_policy *p, float x) {
+  return p->bf16_policy == 2 ? orc_f16_round(x) : orc_bf16_round(x);
+}
 static void maybe_round(const orc_policy *p, float *x, long n) {
-  if (p && p->bf16_policy) orc_bf16_round_array(x, n);
+  if (!p || !p->bf16_policy) return;
+  if (p->bf16_policy == 2) {
+    for (long i = 0; i < n; ++i) x[i] = orc_f16_round(x[i]);
+  } else {
+    orc_bf16_round_array(x, n);
+  }
 }
 
 /* ---------------------------------------------------------------- front-end */
@@ -328,7 +340,7 @@ static void attention_full(const orc_policy *p, int T, int d, int H, const float
       float inv = (float)(1.0 / sum);
       if (p && p->bf16_policy) {
         /* engine: P is narrowed to bf16 for the PV MFMA, the row sum stays fp32 */
-        for (int j = 0; j < T; ++j) s[j] = orc_bf16_round(s[j]) * inv;
+        for (int j = 0; j < T; ++j) s[j] = round16(p, s[j]) * inv;
       } else {
         for (int j = 0; j < T; ++j) s[j] *= inv;
       }

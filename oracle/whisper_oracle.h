@@ -37,7 +37,8 @@ extern "C" {
 /* Rounding policy: where the GPU engine narrows to bf16, the oracle can narrow at the
  * same points so that the only remaining differences are fp32 summation order and
  * libm-vs-device transcendental ulps. 0 = pure fp32 everywhere (the reference's ONNX fp32
- * lineage), 1 = mirror the engine's bf16 storage points. */
+ * lineage), 1 = mirror the engine's bf16 storage points, 2 = the same storage points in IEEE
+ * half (the engine's fp16 build: BASELINE configs[3] "Whisper-turbo fp16"). */
 typedef struct {
   int bf16_policy;
 } orc_policy;
@@ -111,6 +112,7 @@ int orc_transcribe(const orc_model *m, const orc_policy *p, const float *pcm, in
 
 /* bf16 round-to-nearest-even of an fp32 value (returned as fp32). */
 float orc_bf16_round(float x);
+float orc_f16_round(float x);
 void orc_bf16_round_array(float *x, long n);
 
 void orc_set_threads(int n);

@@ -52,18 +52,25 @@ def oracle_mod():
 class ModelCase:
     """A seeded synthetic model on disk + the matching oracle objects."""
 
-    def __init__(self, tmpdir, model_type, seed):
+    def __init__(self, tmpdir, model_type, seed, dtype="BF16"):
+        """dtype "BF16": weights representable in bfloat16, engine in its bf16 build; "F16": weights representable in
+        IEEE half, stored as F16, engine in its fp16 build. Either way both sides hold identical weight values and
+        `oracle_bf16` is the oracle that narrows at the engine's 16-bit storage points (in that engine's type)."""
         import modelgen
         import oracle
 
-        self.model_type, self.seed, self.root = model_type, seed, str(tmpdir)
+        self.model_type, self.seed, self.root, self.dtype = model_type, seed, str(tmpdir), dtype
         self.dims = modelgen.DIMS[model_type]
-        self.weights = modelgen.synth_weights(self.dims, seed)
+        if dtype == "F16":
+            w = modelgen.synth_weights(self.dims, seed, bf16=False)
+            self.weights = {k: v.astype(np.float16).astype(np.float32) for k, v in w.items()}
+        else:
+            self.weights = modelgen.synth_weights(self.dims, seed)
         self.cfg = modelgen.make_config(model_type, self.dims)
-        modelgen.write_model_dir(self.root, model_type, self.dims, weights=self.weights,
+        modelgen.write_model_dir(self.root, model_type, self.dims, weights=self.weights, dtype=dtype,
                                  tiktoken_path=os.path.join(GOLDEN, "multilingual.tiktoken"))
         self.oracle_fp32 = oracle.Oracle(self.cfg, self.weights, bf16_policy=False)
-        self.oracle_bf16 = oracle.Oracle(self.cfg, self.weights, bf16_policy=True)
+        self.oracle_bf16 = oracle.Oracle(self.cfg, self.weights, bf16_policy=2 if dtype == "F16" else True)
 
 
 @pytest.fixture(scope="session")

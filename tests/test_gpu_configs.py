@@ -1,7 +1,7 @@
 """GPU: the BASELINE.json configurations at their STATED workload (these were only builder-run before).
 
   configs[2]  Whisper-small, batch 64, 30 s clips     -> test_config2_small_batch64
-  configs[3]  Whisper-turbo (d 1280, 32+4 layers, 128 mels), batch 16 -> test_config3_turbo_batch16
+  configs[3]  Whisper-turbo fp16 (d 1280, 32+4 layers, 128 mels), batch 16 -> test_config3_turbo_fp16_batch16
   a14         exact logit ties: every decode path returns the LOWER index (Whisper.cpp:42-45)
   a15         per-clip exit from the greedy loop (Whisper.cpp:219-222) at batch: a ragged batch
 
@@ -109,13 +109,14 @@ def test_ragged_batch_leaves_the_loop_clip_by_clip(built_lib, small_case):
         e.close()
 
 
-def test_config3_turbo_batch16(built_lib, oracle_mod, tmp_path_factory):
+def test_config3_turbo_fp16_batch16(built_lib, oracle_mod, tmp_path_factory):
     """Full-size large-v3-turbo dims (d 1280, 20 heads, 32 encoder + 4 decoder layers, 128 mels, 51866 ids, 100
-    languages), batch 16; dtype as DESIGN.md §2 states for configs[3]."""
-    case = ModelCase(tmp_path_factory.mktemp("models_turbo_cfg"), "turbo", 3)
+    languages), batch 16, in fp16 as BASELINE configs[3] states: F16 weights file -> the engine's IEEE-half build."""
+    case = ModelCase(tmp_path_factory.mktemp("models_turbo_cfg"), "turbo", 3, dtype="F16")
     B = 16
     e = built_lib.Whisper("turbo", case.root, "zh", device=0, max_batch=B)
     try:
+        assert e.L.AX_WHISPER_GetConfigInt(e.h, b"fp16") == 1
         assert (e.n_mels, e.n_vocab, e.n_text_state, e.n_text_layer) == (128, 51866, 1280, 4)
         _batch_vs_single_and_oracle(e, case, oracle_mod, _clips(B), 12, oracle_clips=(0, 15), n_mels=128)
     finally:

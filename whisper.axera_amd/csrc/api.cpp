@@ -18,11 +18,14 @@
 #include <string>
 #include <vector>
 
-#include "engine.hpp"
+#include <hip/hip_runtime.h>
+
+#include "iengine.hpp"
 #include "host_io.hpp"
+#include "t2s.hpp"
 #include "multi_device.hpp"
 
-using axw::Engine;
+using Engine = axw::IEngine;
 
 namespace {
 thread_local std::string g_init_error;
@@ -75,14 +78,34 @@ int guarded_group(AX_WHISPER_HANDLE handle, F&& f) {
   }
 }
 
+int visible_devices() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    throw std::runtime_error("no HIP device visible: the MI355X engine has no CPU fallback");
+  return n;
+}
 AX_WHISPER_HANDLE init_devices(const char* model_type, const char* model_path, const char* language,
                                const std::vector<int>& devices, int max_batch) {
   std::unique_ptr<Handle> h(new Handle());
   const int G = (int)devices.size();
+  (void)visible_devices();  // no GPU: fail with that message, before any file is touched (there is no CPU fallback)
   std::vector<std::unique_ptr<Engine>> engines(G);
   // engines load side by side (one host thread per device): each uploads its own replica of the weights
+  // 16-bit storage type of the engine: AX_WHISPER_DTYPE=bf16|fp16 when set, else the dtype of the weights file
+  // (F16 -> half; BF16 and F32 -> bfloat16)
+  const std::string wfile = std::string(model_path) + "/" + model_type + "/" + model_type + ".safetensors";
+  bool f16 = false;
+  if (const char* e = getenv("AX_WHISPER_DTYPE")) {
+    const std::string v = e;
+    if (v == "fp16" || v == "f16" || v == "half") f16 = true;
+    else if (v != "bf16") throw std::runtime_error("AX_WHISPER_DTYPE must be bf16 or fp16");
+  } else {
+    axw::SafeTensors st(wfile);
+    f16 = st.get("decoder.token_embedding.weight").dtype == "F16";
+  }
   axw::run_sharded(G, G, [&](int w, int, int) {
-    engines[w].reset(new Engine(model_type, model_path, language, devices[w], max_batch));
+    engines[w].reset(f16 ? axw::make_engine_f16(model_type, model_path, language, devices[w], max_batch)
+                         : axw::make_engine_bf16(model_type, model_path, language, devices[w], max_batch));
   });
   for (auto& e : engines) h->group.add(std::move(e));
   return h.release();  // a throw above destroys every engine already built (the reference leaks: ax_whisper_api.cpp:49-53)
@@ -102,12 +125,6 @@ AX_WHISPER_HANDLE init_guarded(F&& f) {
   }
 }
 
-int visible_devices() {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
-    throw std::runtime_error("no HIP device visible: the MI355X engine has no CPU fallback");
-  return n;
-}
 }  // namespace
 
 extern "C" {
@@ -264,7 +281,7 @@ AX_WHISPER_API const char* AX_WHISPER_LastError(AX_WHISPER_HANDLE handle) {
 }
 
 AX_WHISPER_API int AX_WHISPER_SetStream(AX_WHISPER_HANDLE handle, void* hip_stream) {
-  return guarded(handle, [&](Engine& e) { e.set_stream(static_cast<hipStream_t>(hip_stream)); });
+  return guarded(handle, [&](Engine& e) { e.set_stream(hip_stream); });
 }
 
 AX_WHISPER_API int AX_WHISPER_ComputeMel(AX_WHISPER_HANDLE handle, const float* pcm, int num_samples, float* mel_out) {

@@ -4,11 +4,35 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace axw {
+// ------------------------------------------------------------------ the 16-bit storage / MFMA operand type
+// Every kernel file and the engine are compiled TWICE (Makefile): -DAXW_F16=0 -> bfloat16 (the default; what
+// BASELINE configs[1], [2], [4] name), -DAXW_F16=1 -> IEEE half (configs[3]: "Whisper-turbo fp16"; also the dtype
+// OpenAI's and HF's checkpoints are published in, so their weights load without a rounding step). Everything that
+// depends on the type lives in the inline namespace axw::bf / axw::hf — same source, two sets of symbols — and the C ABI
+// (api.cpp) picks one per model from the dtype of its weights file. `h16` is that type: weights, MFMA operands,
+// K/V caches and the (hi, lo) activation pairs of the batched decoder. Accumulation, LayerNorm, softmax, GELU, the
+// residual stream and the logits are fp32 in both builds.
+#ifndef AXW_F16
+#define AXW_F16 0
+#endif
+#if AXW_F16
+#define AXW_NS hf
+#else
+#define AXW_NS bf
+#endif
 
-typedef __bf16 bf16;
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+namespace axw {
+inline namespace AXW_NS {
+
+#if AXW_F16
+typedef _Float16 h16;
+constexpr const char* kDtypeName = "fp16";
+#else
+typedef __bf16 h16;
+constexpr const char* kDtypeName = "h16";
+#endif
+typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-byte staging register (HIP's uint4 struct can end up in scratch)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -22,6 +46,20 @@ constexpr int kKeyBlk = 64;        // keys per block of the decode K layout
 
 // ------------------------------------------------------------------ device helpers
 #ifdef __HIPCC__
+// the two h16 values packed in one dword (element 2i in the low half), widened to fp32: one shift / one mask for
+// bfloat16; v_cvt_f32_f16 (folded into v_fma_mix_f32 where the value feeds an FMA) for half
+#if AXW_F16
+typedef _Float16 axw_half2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float h16lo(unsigned u) { return (float)__builtin_bit_cast(axw_half2, u)[0]; }
+__device__ __forceinline__ float h16hi(unsigned u) { return (float)__builtin_bit_cast(axw_half2, u)[1]; }
+#define AXW_MFMA_32x32x16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+#define AXW_MFMA_16x16x32(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C, 0, 0, 0)
+#else
+__device__ __forceinline__ float h16lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float h16hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+#define AXW_MFMA_32x32x16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+#define AXW_MFMA_16x16x32(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
+#endif
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -34,8 +72,8 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 // exact-erf GELU (nn.GELU default; export_onnx.py:158-159 F.gelu)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-// The same GELU with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. far below one bf16 ulp of the
-// result): 1 rcp + 1 exp + 6 FMA instead of libm erff's ~60 instructions. Used where the result is narrowed to bf16.
+// The same GELU with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. far below one h16 ulp of the
+// result): 1 rcp + 1 exp + 6 FMA instead of libm erff's ~60 instructions. Used where the result is narrowed to h16.
 __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
   const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
@@ -69,19 +107,19 @@ __device__ __forceinline__ f32x2_t gelu_erf_fast2(f32x2_t x) {
 #endif
 
 // ------------------------------------------------------------------ GEMM (encoder)
-// C[M,N] = A[M,K] (bf16, row stride lda, rows may overlap) * W[N,K]^T (bf16) with a fused epilogue.
+// C[M,N] = A[M,K] (h16, row stride lda, rows may overlap) * W[N,K]^T (h16) with a fused epilogue.
 enum GemmEpilogue : int {
-  EPI_BIAS_BF16 = 0,       // C bf16 = acc + bias
-  EPI_BIAS_GELU_BF16 = 1,  // C bf16 = gelu(acc + bias)
+  EPI_BIAS_BF16 = 0,       // C h16 = acc + bias
+  EPI_BIAS_GELU_BF16 = 1,  // C h16 = gelu(acc + bias)
   EPI_GELU_POS_F32 = 2,    // C f32  = gelu(acc + bias) + aux[m][n]      (conv2 + positional embedding)
   EPI_RESID_F32 = 3,       // C f32 += acc + bias                        (out-proj / FFN2 residual)
-  EPI_QKV = 4,             // n<d: Q bf16 [m][d]; d<=n<2d: K bf16 [m][d]; else V^T bf16 [h][64][Tp]
+  EPI_QKV = 4,             // n<d: Q h16 [m][d]; d<=n<2d: K h16 [m][d]; else V^T h16 [h][64][Tp]
   EPI_CROSS_KV = 5,        // decode layouts: K blocked [l][b][h][blk][8][64][8], V [l][b][h][Tp][64]
 };
 
 struct GemmParams {
-  const bf16* A; long lda; long a_batch_stride;
-  const bf16* W;                     // [N][K]
+  const h16* A; long lda; long a_batch_stride;
+  const h16* W;                     // [N][K]
   const float* bias;                 // [N] fp32
   void* C; long ldc; long c_batch_stride;
   const float* aux;                  // EPI_GELU_POS_F32: pos [M][N]
@@ -98,11 +136,11 @@ struct GemmParams {
 };
 void launch_gemm(const GemmParams& p, hipStream_t s);
 
-// fp32 [rows][d] -> bf16 [rows][d] LayerNorm (eps 1e-5)
-void launch_layernorm_bf16(const float* x, const float* g, const float* b, bf16* y, long rows, int d, hipStream_t s);
+// fp32 [rows][d] -> h16 [rows][d] LayerNorm (eps 1e-5)
+void launch_layernorm_bf16(const float* x, const float* g, const float* b, h16* y, long rows, int d, hipStream_t s);
 
-// encoder self-attention (non-causal, T keys), Q/K bf16 [B][T][d], V^T bf16 [B][H][64][Tp] -> O bf16 [B][T][d]
-void launch_encoder_attention(const bf16* q, const bf16* k, const bf16* vt, bf16* o, int batch, int T, int t_pad,
+// encoder self-attention (non-causal, T keys), Q/K h16 [B][T][d], V^T h16 [B][H][64][Tp] -> O h16 [B][T][d]
+void launch_encoder_attention(const h16* q, const h16* k, const h16* vt, h16* o, int batch, int T, int t_pad,
                               int d_model, int n_head, hipStream_t s);
 
 // ------------------------------------------------------------------ front-end
@@ -118,12 +156,12 @@ struct FrontendParams {
   float* logmel;           // device scratch [batch][n_mels][3008]
   unsigned* gmax;          // device [batch] (float bits, ordered-int encoded)
   float* mel_ref;          // device [batch][n_mels][3000] f32 (reference layout) or nullptr
-  bf16* mel_tm;            // device [batch][mel_rows][n_mels] bf16 time-major, row 0 = left pad, or nullptr
+  h16* mel_tm;            // device [batch][mel_rows][n_mels] h16 time-major, row 0 = left pad, or nullptr
   int mel_rows;
   int max_frames;          // frames computed per clip (<= 3001)
 };
 void launch_frontend(const FrontendParams& p, hipStream_t s);
-void launch_mel_to_tm(const float* mel_ref, bf16* mel_tm, int batch, int n_mels, int mel_rows, hipStream_t s);
+void launch_mel_to_tm(const float* mel_ref, h16* mel_tm, int batch, int n_mels, int mel_rows, hipStream_t s);
 
 // ------------------------------------------------------------------ decoder
 struct DecState {          // device-resident loop state, one per engine
@@ -134,11 +172,11 @@ struct DecState {          // device-resident loop state, one per engine
 
 struct DecLayerW {
   const float *attn_ln_w, *attn_ln_b, *cross_ln_w, *cross_ln_b, *mlp_ln_w, *mlp_ln_b;
-  const bf16 *w_qkv, *w_o, *w_cq, *w_co, *w_fc1, *w_fc2;
+  const h16 *w_qkv, *w_o, *w_cq, *w_co, *w_fc1, *w_fc2;
   const float *b_qkv, *b_o, *b_cq, *b_co, *b_fc1, *b_fc2;
 };
 
-// Layout of the decoder-layer weight arenas (engine.cpp load_weights): layer l's bf16 matrices start at
+// Layout of the decoder-layer weight arenas (engine.cpp load_weights): layer l's h16 matrices start at
 // w_base + l * w_stride(d), in units of d*d elements; its fp32 vectors at f_base + l * f_stride(d), in units of d.
 struct DecArena {
   enum : int { W_QKV = 0, W_O = 3, W_CQ = 4, W_CO = 5, W_FC1 = 6, W_FC2 = 10, W_UNITS = 14 };
@@ -159,7 +197,7 @@ enum GemvEpilogue : int {
 };
 
 struct GemvParams {
-  const bf16* W; const float* bias; int N, K, batch;
+  const h16* W; const float* bias; int N, K, batch;
   // prologue
   int prologue;
   const float* in;            // PRO_PLAIN: [B][K]; PRO_LAYERNORM: x [B][K]
@@ -168,7 +206,7 @@ struct GemvParams {
   // epilogue
   int epilogue;
   float* out;                 // [B][N]
-  bf16* k_cache; bf16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;  // GEPI_QKV_CACHE (this layer)
+  h16* k_cache; h16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;  // GEPI_QKV_CACHE (this layer)
   const DecState* state;
   float* amax_val; int* amax_idx; int amax_stride;  // GEPI_LOGITS: partials [clip][amax_stride], one per workgroup
   float* logits_dump;              // optional logits row of this step for clip b at logits_dump + b*logits_dump_stride
@@ -179,37 +217,37 @@ void launch_gemv(const GemvParams& p, hipStream_t s);
 int gemv_grid(const GemvParams& p);  // number of workgroups launch_gemv will use
 
 // x[b] = tok_emb[tok[b]] + pos[step]
-void launch_embed(const bf16* tok_emb, const float* pos, const int* tok, const DecState* st, float* x, int batch, int d,
+void launch_embed(const h16* tok_emb, const float* pos, const int* tok, const DecState* st, float* x, int batch, int d,
                   hipStream_t s);
 
 // single-query attention over blocked K / row-major V, writes split partials [B][H][n_split][66]
 struct DecAttnParams {
   const float* q;             // [B][d]
-  const bf16* k; const bf16* v; long kv_batch_stride;   // this layer, slot 0
+  const h16* k; const h16* v; long kv_batch_stride;   // this layer, slot 0
   float* part; int n_split;
   int batch, n_head, d_model;
   int n_keys;                 // fixed key count (cross) or -1: state->step + 1 (self)
   int cap_blocks;             // allocated 64-key blocks per (slot, head): 24 cross, 7 self
   const DecState* state;
   const int* done;            // optional device [B]: clips whose flag is set are skipped (greedy loop past their eot)
-  bf16* out_hi; bf16* out_lo; int nbs; // n_split == 1 only: normalised output as a fragment-major bf16 pair instead of partials
+  h16* out_hi; h16* out_lo; int nbs; // n_split == 1 only: normalised output as a fragment-major h16 pair instead of partials
   // fused query projection (batched cross-attention): q = Wq[head rows] . LayerNorm(x[b]) + bq computed by the
   // (clip, head) workgroup itself while its first K/V block is in flight; wq == nullptr: q is read from `q`
-  const float* x; const float* ln_w; const float* ln_b; const bf16* wq; const float* bq;
+  const float* x; const float* ln_w; const float* ln_b; const h16* wq; const float* bq;
 };
 void launch_decode_attention(const DecAttnParams& p, hipStream_t s);
 
-// ---- batched decode (5..64 clips per launch): activations as bf16 (hi, lo) pairs, MFMA GEMM (decode_gemm.hip)
+// ---- batched decode (5..64 clips per launch): activations as h16 (hi, lo) pairs, MFMA GEMM (decode_gemm.hip)
 struct DecGemmParams {
-  const bf16* W;                           // fragment-major packed weights
+  const h16* W;                           // fragment-major packed weights
   const float* bias; int N, K, batch;
-  const bf16* a_hi; const bf16* a_lo;      // fragment-major bf16 pair (decode_gemm.hip), this launch's first clip block
+  const h16* a_hi; const h16* a_lo;      // fragment-major h16 pair (decode_gemm.hip), this launch's first clip block
   int nbs;                                 // allocated clip blocks (stride of the activation layout)
   int epilogue;                            // GemvEpilogue
   int rt;                                  // weight-row tiles per wave: 1 (16 rows/WG) or 4 (64 rows/WG, vocabulary)
   float* out;                              // fp32 [batch][N] (STORE / RESID / q of QKV_CACHE)
-  bf16* out_hi; bf16* out_lo;              // GEPI_GELU: bf16 pair [batch][N]
-  bf16* k_cache; bf16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;
+  h16* out_hi; h16* out_lo;              // GEPI_GELU: h16 pair [batch][N]
+  h16* k_cache; h16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;
   const DecState* state;
   float* amax_val; int* amax_idx; int amax_stride;
   float* logits_dump; long logits_dump_stride;
@@ -223,24 +261,24 @@ void launch_decode_gemm(const DecGemmParams& p, hipStream_t s);
 // separate preparation launch, no activation round trip through memory) and the residual add can be the epilogue
 // (every output element has exactly one owner: no split-K partials to fold).
 struct DecCGemmParams {
-  const bf16* W;                           // fragment-major packed weights
+  const h16* W;                           // fragment-major packed weights
   const float* bias; int N, K, batch;
   const float* x; const float* ln_w; const float* ln_b;   // ln_w != nullptr: input = LayerNorm(x [batch][K] fp32)
-  const bf16* a_hi; const bf16* a_lo;      // else: fragment-major bf16 pair
+  const h16* a_hi; const h16* a_lo;      // else: fragment-major h16 pair
   int nbs;                                 // allocated clip blocks (stride of the pair layouts)
   int epilogue;                            // GEPI_STORE / GEPI_GELU / GEPI_RESID / GEPI_QKV_CACHE
   int rt;                                  // 1 or 2
   float* out;                              // fp32 [batch][N] (STORE, RESID: out += y; q of QKV_CACHE)
-  bf16* out_hi; bf16* out_lo;              // GEPI_GELU: bf16 pair
-  bf16* k_cache; bf16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;
+  h16* out_hi; h16* out_lo;              // GEPI_GELU: h16 pair
+  h16* k_cache; h16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;
   const DecState* state;
 };
 void launch_decode_cgemm(const DecCGemmParams& p, hipStream_t s);
 int decode_gemm_grid(int N, int rt);
 bool decode_logits_resident_ok(int K, int batch);  // rt == 0 (one workgroup per CU, activations in registers) supports this shape
-void launch_act_prep(float* x, const float* g, const float* be, bf16* hi, bf16* lo, int batch, int K, bool do_ln, int nbs,
+void launch_act_prep(float* x, const float* g, const float* be, h16* hi, h16* lo, int batch, int K, bool do_ln, int nbs,
                      const float* part, int n_part, int part_batch, const float* part_bias, hipStream_t s);
-void launch_pack_weight_frag(const bf16* w, bf16* wp, int N, int K, hipStream_t s);
+void launch_pack_weight_frag(const h16* w, h16* wp, int N, int K, hipStream_t s);
 
 struct AdvanceParams {
   const float* amax_val; const int* amax_idx; int n_part; int amax_stride;
@@ -250,16 +288,16 @@ struct AdvanceParams {
   const int* sot;             // device [4]
   const int* forced; int n_forced;   // teacher forcing (device [B][n_forced]) or nullptr
   int* argmax_dump;           // optional [B][n_forced+1]
-  const bf16* tok_emb; const float* pos; float* x; int d_model;  // fused embedding of the next step
+  const h16* tok_emb; const float* pos; float* x; int d_model;  // fused embedding of the next step
 };
 void launch_advance(const AdvanceParams& p, hipStream_t s);
 
 // ---- persistent batch-1 decode (decode_persistent.hip): the whole greedy loop of one clip in ONE launch
 typedef unsigned long long u64;
 struct PersistParams {
-  const bf16* wl; const float* fl;   // decoder-layer weight arenas (DecArena layout)
-  const bf16* tok_emb; const float* pos; const float* ln_w; const float* ln_b;
-  const bf16* cross_k; const bf16* cross_v; long cross_layer_stride;  // this clip's slot, layer 0
+  const h16* wl; const float* fl;   // decoder-layer weight arenas (DecArena layout)
+  const h16* tok_emb; const float* pos; const float* ln_w; const float* ln_b;
+  const h16* cross_k; const h16* cross_v; long cross_layer_stride;  // this clip's slot, layer 0
   int n_layer, n_vocab, n_ctx, n_audio_ctx;
   int eot, max_new, total_steps;
   const int* sot;               // device [4]
@@ -275,10 +313,11 @@ int decode_persistent_grid(int d_model, int n_cu);
 size_t decode_persistent_gran_bytes(int d_model, int grid);   // granule area; the error word sits in its last 8 bytes
 hipError_t launch_decode_persistent(const PersistParams& p, int d_model, int grid, hipStream_t s);
 
-// weight preparation (device): raw file dtype -> bf16 / fp32, with the layout changes the kernels want
-void launch_convert_to_bf16(const void* src, int src_dtype /*0 f32,1 bf16,2 f16*/, bf16* dst, long n, hipStream_t s);
+// weight preparation (device): raw file dtype -> h16 / fp32, with the layout changes the kernels want
+void launch_convert_to_h16(const void* src, int src_dtype /*0 f32,1 h16,2 f16*/, h16* dst, long n, hipStream_t s);
 void launch_convert_to_f32(const void* src, int src_dtype, float* dst, long n, hipStream_t s);
 // conv weight [Cout][Cin][3] -> [Cout][Kpad] with k-major taps: dst[n][k*Cin + c]
-void launch_conv_weight_pack(const void* src, int src_dtype, bf16* dst, int cout, int cin, int kpad, hipStream_t s);
+void launch_conv_weight_pack(const void* src, int src_dtype, h16* dst, int cout, int cin, int kpad, hipStream_t s);
 
+}  // inline namespace AXW_NS
 }  // namespace axw

@@ -1,8 +1,8 @@
 // decode_gemm.hip — the decoder step's nn.Linear layers for 5..64 clips per launch on the matrix cores.
 //
-// y[b][n] = sum_k W[n][k] a[b][k] (+ bias[n]): W bf16 [N][K] streamed from HBM exactly once per step for the
+// y[b][n] = sum_k W[n][k] a[b][k] (+ bias[n]): W h16 [N][K] streamed from HBM exactly once per step for the
 // whole batch (277.8 MB/step for small), activations fp32-equivalent: every activation is carried
-// as a bf16 pair (hi, lo) with hi + lo == x to 16 mantissa bits, and both terms are multiplied on
+// as a h16 pair (hi, lo) with hi + lo == x to 16 mantissa bits, and both terms are multiplied on
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation. The step stays HBM-bound (two MFMAs per 1 KiB of weights
 // is far below the matrix rate), so the second term is free and keeps batched decoding numerically in
 // line with the fp32-FMA GEMV used for 1..4 clips (decode_gemv.hip).
@@ -11,21 +11,22 @@
 //   workgroup = 8 waves = 16*RT weight rows; the 8 waves split K (k-steps round-robin), then reduce through LDS;
 //   a wave keeps RT x NB accumulator tiles (NB = ceil(batch/16) <= 4) so one activation fragment feeds RT MFMAs;
 //   weights: 16-byte loads, 4 lanes cover 64 contiguous bytes of a row per k-step, k-steps unrolled so the
-//   whole 128-byte line is requested back to back; activations come from L2 (bf16 pairs written by the
+//   whole 128-byte line is requested back to back; activations come from L2 (h16 pairs written by the
 //   producer: act_prep_kernel / attention / the GELU epilogue).
 // Three kernels: decode_cgemm_kernel (clip blocks of 16, LayerNorm prologue / residual epilogue: the default sequence
 // for d_model <= 1024), decode_logits_kernel (vocabulary projection with register-resident activations) and
 // decode_gemm_kernel + act_prep_kernel (64 clips per workgroup, split-K partials: d_model > 1024 and the fallbacks).
-// Epilogues mirror decode_gemv.hip: bias, GELU (writes the bf16 pair), residual add, q + KV-cache append,
+// Epilogues mirror decode_gemv.hip: bias, GELU (writes the h16 pair), residual add, q + KV-cache append,
 // vocabulary argmax partials (first max wins, Whisper.cpp:42-45).
 #include "common.hpp"
 #include <algorithm>
 
 namespace axw {
+inline namespace AXW_NS {
 
-__device__ __forceinline__ void split_bf16(float x, bf16& hi, bf16& lo) {
-  hi = (bf16)x;
-  lo = (bf16)(x - (float)hi);
+__device__ __forceinline__ void split_bf16(float x, h16& hi, h16& lo) {
+  hi = (h16)x;
+  lo = (h16)(x - (float)hi);
 }
 
 // Fragment-major layouts: both MFMA operands are stored in the order the 16x16x32 instruction consumes them, so
@@ -37,18 +38,18 @@ __device__ __forceinline__ long frag_index(int row, int k, int row_blocks_stride
   const long tile = weight ? ((long)blk * ks_count + ks) : ((long)ks * row_blocks_stride + blk);
   return (tile * 64 + q * 16 + r) * 8 + j;
 }
-__device__ __forceinline__ void store_pair_frag(float x, bf16* hi, bf16* lo, int clip, int k, int nbs) {
-  bf16 h, l;
+__device__ __forceinline__ void store_pair_frag(float x, h16* hi, h16* lo, int clip, int k, int nbs) {
+  h16 h, l;
   split_bf16(x, h, l);
   const long i = frag_index(clip, k, nbs, 0, false);
   hi[i] = h; lo[i] = l;
 }
 
-// Residual fold + LayerNorm of the residual stream -> fragment-major bf16 (hi, lo) rows; one workgroup per clip.
+// Residual fold + LayerNorm of the residual stream -> fragment-major h16 (hi, lo) rows; one workgroup per clip.
 // x[b] += bias + sum of the previous GEMM's split-K partials (fixed order: deterministic), then LayerNorm; every
 // global load is issued up front and the row is touched once (values stay in registers between the two reductions).
 __global__ __launch_bounds__(256) void act_prep_kernel(float* x, const float* __restrict__ g, const float* __restrict__ be,
-                                                       bf16* __restrict__ hi, bf16* __restrict__ lo, int K, int do_ln, int nbs,
+                                                       h16* __restrict__ hi, h16* __restrict__ lo, int K, int do_ln, int nbs,
                                                        const float* __restrict__ part, int n_part, int part_batch,
                                                        const float* __restrict__ part_bias) {
   __shared__ float red[8];
@@ -102,14 +103,14 @@ __global__ __launch_bounds__(256) void act_prep_kernel(float* x, const float* __
   }
 }
 
-void launch_act_prep(float* x, const float* g, const float* be, bf16* hi, bf16* lo, int batch, int K, bool do_ln, int nbs,
+void launch_act_prep(float* x, const float* g, const float* be, h16* hi, h16* lo, int batch, int K, bool do_ln, int nbs,
                      const float* part, int n_part, int part_batch, const float* part_bias, hipStream_t s) {
   hipLaunchKernelGGL(act_prep_kernel, dim3(batch), dim3(256), 0, s, x, g, be, hi, lo, K, do_ln ? 1 : 0, nbs, part, n_part,
                      part_batch, part_bias);
 }
 
-// row-major bf16 [N][K] -> fragment-major (rows padded to a multiple of 16 with zeros)
-__global__ void pack_weight_frag_kernel(const bf16* __restrict__ w, bf16* __restrict__ wp, int N, int K) {
+// row-major h16 [N][K] -> fragment-major (rows padded to a multiple of 16 with zeros)
+__global__ void pack_weight_frag_kernel(const h16* __restrict__ w, h16* __restrict__ wp, int N, int K) {
   const int KS = K / 32;
   const long total = (long)((N + 15) / 16) * KS * 512;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -117,10 +118,10 @@ __global__ void pack_weight_frag_kernel(const bf16* __restrict__ w, bf16* __rest
     const long tile = i >> 9;
     const int ks = (int)(tile % KS), nb = (int)(tile / KS);
     const int row = nb * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + j;
-    wp[i] = row < N ? w[(long)row * K + k] : (bf16)0.f;
+    wp[i] = row < N ? w[(long)row * K + k] : (h16)0.f;
   }
 }
-void launch_pack_weight_frag(const bf16* w, bf16* wp, int N, int K, hipStream_t s) {
+void launch_pack_weight_frag(const h16* w, h16* wp, int N, int K, hipStream_t s) {
   hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(2048), dim3(256), 0, s, w, wp, N, K);
 }
 
@@ -138,11 +139,11 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
   const int nb0 = blockIdx.x * RT; // first 16-row block of this workgroup
   const int n_rb = (p.N + 15) / 16;
 
-  const bf16* wrow[RT];
+  const h16* wrow[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t) wrow[t] = p.W + ((long)min(nb0 + t, n_rb - 1) * KS_all + ks_base) * 512 + lane * 8;
-  const bf16* ahi = p.a_hi + ks_base * ((long)p.nbs * 512) + lane * 8;
-  const bf16* alo = p.a_lo + ks_base * ((long)p.nbs * 512) + lane * 8;
+  const h16* ahi = p.a_hi + ks_base * ((long)p.nbs * 512) + lane * 8;
+  const h16* alo = p.a_lo + ks_base * ((long)p.nbs * 512) + lane * 8;
   const long a_step = (long)p.nbs * 512;  // elements between consecutive k-steps of the activations
 
   // The bias of this thread's outputs is requested first: every output of a thread has the same weight row
@@ -163,14 +164,14 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
   // Three register sets of operand fragments: with 8 waves splitting K, Whisper-small's K = 768 is 3 k-steps
   // per wave, i.e. every operand byte of the workgroup is requested before the first MFMA (one memory round
   // trip); longer K rotates the sets. Every load is one contiguous 1 KiB wave access.
-  struct Frag { bf16x8 w[RT], h[NB], l[NB]; };
+  struct Frag { h16x8 w[RT], h[NB], l[NB]; };
   auto load = [&](Frag& f, int ks) {
 #pragma unroll
-    for (int t = 0; t < RT; ++t) f.w[t] = *reinterpret_cast<const bf16x8*>(wrow[t] + (long)ks * 512);
+    for (int t = 0; t < RT; ++t) f.w[t] = *reinterpret_cast<const h16x8*>(wrow[t] + (long)ks * 512);
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-      f.h[c] = *reinterpret_cast<const bf16x8*>(ahi + ks * a_step + c * 512);
-      f.l[c] = *reinterpret_cast<const bf16x8*>(alo + ks * a_step + c * 512);
+      f.h[c] = *reinterpret_cast<const h16x8*>(ahi + ks * a_step + c * 512);
+      f.l[c] = *reinterpret_cast<const h16x8*>(alo + ks * a_step + c * 512);
     }
   };
   auto mma = [&](const Frag& f) {
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
     for (int t = 0; t < RT; ++t)
 #pragma unroll
       for (int c = 0; c < NB; ++c) {
-        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t], f.h[c], acc[t][c], 0, 0, 0);
-        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t], f.l[c], acc[t][c], 0, 0, 0);
+        acc[t][c] = AXW_MFMA_16x16x32(f.w[t], f.h[c], acc[t][c]);
+        acc[t][c] = AXW_MFMA_16x16x32(f.w[t], f.l[c], acc[t][c]);
       }
   };
   Frag f0, f1, f2;
@@ -241,8 +242,8 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
           const int cc = (n < 2 * d) ? n - d : n - 2 * d;
           const int head = cc >> 6, dd = cc & 63;
           const long base = (long)b * p.kv_batch_stride + (long)head * p.n_ctx_pad * 64;
-          if (n < 2 * d) p.k_cache[base + (long)(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (bf16)y;
-          else p.v_cache[base + (long)step * 64 + dd] = (bf16)y;
+          if (n < 2 * d) p.k_cache[base + (long)(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (h16)y;
+          else p.v_cache[base + (long)step * 64 + dd] = (h16)y;
         }
         break;
       }
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
 // ---------------------------------------------------------------------------- clip-block GEMM (DecCGemmParams)
 // grid = (weight-row blocks of 16*RT, clip blocks of 16); 8 waves split K (k-steps w, w+8, ...), reduce through LDS;
 // at most one output per thread (RT <= 2), so the bias and the residual value are requested before anything else.
-// CH > 0: LayerNorm prologue, CH = k-steps per wave held in registers (K = 256*CH at most); CH == 0: bf16-pair input.
+// CH > 0: LayerNorm prologue, CH = k-steps per wave held in registers (K = 256*CH at most); CH == 0: h16-pair input.
 template <int RT, int CH>
 __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
   __shared__ __attribute__((aligned(16))) float red[8 * RT * 256];  // [wave][t][clip][row]
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
   if (has_out && p.epilogue == GEPI_RESID) old_t = p.out[(long)o_b * p.N + o_n];
   const int step = p.epilogue == GEPI_QKV_CACHE ? p.state->step : 0;
 
-  const bf16* wrow[RT];
+  const h16* wrow[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t) wrow[t] = p.W + (long)min(nb0 + t, n_rb - 1) * KS * 512 + lane * 8;
 
@@ -304,12 +305,12 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
 
   if constexpr (CH > 0) {
     // weights of this wave's k-steps: all requested before the LayerNorm arithmetic
-    bf16x8 w[CH][RT];
+    h16x8 w[CH][RT];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int ks = min(wave + 8 * c, KS - 1);
 #pragma unroll
-      for (int t = 0; t < RT; ++t) w[c][t] = *reinterpret_cast<const bf16x8*>(wrow[t] + (long)ks * 512);
+      for (int t = 0; t < RT; ++t) w[c][t] = *reinterpret_cast<const h16x8*>(wrow[t] + (long)ks * 512);
     }
     // lane (r, q) holds x[clip r][k = ks*32 + 8q .. +8] of every k-step of this wave: exactly its MFMA B fragment
     const float* xr = p.x + (long)min(cb * 16 + r, p.batch - 1) * p.K;
@@ -360,38 +361,38 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
 #pragma unroll
     for (int c = 0; c < CH; ++c)
       if (wave + 8 * c < KS) {
-        bf16x8 hi, lo;
+        h16x8 hi, lo;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float y = (v[c][u][e] - mean) * rstd * gg[c][u][e] + bb[c][u][e];
-            bf16 hh, ll;
+            h16 hh, ll;
             split_bf16(y, hh, ll);
             hi[4 * u + e] = hh; lo[4 * u + e] = ll;
           }
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][t], hi, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][t], lo, acc[t], 0, 0, 0);
+          acc[t] = AXW_MFMA_16x16x32(w[c][t], hi, acc[t]);
+          acc[t] = AXW_MFMA_16x16x32(w[c][t], lo, acc[t]);
         }
       }
   } else {
-    const bf16* ahi = p.a_hi + (long)cb * 512 + lane * 8;
-    const bf16* alo = p.a_lo + (long)cb * 512 + lane * 8;
+    const h16* ahi = p.a_hi + (long)cb * 512 + lane * 8;
+    const h16* alo = p.a_lo + (long)cb * 512 + lane * 8;
     const long a_step = (long)p.nbs * 512;
-    struct Frag { bf16x8 w[RT], h, l; };
+    struct Frag { h16x8 w[RT], h, l; };
     auto load = [&](Frag& f, int ks) {
 #pragma unroll
-      for (int t = 0; t < RT; ++t) f.w[t] = *reinterpret_cast<const bf16x8*>(wrow[t] + (long)ks * 512);
-      f.h = *reinterpret_cast<const bf16x8*>(ahi + ks * a_step);
-      f.l = *reinterpret_cast<const bf16x8*>(alo + ks * a_step);
+      for (int t = 0; t < RT; ++t) f.w[t] = *reinterpret_cast<const h16x8*>(wrow[t] + (long)ks * 512);
+      f.h = *reinterpret_cast<const h16x8*>(ahi + ks * a_step);
+      f.l = *reinterpret_cast<const h16x8*>(alo + ks * a_step);
     };
     auto mma = [&](const Frag& f) {
 #pragma unroll
       for (int t = 0; t < RT; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t], f.h, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t], f.l, acc[t], 0, 0, 0);
+        acc[t] = AXW_MFMA_16x16x32(f.w[t], f.h, acc[t]);
+        acc[t] = AXW_MFMA_16x16x32(f.w[t], f.l, acc[t]);
       }
     };
     // eight k-steps in flight per wave (96 VGPRs at RT = 1): K = 5120 is 20 k-steps per wave, i.e. 3 dependent round
@@ -434,8 +435,8 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
         const int cc = (n < 2 * d) ? n - d : n - 2 * d;
         const int head = cc >> 6, dd = cc & 63;
         const long base = (long)b * p.kv_batch_stride + (long)head * p.n_ctx_pad * 64;
-        if (n < 2 * d) p.k_cache[base + (long)(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (bf16)y;
-        else p.v_cache[base + (long)step * 64 + dd] = (bf16)y;
+        if (n < 2 * d) p.k_cache[base + (long)(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (h16)y;
+        else p.v_cache[base + (long)step * 64 + dd] = (h16)y;
       }
       break;
     }
@@ -478,22 +479,22 @@ __global__ __launch_bounds__(512) void decode_logits_kernel(DecGemmParams p) {
   const int r = lane & 15, q = lane >> 4;
   const int KS = p.K / 32, n_rb = (p.N + 15) / 16, G = gridDim.x;
 
-  bf16x8 ah[CH][NB], al[CH][NB];
+  h16x8 ah[CH][NB], al[CH][NB];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const long ks = min(wave + 8 * c, KS - 1);
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
-      ah[c][cb] = *reinterpret_cast<const bf16x8*>(p.a_hi + (ks * p.nbs + cb) * 512 + lane * 8);
-      al[c][cb] = *reinterpret_cast<const bf16x8*>(p.a_lo + (ks * p.nbs + cb) * 512 + lane * 8);
+      ah[c][cb] = *reinterpret_cast<const h16x8*>(p.a_hi + (ks * p.nbs + cb) * 512 + lane * 8);
+      al[c][cb] = *reinterpret_cast<const h16x8*>(p.a_lo + (ks * p.nbs + cb) * 512 + lane * 8);
     }
   }
-  auto loadw = [&](bf16x8 (&w)[CH], int rb) {
+  auto loadw = [&](h16x8 (&w)[CH], int rb) {
 #pragma unroll
     for (int c = 0; c < CH; ++c)
-      w[c] = *reinterpret_cast<const bf16x8*>(p.W + ((long)min(rb, n_rb - 1) * KS + min(wave + 8 * c, KS - 1)) * 512 + lane * 8);
+      w[c] = *reinterpret_cast<const h16x8*>(p.W + ((long)min(rb, n_rb - 1) * KS + min(wave + 8 * c, KS - 1)) * 512 + lane * 8);
   };
-  bf16x8 w0[CH], w1[CH];
+  h16x8 w0[CH], w1[CH];
   loadw(w0, blockIdx.x);
   if (p.state->step < p.skip_before_step) return;  // SOT steps: logits are discarded (Whisper.cpp:214-217)
 
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(512) void decode_logits_kernel(DecGemmParams p) {
 #pragma unroll
   for (int u = 0; u < NU; ++u) { bv[u] = -INFINITY; bi[u] = 0x7fffffff; }
 
-  auto body = [&](const bf16x8 (&w)[CH], int rb, int it) {
+  auto body = [&](const h16x8 (&w)[CH], int rb, int it) {
     f32x4 acc[NB];
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb)
@@ -514,8 +515,8 @@ __global__ __launch_bounds__(512) void decode_logits_kernel(DecGemmParams p) {
       if (wave + 8 * c < KS) {
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
-          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c], ah[c][cb], acc[cb], 0, 0, 0);
-          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c], al[c][cb], acc[cb], 0, 0, 0);
+          acc[cb] = AXW_MFMA_16x16x32(w[c], ah[c][cb], acc[cb]);
+          acc[cb] = AXW_MFMA_16x16x32(w[c], al[c][cb], acc[cb]);
         }
       }
     float* rd = red + (it & 1) * (8 * NB * 256);  // two buffers: a wave may park iteration i+1 while others still sum i
@@ -616,4 +617,5 @@ void launch_decode_gemm(const DecGemmParams& p, hipStream_t s) {
   else launch_nb<1>(p, s);
 }
 
+}  // inline namespace AXW_NS
 }  // namespace axw

@@ -1,9 +1,9 @@
 // decode_gemv.hip — weight-streaming GEMV of the decoder step for 1..4 clips, and the loop-advance kernel.
 //
-// y[b][n] = sum_k W[n][k] * a[b][k] (+ bias[n]) with W bf16 [N][K] read exactly once, activations fp32.
+// y[b][n] = sum_k W[n][k] * a[b][k] (+ bias[n]) with W h16 [N][K] read exactly once, activations fp32.
 // This is where the decoder's nn.Linear layers run at small batch (export_onnx.py:238-261 q/k/v/out,
 // :221-230 cross query/out, :298 mlp, :378-385 tied-embedding logits); decode is HBM-bound, the FLOPs
-// are free, so the products stay fp32 FMA (bf16 weight x fp32 activation is exact in fp32).
+// are free, so the products stay fp32 FMA (h16 weight x fp32 activation is exact in fp32).
 //
 // Latency structure (batch 1 is a chain of ~100 dependent launches per token, each a few microseconds):
 //   1. every lane issues the 16-byte weight loads of its first row BEFORE the prologue, so the HBM round
@@ -18,6 +18,7 @@
 #include "common.hpp"
 
 namespace axw {
+inline namespace AXW_NS {
 
 constexpr int kPartStride = 66;  // m, l, o[64]
 
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p, int rows_per_wg
   uint4 wnext[CH];
   {
     const int n = min(row_begin + rsub, row_end - 1);
-    const bf16* wrow = p.W + (long)n * K;
+    const h16* wrow = p.W + (long)n * K;
 #pragma unroll
     for (int i = 0; i < CH; ++i) wnext[i] = *reinterpret_cast<const uint4*>(wrow + (j + LPR * i) * 8);
   }
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p, int rows_per_wg
     for (int i = 0; i < CH; ++i) w[i] = wnext[i];
     if (row0 + RP < row_end) {  // next pass in flight while this one is reduced
       const int nn = min(row0 + RP + rsub, row_end - 1);
-      const bf16* wrow = p.W + (long)nn * K;
+      const h16* wrow = p.W + (long)nn * K;
 #pragma unroll
       for (int i = 0; i < CH; ++i) wnext[i] = *reinterpret_cast<const uint4*>(wrow + (j + LPR * i) * 8);
     }
@@ -181,14 +182,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p, int rows_per_wg
       for (int b = 0; b < BT; ++b) {
         const float4 a0 = *reinterpret_cast<const float4*>(act + b * K + c8);
         const float4 a1 = *reinterpret_cast<const float4*>(act + b * K + c8 + 4);
-        acc[b] = fmaf(__uint_as_float(uw[0] << 16), a0.x, acc[b]);
-        acc[b] = fmaf(__uint_as_float(uw[0] & 0xffff0000u), a0.y, acc[b]);
-        acc[b] = fmaf(__uint_as_float(uw[1] << 16), a0.z, acc[b]);
-        acc[b] = fmaf(__uint_as_float(uw[1] & 0xffff0000u), a0.w, acc[b]);
-        acc[b] = fmaf(__uint_as_float(uw[2] << 16), a1.x, acc[b]);
-        acc[b] = fmaf(__uint_as_float(uw[2] & 0xffff0000u), a1.y, acc[b]);
-        acc[b] = fmaf(__uint_as_float(uw[3] << 16), a1.z, acc[b]);
-        acc[b] = fmaf(__uint_as_float(uw[3] & 0xffff0000u), a1.w, acc[b]);
+        acc[b] = fmaf(h16lo(uw[0]), a0.x, acc[b]);
+        acc[b] = fmaf(h16hi(uw[0]), a0.y, acc[b]);
+        acc[b] = fmaf(h16lo(uw[1]), a0.z, acc[b]);
+        acc[b] = fmaf(h16hi(uw[1]), a0.w, acc[b]);
+        acc[b] = fmaf(h16lo(uw[2]), a1.x, acc[b]);
+        acc[b] = fmaf(h16hi(uw[2]), a1.y, acc[b]);
+        acc[b] = fmaf(h16lo(uw[3]), a1.z, acc[b]);
+        acc[b] = fmaf(h16hi(uw[3]), a1.w, acc[b]);
       }
     }
 #pragma unroll
@@ -216,9 +217,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p, int rows_per_wg
               const int head = c >> 6, dd = c & 63;
               const long base = (long)b * p.kv_batch_stride + (long)head * p.n_ctx_pad * 64;
               if (n < 2 * d)  // blocked K: [blk][dd/8][key%64][8]
-                p.k_cache[base + (long)(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (bf16)y;
+                p.k_cache[base + (long)(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (h16)y;
               else            // row-major V: [key][64]
-                p.v_cache[base + (long)step * 64 + dd] = (bf16)y;
+                p.v_cache[base + (long)step * 64 + dd] = (h16)y;
             }
             break;
           }
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvParams p, int rows_per_w
   uint4 wnext[CH];
   {
     const int n = min(row_begin + rsub, row_end - 1);
-    const bf16* wrow = p.W + (long)n * K;
+    const h16* wrow = p.W + (long)n * K;
 #pragma unroll
     for (int i = 0; i < CH; ++i) wnext[i] = *reinterpret_cast<const uint4*>(wrow + (j + LPR * i) * 8);
   }
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvParams p, int rows_per_w
     for (int i = 0; i < CH; ++i) w[i] = wnext[i];
     if (row0 + RP < row_end) {
       const int nn = min(row0 + RP + rsub, row_end - 1);
-      const bf16* wrow = p.W + (long)nn * K;
+      const h16* wrow = p.W + (long)nn * K;
 #pragma unroll
       for (int i = 0; i < CH; ++i) wnext[i] = *reinterpret_cast<const uint4*>(wrow + (j + LPR * i) * 8);
     }
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvParams p, int rows_per_w
       const unsigned uw[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        acc = fmaf(__uint_as_float(uw[e] << 16), a[i][2 * e], acc);
-        acc = fmaf(__uint_as_float(uw[e] & 0xffff0000u), a[i][2 * e + 1], acc);
+        acc = fmaf(h16lo(uw[e]), a[i][2 * e], acc);
+        acc = fmaf(h16hi(uw[e]), a[i][2 * e + 1], acc);
       }
     }
 #pragma unroll
@@ -372,8 +373,8 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvParams p, int rows_per_w
             const int c = (n < 2 * d) ? n - d : n - 2 * d;
             const int head = c >> 6, dd = c & 63;
             const long base = (long)head * p.n_ctx_pad * 64;
-            if (n < 2 * d) p.k_cache[base + (long)(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (bf16)y;
-            else p.v_cache[base + (long)step * 64 + dd] = (bf16)y;
+            if (n < 2 * d) p.k_cache[base + (long)(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (h16)y;
+            else p.v_cache[base + (long)step * 64 + dd] = (h16)y;
           }
           break;
         }
@@ -549,4 +550,5 @@ void launch_advance(const AdvanceParams& p, hipStream_t s) {
   hipLaunchKernelGGL(advance_kernel, dim3((p.batch + 15) / 16), dim3(1024), 0, s, p);
 }
 
+}  // inline namespace AXW_NS
 }  // namespace axw

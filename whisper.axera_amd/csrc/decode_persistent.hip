@@ -3,7 +3,7 @@
 // Replaces, for batch 1, the per-token sequence Whisper::run_decoder (cpp/src/Whisper.cpp:290-346) + argmax (:42-45)
 // + the host loop (:207-222) = the decoder graph TextDecoderTensorCache.forward (model_convert/export_onnx.py:312-387)
 // with its attention (:103-150, :221-230). Same arithmetic as the launch-per-phase path (decode_gemv.hip,
-// decoder.hip): bf16 weights x fp32 activations with fp32 FMA, fp32 LayerNorm/softmax, bf16 self/cross K/V.
+// decoder.hip): h16 weights x fp32 activations with fp32 FMA, fp32 LayerNorm/softmax, h16 self/cross K/V.
 //
 // Why: at batch 1 a decoder step is a chain of ~100 dependent phases that each move only a few MB, so the chain is
 // bound by per-phase latency, not by HBM. As separate graph nodes a phase costs ~4.4 us (kernel
@@ -20,7 +20,7 @@
 //     in flight — with the roles split, a poll never queues behind a weight or K/V load, and the compute waves request
 //     the rows of the NEXT phase right after publishing the current one, a whole hand-off ahead of their use;
 //   * the self-attention K/V cache of one (layer, head) lives in the LDS of the workgroup that owns that head for
-//     the whole utterance (448 keys x 64 x 2 x bf16 = 112 KB): it never touches HBM. Workgroups that own no head
+//     the whole utterance (448 keys x 64 x 2 x h16 = 112 KB): it never touches HBM. Workgroups that own no head
 //     use the same LDS region to stage cross-attention K/V tiles by LDS-DMA one layer before their use;
 //   * every workgroup keeps its own copy of the residual stream, so a LayerNorm needs no extra hand-off;
 //   * the token feedback (argmax merge, SOT forcing, eot / context stop, embedding of the next token) is computed
@@ -30,6 +30,7 @@
 #include "common.hpp"
 
 namespace axw {
+inline namespace AXW_NS {
 
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
@@ -50,7 +51,7 @@ constexpr long long kSpinTicks = 5000000;
 constexpr int kPS = 66;            // attention partial record in LDS: m, l, o[64]
 constexpr int kRec = 80;           // cross-attention partial record as granules: o[64] (four full lines), m, l; 5-line stride
 constexpr int kCrossSplit = 3;     // cross-attention key ranges per head (8 blocks of 64 keys each = 8 compute waves)
-constexpr int kKvBytes = 2 * NCW * 8192;  // LDS K/V region: K [8 blk][8][64][8] bf16 + V [512 keys][64] bf16
+constexpr int kKvBytes = 2 * NCW * 8192;  // LDS K/V region: K [8 blk][8][64][8] h16 + V [512 keys][64] h16
 
 // ---------------------------------------------------------------------------------------- lane-group reductions
 template <int CTRL>
@@ -169,21 +170,21 @@ __device__ __forceinline__ bool gather(const u64* buf, unsigned tag, unsigned (&
 
 // ---------------------------------------------------------------------------------------- weight rows
 template <int LPR, int CH>
-__device__ __forceinline__ void rows_load(u32x4 (&w)[CH], const bf16* W, int K, int row, int tid) {
+__device__ __forceinline__ void rows_load(u32x4 (&w)[CH], const h16* W, int K, int row, int tid) {
   const int j = tid % LPR;
-  const bf16* wr = W + (long)row * K;
+  const h16* wr = W + (long)row * K;
 #pragma unroll
   for (int i = 0; i < CH; ++i) w[i] = *reinterpret_cast<const u32x4*>(wr + (j + LPR * i) * 8);
 }
 #define AXW_FMA8(ACC0, ACC1, U, X0, X1)                       \
-  ACC0 = fmaf(__uint_as_float(U[0] << 16), X0.x, ACC0);       \
-  ACC1 = fmaf(__uint_as_float(U[0] & 0xffff0000u), X0.y, ACC1); \
-  ACC0 = fmaf(__uint_as_float(U[1] << 16), X0.z, ACC0);       \
-  ACC1 = fmaf(__uint_as_float(U[1] & 0xffff0000u), X0.w, ACC1); \
-  ACC0 = fmaf(__uint_as_float(U[2] << 16), X1.x, ACC0);       \
-  ACC1 = fmaf(__uint_as_float(U[2] & 0xffff0000u), X1.y, ACC1); \
-  ACC0 = fmaf(__uint_as_float(U[3] << 16), X1.z, ACC0);       \
-  ACC1 = fmaf(__uint_as_float(U[3] & 0xffff0000u), X1.w, ACC1);
+  ACC0 = fmaf(h16lo(U[0]), X0.x, ACC0);       \
+  ACC1 = fmaf(h16hi(U[0]), X0.y, ACC1); \
+  ACC0 = fmaf(h16lo(U[1]), X0.z, ACC0);       \
+  ACC1 = fmaf(h16hi(U[1]), X0.w, ACC1); \
+  ACC0 = fmaf(h16lo(U[2]), X1.x, ACC0);       \
+  ACC1 = fmaf(h16hi(U[2]), X1.y, ACC1); \
+  ACC0 = fmaf(h16lo(U[3]), X1.z, ACC0);       \
+  ACC1 = fmaf(h16hi(U[3]), X1.w, ACC1);
 // dot product of one weight row (registers) with the activation vector in LDS; LPR lanes share the row
 template <int LPR, int CH>
 __device__ __forceinline__ float rows_dot(const u32x4 (&w)[CH], const float* act, int tid) {
@@ -220,7 +221,7 @@ struct RowSet {
   int r0, r1;
   // first < 0: rows dealt evenly over all workgroups; else one full pass (SLOTS rows) per producer, producers =
   // workgroups first, first + 1, ... (the others get no rows)
-  __device__ __forceinline__ void prefetch(const bf16* W, const float* b, int K, int N, int wg, int P, int ctid, int first = -1) {
+  __device__ __forceinline__ void prefetch(const h16* W, const float* b, int K, int N, int wg, int P, int ctid, int first = -1) {
     if (first < 0) {
       r0 = (int)((unsigned)wg * (unsigned)N / (unsigned)P);  // wg * N < 2^31 (256 workgroups x 51866 rows)
       r1 = (int)((unsigned)(wg + 1) * (unsigned)N / (unsigned)P);
@@ -239,7 +240,7 @@ struct RowSet {
   // Computes this slot's rows (at most two passes: every supported shape has <= 2 * slots rows per workgroup) into
   // res[]. The caller requests the NEXT phase's rows before it publishes: a write-through store in front of a load
   // holds the load back for about a microsecond.
-  __device__ __forceinline__ void run(const bf16* W, const float* b, int K, const float* act, int ctid, float (&res)[2]) {
+  __device__ __forceinline__ void run(const h16* W, const float* b, int K, const float* act, int ctid, float (&res)[2]) {
     constexpr int SLOTS = CT / LPR;
     const int slot = ctid / LPR, j = ctid % LPR;
     res[0] = rows_dot<LPR, CH>(w, act, ctid) + bias;
@@ -287,10 +288,10 @@ __device__ __forceinline__ float sum_hi3(float v) {
   return v;
 }
 
-// One wave, one block of 64 keys in LDS: kblk = [8 (d/8)][64 keys][8] bf16 (lane = key for the scores),
-// vblk = [64 keys][64] bf16. Writes the softmax partial (m, l, o[64]) to part[0..66).
+// One wave, one block of 64 keys in LDS: kblk = [8 (d/8)][64 keys][8] h16 (lane = key for the scores),
+// vblk = [64 keys][64] h16. Writes the softmax partial (m, l, o[64]) to part[0..66).
 // pw: 64 floats of wave-private LDS scratch that transposes the probabilities (no cross-lane shuffles).
-__device__ __forceinline__ void attn_block(const bf16* kblk, const bf16* vblk, const float* qs, bool valid, float* pw, float* part, int lane) {
+__device__ __forceinline__ void attn_block(const h16* kblk, const h16* vblk, const float* qs, bool valid, float* pw, float* part, int lane) {
   float sc0 = 0.f, sc1 = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -315,8 +316,8 @@ __device__ __forceinline__ void attn_block(const bf16* kblk, const bf16* vblk, c
     const u32x4 vv = *reinterpret_cast<const u32x4*>(vblk + (8 * i + (lane >> 3)) * 64 + (lane & 7) * 8);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      o[2 * e] = fmaf(pr[i], __uint_as_float(vv[e] << 16), o[2 * e]);
-      o[2 * e + 1] = fmaf(pr[i], __uint_as_float(vv[e] & 0xffff0000u), o[2 * e + 1]);
+      o[2 * e] = fmaf(pr[i], h16lo(vv[e]), o[2 * e]);
+      o[2 * e + 1] = fmaf(pr[i], h16hi(vv[e]), o[2 * e + 1]);
     }
   }
 #pragma unroll
@@ -360,8 +361,8 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   static_assert(kCrossSplit * NCW == 24, "cross-attention key blocks");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* sK = reinterpret_cast<bf16*>(smem);                  // [8 blk][8][64 keys][8]  (blocked, lane = key)
-  bf16* sV = sK + NCW * 4096;                                // [512 keys][64]
+  h16* sK = reinterpret_cast<h16*>(smem);                  // [8 blk][8][64 keys][8]  (blocked, lane = key)
+  h16* sV = sK + NCW * 4096;                                // [512 keys][64]
   float* act = reinterpret_cast<float*>(smem + kKvBytes);    // [F + D/8] input vector of the current rows phase
   float* wpart = act + F + D / 8;                            // [NCW][kPS] per-wave attention partials
   float* red = wpart + NCW * kPS;                            // [2*NPW] LayerNorm partial sums
@@ -513,8 +514,8 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
               const float val = __uint_as_float(v[e]);
               if (tid < 32) qs[dd] = val;
               else if (tid < 64)  // K row `step`, blocked [blk][d/8][key%64][8]
-                sK[(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (bf16)val;
-              else sV[step * 64 + dd] = (bf16)val;
+                sK[(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (h16)val;
+              else sV[step * 64 + dd] = (h16)val;
             }
           }
           if (fail) ctl[0] = 1;
@@ -713,9 +714,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         const bool tl_on = step == p.total_steps / 2 && l == L / 2;
         const int lane = ctid & 63, cw = __builtin_amdgcn_readfirstlane(ctid >> 6);
         constexpr long DD = (long)D * D;
-        const bf16* WL = p.wl + (long)l * DecArena::w_stride(D);
+        const h16* WL = p.wl + (long)l * DecArena::w_stride(D);
         const float* FL = p.fl + (long)l * DecArena::f_stride(D);
-        const bf16 *w_qkv = WL + DecArena::W_QKV * DD, *w_o = WL + DecArena::W_O * DD, *w_cq = WL + DecArena::W_CQ * DD,
+        const h16 *w_qkv = WL + DecArena::W_QKV * DD, *w_o = WL + DecArena::W_O * DD, *w_cq = WL + DecArena::W_CQ * DD,
                    *w_co = WL + DecArena::W_CO * DD, *w_fc1 = WL + DecArena::W_FC1 * DD, *w_fc2 = WL + DecArena::W_FC2 * DD;
         const float *b_qkv = FL + DecArena::F_B_QKV * D, *b_o = FL + DecArena::F_B_O * D, *b_cq = FL + DecArena::F_B_CQ * D,
                     *b_co = FL + DecArena::F_B_CO * D, *b_fc1 = FL + DecArena::F_B_FC1 * D, *b_fc2 = FL + DecArena::F_B_FC2 * D;
@@ -731,8 +732,8 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           const int kb = (cun % kCrossSplit) * NCW + cw;  // 64-key block of this wave (24 blocks = t_pad 1536)
           const long off = (long)ln * p.cross_layer_stride + (long)(cun / kCrossSplit) * 24 * 4096 + (long)kb * 4096;
           for (int i = i0; i < i1; ++i) {
-            const bf16* src = (i < 8 ? p.cross_k : p.cross_v) + off + (i & 7) * 512 + lane * 8;
-            bf16* dst = (i < 8 ? sK : sV) + cw * 4096 + (i & 7) * 512;
+            const h16* src = (i < 8 ? p.cross_k : p.cross_v) + off + (i & 7) * 512 + lane * 8;
+            h16* dst = (i < 8 ? sK : sV) + cw * 4096 + (i & 7) * 512;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
           }
         };
@@ -1046,4 +1047,5 @@ hipError_t launch_decode_persistent(const PersistParams& p, int d_model, int gri
   }
 }
 
+}  // inline namespace AXW_NS
 }  // namespace axw

@@ -8,9 +8,9 @@
 // step is a fixed sequence of launches that is captured ONCE into a hipGraph and replayed; the
 // host never reads anything back inside the loop except a done counter every few steps.
 //
-// Kernels (decode is HBM-bound: weights are bf16 and read exactly once per step, K/V caches bf16):
+// Kernels (decode is HBM-bound: weights are h16 and read exactly once per step, K/V caches h16):
 //   embed_kernel            x = tok_emb[token] + pos[step]                       (export_onnx.py:334-336)
-//   gemv_kernel<LPR,BT,CH>  y = W a (+bias) for B <= 4 rows at a time, fp32 activations x bf16
+//   gemv_kernel<LPR,BT,CH>  y = W a (+bias) for B <= 4 rows at a time, fp32 activations x h16
 //                           weights with fp32 FMA; LPR lanes share one weight row (16-byte loads,
 //                           all CH loads of a lane issued before the first use); fused prologues
 //                           (LayerNorm of the residual stream / merge of the attention split
@@ -27,13 +27,14 @@
 #include "common.hpp"
 
 namespace axw {
+inline namespace AXW_NS {
 
 constexpr int kPartStride = 66;  // m, l, o[64]  (decode_gemv.hip merges these partials)
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
 
 // ------------------------------------------------------------------------------- embed
-__global__ __launch_bounds__(256) void embed_kernel(const bf16* __restrict__ tok_emb, const float* __restrict__ pos,
+__global__ __launch_bounds__(256) void embed_kernel(const h16* __restrict__ tok_emb, const float* __restrict__ pos,
                                                     const int* __restrict__ tok, const DecState* __restrict__ st, float* __restrict__ x,
                                                     int d) {
   const int b = blockIdx.x;
@@ -41,14 +42,14 @@ __global__ __launch_bounds__(256) void embed_kernel(const bf16* __restrict__ tok
   for (int c = threadIdx.x; c < d; c += 256) x[(long)b * d + c] = (float)tok_emb[(long)t * d + c] + pos[(long)step * d + c];
 }
 
-void launch_embed(const bf16* tok_emb, const float* pos, const int* tok, const DecState* st, float* x, int batch, int d,
+void launch_embed(const h16* tok_emb, const float* pos, const int* tok, const DecState* st, float* x, int batch, int d,
                   hipStream_t s) {
   hipLaunchKernelGGL(embed_kernel, dim3(batch), dim3(256), 0, s, tok_emb, pos, tok, st, x, d);
 }
 
 // ------------------------------------------------------------------------------- decode attention
 // FUSE_Q: the workgroup computes its own 64 query values, q = Wq[head*64 .. +64][:] . LayerNorm(x[b]) + bq (fp32 FMA on
-// bf16 weights, export_onnx.py:221-230), instead of reading them from a preceding GEMM launch: the 98 KB of weight rows
+// h16 weights, export_onnx.py:221-230), instead of reading them from a preceding GEMM launch: the 98 KB of weight rows
 // come from L2 (the 64 clips of a head share them) while the first K/V block is already in flight, and a decoder
 // layer loses one dependent launch.
 template <bool FUSE_Q>
@@ -64,8 +65,8 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
   const int blk_begin = split * bps, blk_cap_end = min(cap_blocks, blk_begin + bps);
 
   const float* __restrict__ qp = p.q + (long)b * p.d_model + head * 64;  // wave-uniform: scalar loads
-  const bf16* kb = p.k + (long)b * p.kv_batch_stride + (long)head * cap_blocks * 4096;
-  const bf16* vb = p.v + (long)b * p.kv_batch_stride + (long)head * cap_blocks * 4096;
+  const h16* kb = p.k + (long)b * p.kv_batch_stride + (long)head * cap_blocks * 4096;
+  const h16* vb = p.v + (long)b * p.kv_batch_stride + (long)head * cap_blocks * 4096;
 
   // The first block's K/V loads go out before the step counter is even known: every block below
   // cap_blocks is allocated (and zero-initialised), keys beyond n_keys are masked afterwards.
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
     }
     // the first weight chunks of this lane's row: 4 lanes share a row, lane j takes the 16-byte chunks j, j+4, ...
     const int qrow = tid >> 2, qj = tid & 3;
-    const bf16* wr = p.wq + (long)(head * 64 + qrow) * d;
+    const h16* wr = p.wq + (long)(head * 64 + qrow) * d;
     const int nch = d >> 3;  // 16-byte chunks per row
     u32x4 wc[8];
 #pragma unroll
@@ -128,14 +129,14 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
         const int c = c0 + qj + 4 * i;
         if (c < nch) {
           const float4 y0 = *reinterpret_cast<const float4*>(s_act + c * 8), y1 = *reinterpret_cast<const float4*>(s_act + c * 8 + 4);
-          a0 = fmaf(__uint_as_float(cur[i][0] << 16), y0.x, a0);
-          a1 = fmaf(__uint_as_float(cur[i][0] & 0xffff0000u), y0.y, a1);
-          a0 = fmaf(__uint_as_float(cur[i][1] << 16), y0.z, a0);
-          a1 = fmaf(__uint_as_float(cur[i][1] & 0xffff0000u), y0.w, a1);
-          a0 = fmaf(__uint_as_float(cur[i][2] << 16), y1.x, a0);
-          a1 = fmaf(__uint_as_float(cur[i][2] & 0xffff0000u), y1.y, a1);
-          a0 = fmaf(__uint_as_float(cur[i][3] << 16), y1.z, a0);
-          a1 = fmaf(__uint_as_float(cur[i][3] & 0xffff0000u), y1.w, a1);
+          a0 = fmaf(h16lo(cur[i][0]), y0.x, a0);
+          a1 = fmaf(h16hi(cur[i][0]), y0.y, a1);
+          a0 = fmaf(h16lo(cur[i][1]), y0.z, a0);
+          a1 = fmaf(h16hi(cur[i][1]), y0.w, a1);
+          a0 = fmaf(h16lo(cur[i][2]), y1.x, a0);
+          a1 = fmaf(h16hi(cur[i][2]), y1.y, a1);
+          a0 = fmaf(h16lo(cur[i][3]), y1.z, a0);
+          a1 = fmaf(h16hi(cur[i][3]), y1.w, a1);
         }
       }
     }
@@ -173,8 +174,8 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
       const unsigned u[4] = {kr[i].x, kr[i].y, kr[i].z, kr[i].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        sc = fmaf(qv[i * 8 + 2 * e], __uint_as_float(u[e] << 16), sc);
-        sc = fmaf(qv[i * 8 + 2 * e + 1], __uint_as_float(u[e] & 0xffff0000u), sc);
+        sc = fmaf(qv[i * 8 + 2 * e], h16lo(u[e]), sc);
+        sc = fmaf(qv[i * 8 + 2 * e + 1], h16hi(u[e]), sc);
       }
     }
     sc *= 0.125f;  // (64^-0.25)^2, export_onnx.py:116,124-126
@@ -192,8 +193,8 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
       const unsigned u[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o[2 * e] = fmaf(w, __uint_as_float(u[e] << 16), o[2 * e]);
-        o[2 * e + 1] = fmaf(w, __uint_as_float(u[e] & 0xffff0000u), o[2 * e + 1]);
+        o[2 * e] = fmaf(w, h16lo(u[e]), o[2 * e]);
+        o[2 * e + 1] = fmaf(w, h16hi(u[e]), o[2 * e + 1]);
       }
     }
   }
@@ -224,11 +225,11 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
     }
     if (p.out_hi) {  // single split: this IS the attention output (batched decode path)
       const float y = ov / l;
-      const bf16 yh = (bf16)y;
+      const h16 yh = (h16)y;
       const int k = head * 64 + tid;  // fragment-major pair (layout: decode_gemm.hip)
       const long i = ((((long)(k >> 5) * p.nbs + (b >> 4)) * 64) + ((k >> 3) & 3) * 16 + (b & 15)) * 8 + (k & 7);
       p.out_hi[i] = yh;
-      p.out_lo[i] = (bf16)(y - (float)yh);
+      p.out_lo[i] = (h16)(y - (float)yh);
     } else {
       float* out = p.part + (((long)b * p.n_head + head) * p.n_split + split) * kPartStride;
       if (tid == 0) { out[0] = m; out[1] = l; }
@@ -252,14 +253,14 @@ __device__ __forceinline__ float load_as_f32(const void* src, int dt, long i) {
   if (dt == 1) return bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(src)[i]);
   return (float)reinterpret_cast<const _Float16*>(src)[i];
 }
-__global__ void convert_to_bf16_kernel(const void* src, int dt, bf16* dst, long n) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = (bf16)load_as_f32(src, dt, i);
+__global__ void convert_to_bf16_kernel(const void* src, int dt, h16* dst, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = (h16)load_as_f32(src, dt, i);
 }
 __global__ void convert_to_f32_kernel(const void* src, int dt, float* dst, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = load_as_f32(src, dt, i);
 }
 // Conv1d weight [Cout][Cin][3] -> GEMM weight [Cout][kpad], column k*Cin + c (zero beyond 3*Cin)
-__global__ void conv_weight_pack_kernel(const void* src, int dt, bf16* dst, int cout, int cin, int kpad) {
+__global__ void conv_weight_pack_kernel(const void* src, int dt, h16* dst, int cout, int cin, int kpad) {
   const long total = (long)cout * kpad;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int n = (int)(i / kpad), col = (int)(i - (long)n * kpad);
@@ -268,18 +269,19 @@ __global__ void conv_weight_pack_kernel(const void* src, int dt, bf16* dst, int 
       int k = col / cin, c = col - k * cin;
       v = load_as_f32(src, dt, ((long)n * cin + c) * 3 + k);
     }
-    dst[i] = (bf16)v;
+    dst[i] = (h16)v;
   }
 }
 static int grid_for(long n) { long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
-void launch_convert_to_bf16(const void* src, int dt, bf16* dst, long n, hipStream_t s) {
+void launch_convert_to_h16(const void* src, int dt, h16* dst, long n, hipStream_t s) {
   hipLaunchKernelGGL(convert_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dt, dst, n);
 }
 void launch_convert_to_f32(const void* src, int dt, float* dst, long n, hipStream_t s) {
   hipLaunchKernelGGL(convert_to_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dt, dst, n);
 }
-void launch_conv_weight_pack(const void* src, int dt, bf16* dst, int cout, int cin, int kpad, hipStream_t s) {
+void launch_conv_weight_pack(const void* src, int dt, h16* dst, int cout, int cin, int kpad, hipStream_t s) {
   hipLaunchKernelGGL(conv_weight_pack_kernel, dim3(grid_for((long)cout * kpad)), dim3(256), 0, s, src, dt, dst, cout, cin, kpad);
 }
 
+}  // inline namespace AXW_NS
 }  // namespace axw

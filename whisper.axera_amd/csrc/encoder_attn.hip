@@ -10,22 +10,23 @@
 //   S^T = K Q^T  (A = K tile rows from LDS, B = Q rows held in registers for the whole kernel):
 //     the 32x32 accumulator then has the QUERY on the lane and the keys in registers, so the
 //     row max / row sum are per-lane reductions plus one lane^32 exchange;
-//   the exponentiated accumulator registers, narrowed pairwise to bf16, ARE the B operand of
+//   the exponentiated accumulator registers, narrowed pairwise to h16, ARE the B operand of
 //   O^T = V^T P^T with no lane movement (cdna guide §3, accumulator-as-operand); the A operand
 //   is read from the V^T tile with the matching permuted key order (two 8-byte reads).
 //   V^T comes for free from the QKV GEMM's swapped-operand epilogue (gemm.hip).
-// LDS: K tile [64 keys][64 d] + V^T tile [64 d][64 keys], bf16, XOR-swizzled 16-byte chunks.
+// LDS: K tile [64 keys][64 d] + V^T tile [64 d][64 keys], h16, XOR-swizzled 16-byte chunks.
 // Work per (clip, layer): 4*T^2*64*H flops = 6.9 GFLOP (small); HBM: Q,K,V read once per
 // 128-row block (K,V stay in ONE L2 across the 12 blocks of a head: XCD-aware block order), O written once.
 #include "common.hpp"
 #include <type_traits>
 
 namespace axw {
+inline namespace AXW_NS {
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + 16 * (chunk ^ ((row >> 1) & 7)); }
 
-__global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
-                                                                const bf16* __restrict__ VT, bf16* __restrict__ O, int T,
+__global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const h16* __restrict__ Q, const h16* __restrict__ K,
+                                                                const h16* __restrict__ VT, h16* __restrict__ O, int T,
                                                                 int t_pad, int d_model, int n_head) {
   __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
   __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
@@ -50,13 +51,13 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const bf16* _
   const int q_row = qblk * 128 + wave * 32 + r;
   const int q_ld = min(q_row, T - 1);
 
-  const bf16* Qb = Q + ((long)b * T) * d_model + head * 64;
-  const bf16* Kb = K + ((long)b * T) * d_model + head * 64;
-  const bf16* Vb = VT + ((long)b * n_head + head) * 64 * t_pad;
+  const h16* Qb = Q + ((long)b * T) * d_model + head * 64;
+  const h16* Kb = K + ((long)b * T) * d_model + head * 64;
+  const h16* Vb = VT + ((long)b * n_head + head) * 64 * t_pad;
 
-  bf16x8 qf[4];
+  h16x8 qf[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qb + (long)q_ld * d_model + 16 * s + 8 * h);
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const h16x8*>(Qb + (long)q_ld * d_model + 16 * s + 8 * h);
 
   f32x16 oacc[2];
 #pragma unroll
@@ -104,8 +105,8 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const bf16* _
       for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + swz128(kb * 32 + r, 2 * s + h));
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+        h16x8 kf = *reinterpret_cast<const h16x8*>(Ks + swz128(kb * 32 + r, 2 * s + h));
+        sacc[kb] = AXW_MFMA_32x32x16(kf, qf[s], sacc[kb]);
       }
     }
     // ---- online softmax (fp32, base-2)
@@ -126,14 +127,14 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const bf16* _
     m_run = m_new;
     const float m_sc = m_new * sc;
     float ls = 0.f;
-    bf16x8 pf[2][2];
+    h16x8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], sc, -m_sc));
         ls += pv;
-        pf[kb][e >> 3][e & 7] = (bf16)pv;
+        pf[kb][e >> 3][e & 7] = (h16)pv;
       }
     l_run = l_run * alpha + ls;
 #pragma unroll
@@ -149,12 +150,12 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const bf16* _
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const int row = db * 32 + r, c0 = 4 * kb + 2 * s2;
-          bf16x4 lo = *reinterpret_cast<const bf16x4*>(Vs + swz128(row, c0) + 8 * h);
-          bf16x4 hi = *reinterpret_cast<const bf16x4*>(Vs + swz128(row, c0 + 1) + 8 * h);
-          bf16x8 vf;
+          h16x4 lo = *reinterpret_cast<const h16x4*>(Vs + swz128(row, c0) + 8 * h);
+          h16x4 hi = *reinterpret_cast<const h16x4*>(Vs + swz128(row, c0 + 1) + 8 * h);
+          h16x8 vf;
 #pragma unroll
           for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], oacc[db], 0, 0, 0);
+          oacc[db] = AXW_MFMA_32x32x16(vf, pf[kb][s2], oacc[db]);
         }
 
   };
@@ -172,23 +173,24 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const bf16* _
   const float l = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l;
   if (q_row < T) {
-    bf16* orow = O + ((long)b * T + q_row) * d_model + head * 64;
+    h16* orow = O + ((long)b * T + q_row) * d_model + head * 64;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        bf16x4 pk;
+        h16x4 pk;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pk[e] = (bf16)(oacc[db][4 * g + e] * inv);
-        *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * g + 4 * h) = pk;
+        for (int e = 0; e < 4; ++e) pk[e] = (h16)(oacc[db][4 * g + e] * inv);
+        *reinterpret_cast<h16x4*>(orow + db * 32 + 8 * g + 4 * h) = pk;
       }
   }
 }
 
-void launch_encoder_attention(const bf16* q, const bf16* k, const bf16* vt, bf16* o, int batch, int T, int t_pad, int d_model,
+void launch_encoder_attention(const h16* q, const h16* k, const h16* vt, h16* o, int batch, int T, int t_pad, int d_model,
                               int n_head, hipStream_t s) {
   dim3 grid(((T + 127) / 128) * n_head * batch);
   hipLaunchKernelGGL(encoder_attention_kernel, grid, dim3(256), 0, s, q, k, vt, o, T, t_pad, d_model, n_head);
 }
 
+}  // inline namespace AXW_NS
 }  // namespace axw

@@ -12,6 +12,7 @@
 #include "host_io.hpp"
 
 namespace axw {
+inline namespace AXW_NS {
 
 #define HIP_CHECK(expr)                                                                                  \
   do {                                                                                                   \
@@ -32,6 +33,20 @@ static int logits_rt() {
 }
 
 static int dtype_code(const std::string& d) { return d == "F32" ? 0 : d == "BF16" ? 1 : 2; }
+
+// host: the bits of one stored h16 value -> float (bfloat16: the upper half of the fp32 pattern; half: IEEE binary16)
+static float h16_bits_to_float(uint16_t bits) {
+#if AXW_F16
+  _Float16 h;
+  memcpy(&h, &bits, 2);
+  return (float)h;
+#else
+  const uint32_t u = (uint32_t)bits << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+#endif
+}
 
 // ------------------------------------------------------------------------------ construction
 Engine::Engine(const std::string& model_type, const std::string& model_path, const std::string& language, int device,
@@ -100,6 +115,7 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
     cfg_.ints["batched_ln"] = batched_ln_ ? 1 : 0;
   }
   cfg_.ints["t2s"] = t2s_ ? 1 : 0;
+  cfg_.ints["fp16"] = AXW_F16;  // 16-bit storage / MFMA operand type of this engine: 0 bfloat16, 1 IEEE half
   ensure_capacity(std::max(1, max_batch));
   HIP_CHECK(hipStreamSynchronize(own_stream_));
 }
@@ -241,28 +257,28 @@ void Engine::load_weights(const std::string& path) {
     launch_convert_to_f32(stage, dtype_code(t.dtype), dst, t.numel(), s);
     return dst;
   };
-  auto to_bf16_into = [&](const std::string& n, std::vector<int64_t> shape, bf16* dst) {
+  auto to_h16_into = [&](const std::string& n, std::vector<int64_t> shape, h16* dst) {
     const TensorView& t = check(n, shape);
     up(t);
-    launch_convert_to_bf16(stage, dtype_code(t.dtype), dst, t.numel(), s);
+    launch_convert_to_h16(stage, dtype_code(t.dtype), dst, t.numel(), s);
   };
   auto to_f32_into = [&](const std::string& n, std::vector<int64_t> shape, float* dst) {
     const TensorView& t = check(n, shape);
     up(t);
     launch_convert_to_f32(stage, dtype_code(t.dtype), dst, t.numel(), s);
   };
-  auto new_bf16 = [&](size_t n) { bf16* p = (bf16*)dalloc(n * 2, true); allocs_.push_back(p); return p; };
+  auto new_h16 = [&](size_t n) { h16* p = (h16*)dalloc(n * 2, true); allocs_.push_back(p); return p; };
   auto new_f32 = [&](size_t n) { float* p = (float*)dalloc(n * 4, true); allocs_.push_back(p); return p; };
 
   // conv stem: [Cout][Cin][3] -> GEMM weights with k-major taps (gemm.hip header)
   conv1_k_ = ((3 * nm + 63) / 64) * 64;
-  conv1_w_ = new_bf16((size_t)d * conv1_k_);
+  conv1_w_ = new_h16((size_t)d * conv1_k_);
   {
     const TensorView& t = check("encoder.conv1.weight", {d, nm, 3});
     up(t);
     launch_conv_weight_pack(stage, dtype_code(t.dtype), conv1_w_, d, nm, conv1_k_, s);
   }
-  conv2_w_ = new_bf16((size_t)d * 3 * d);
+  conv2_w_ = new_h16((size_t)d * 3 * d);
   {
     const TensorView& t = check("encoder.conv2.weight", {d, d, 3});
     up(t);
@@ -289,24 +305,24 @@ void Engine::load_weights(const std::string& path) {
   ln_post_b_ = to_f32("encoder.ln_post.bias", {d});
 
   // attention block: q,k,v rows concatenated [3d][d]; key has no bias (upstream: bias=False)
-  auto load_attn = [&](const std::string& pre, bf16*& w_qkv, float*& b_qkv, bf16*& w_o, float*& b_o) {
-    w_qkv = new_bf16((size_t)3 * d * d);
+  auto load_attn = [&](const std::string& pre, h16*& w_qkv, float*& b_qkv, h16*& w_o, float*& b_o) {
+    w_qkv = new_h16((size_t)3 * d * d);
     b_qkv = new_f32((size_t)3 * d);
-    to_bf16_into(pre + ".query.weight", {d, d}, w_qkv);
-    to_bf16_into(pre + ".key.weight", {d, d}, w_qkv + (size_t)d * d);
-    to_bf16_into(pre + ".value.weight", {d, d}, w_qkv + (size_t)2 * d * d);
+    to_h16_into(pre + ".query.weight", {d, d}, w_qkv);
+    to_h16_into(pre + ".key.weight", {d, d}, w_qkv + (size_t)d * d);
+    to_h16_into(pre + ".value.weight", {d, d}, w_qkv + (size_t)2 * d * d);
     to_f32_into(pre + ".query.bias", {d}, b_qkv);
     to_f32_into(pre + ".value.bias", {d}, b_qkv + 2 * d);
-    w_o = new_bf16((size_t)d * d);
-    to_bf16_into(pre + ".out.weight", {d, d}, w_o);
+    w_o = new_h16((size_t)d * d);
+    to_h16_into(pre + ".out.weight", {d, d}, w_o);
     b_o = to_f32(pre + ".out.bias", {d});
   };
-  auto load_mlp = [&](const std::string& pre, bf16*& w1, float*& b1, bf16*& w2, float*& b2) {
-    w1 = new_bf16((size_t)4 * d * d);
-    to_bf16_into(pre + ".mlp.0.weight", {4 * d, d}, w1);
+  auto load_mlp = [&](const std::string& pre, h16*& w1, float*& b1, h16*& w2, float*& b2) {
+    w1 = new_h16((size_t)4 * d * d);
+    to_h16_into(pre + ".mlp.0.weight", {4 * d, d}, w1);
     b1 = to_f32(pre + ".mlp.0.bias", {4 * d});
-    w2 = new_bf16((size_t)4 * d * d);
-    to_bf16_into(pre + ".mlp.2.weight", {d, 4 * d}, w2);
+    w2 = new_h16((size_t)4 * d * d);
+    to_h16_into(pre + ".mlp.2.weight", {d, 4 * d}, w2);
     b2 = to_f32(pre + ".mlp.2.bias", {d});
   };
 
@@ -323,46 +339,46 @@ void Engine::load_weights(const std::string& path) {
   }
 
   // cross K/V projection of every decoder layer as ONE GEMM: rows [all K | all V] (gemm.hip EPI_CROSS_KV)
-  w_cross_kv_ = new_bf16((size_t)2 * L * d * d);
+  w_cross_kv_ = new_h16((size_t)2 * L * d * d);
   b_cross_kv_ = new_f32((size_t)2 * L * d);
   // decoder layer weights live in two arenas with a fixed per-layer stride (layout: DecArena in common.hpp), so the
   // persistent decode kernel derives every address from two base pointers with scalar arithmetic
-  dec_w_arena_ = new_bf16((size_t)L * DecArena::w_stride(d));
+  dec_w_arena_ = new_h16((size_t)L * DecArena::w_stride(d));
   dec_f_arena_ = new_f32((size_t)L * DecArena::f_stride(d));
   dec_.resize(L);
   for (int i = 0; i < L; ++i) {
     const std::string pre = "decoder.blocks." + std::to_string(i);
     DecLayerW& w = dec_[i];
-    bf16* wb = dec_w_arena_ + (size_t)i * DecArena::w_stride(d);
+    h16* wb = dec_w_arena_ + (size_t)i * DecArena::w_stride(d);
     float* fb = dec_f_arena_ + (size_t)i * DecArena::f_stride(d);
     const size_t dd = (size_t)d * d;
-    bf16 *w_qkv = wb + DecArena::W_QKV * dd, *w_o = wb + DecArena::W_O * dd, *w_cq = wb + DecArena::W_CQ * dd,
+    h16 *w_qkv = wb + DecArena::W_QKV * dd, *w_o = wb + DecArena::W_O * dd, *w_cq = wb + DecArena::W_CQ * dd,
          *w_co = wb + DecArena::W_CO * dd, *w_fc1 = wb + DecArena::W_FC1 * dd, *w_fc2 = wb + DecArena::W_FC2 * dd;
     auto f = [&](int off) { return fb + (size_t)off * d; };
     to_f32_into(pre + ".attn_ln.weight", {d}, f(DecArena::F_ATTN_LN_W));
     to_f32_into(pre + ".attn_ln.bias", {d}, f(DecArena::F_ATTN_LN_B));
     // q,k,v rows concatenated [3d][d]; key has no bias (upstream: bias=False): the arena is zero-initialised
-    to_bf16_into(pre + ".attn.query.weight", {d, d}, w_qkv);
-    to_bf16_into(pre + ".attn.key.weight", {d, d}, w_qkv + dd);
-    to_bf16_into(pre + ".attn.value.weight", {d, d}, w_qkv + 2 * dd);
+    to_h16_into(pre + ".attn.query.weight", {d, d}, w_qkv);
+    to_h16_into(pre + ".attn.key.weight", {d, d}, w_qkv + dd);
+    to_h16_into(pre + ".attn.value.weight", {d, d}, w_qkv + 2 * dd);
     to_f32_into(pre + ".attn.query.bias", {d}, f(DecArena::F_B_QKV));
     to_f32_into(pre + ".attn.value.bias", {d}, f(DecArena::F_B_QKV) + 2 * d);
-    to_bf16_into(pre + ".attn.out.weight", {d, d}, w_o);
+    to_h16_into(pre + ".attn.out.weight", {d, d}, w_o);
     to_f32_into(pre + ".attn.out.bias", {d}, f(DecArena::F_B_O));
     to_f32_into(pre + ".cross_attn_ln.weight", {d}, f(DecArena::F_CROSS_LN_W));
     to_f32_into(pre + ".cross_attn_ln.bias", {d}, f(DecArena::F_CROSS_LN_B));
-    to_bf16_into(pre + ".cross_attn.query.weight", {d, d}, w_cq);
+    to_h16_into(pre + ".cross_attn.query.weight", {d, d}, w_cq);
     to_f32_into(pre + ".cross_attn.query.bias", {d}, f(DecArena::F_B_CQ));
-    to_bf16_into(pre + ".cross_attn.key.weight", {d, d}, w_cross_kv_ + (size_t)i * d * d);
-    to_bf16_into(pre + ".cross_attn.value.weight", {d, d}, w_cross_kv_ + (size_t)(L + i) * d * d);
+    to_h16_into(pre + ".cross_attn.key.weight", {d, d}, w_cross_kv_ + (size_t)i * d * d);
+    to_h16_into(pre + ".cross_attn.value.weight", {d, d}, w_cross_kv_ + (size_t)(L + i) * d * d);
     to_f32_into(pre + ".cross_attn.value.bias", {d}, b_cross_kv_ + (size_t)(L + i) * d);
-    to_bf16_into(pre + ".cross_attn.out.weight", {d, d}, w_co);
+    to_h16_into(pre + ".cross_attn.out.weight", {d, d}, w_co);
     to_f32_into(pre + ".cross_attn.out.bias", {d}, f(DecArena::F_B_CO));
     to_f32_into(pre + ".mlp_ln.weight", {d}, f(DecArena::F_MLP_LN_W));
     to_f32_into(pre + ".mlp_ln.bias", {d}, f(DecArena::F_MLP_LN_B));
-    to_bf16_into(pre + ".mlp.0.weight", {4 * d, d}, w_fc1);
+    to_h16_into(pre + ".mlp.0.weight", {4 * d, d}, w_fc1);
     to_f32_into(pre + ".mlp.0.bias", {4 * d}, f(DecArena::F_B_FC1));
-    to_bf16_into(pre + ".mlp.2.weight", {d, 4 * d}, w_fc2);
+    to_h16_into(pre + ".mlp.2.weight", {d, 4 * d}, w_fc2);
     to_f32_into(pre + ".mlp.2.bias", {d}, f(DecArena::F_B_FC2));
     w.attn_ln_w = f(DecArena::F_ATTN_LN_W); w.attn_ln_b = f(DecArena::F_ATTN_LN_B);
     w.cross_ln_w = f(DecArena::F_CROSS_LN_W); w.cross_ln_b = f(DecArena::F_CROSS_LN_B);
@@ -371,16 +387,16 @@ void Engine::load_weights(const std::string& path) {
     w.b_qkv = f(DecArena::F_B_QKV); w.b_o = f(DecArena::F_B_O); w.b_cq = f(DecArena::F_B_CQ); w.b_co = f(DecArena::F_B_CO);
     w.b_fc1 = f(DecArena::F_B_FC1); w.b_fc2 = f(DecArena::F_B_FC2);
   }
-  tok_emb_ = new_bf16((size_t)cfg_.n_vocab * d);
-  to_bf16_into("decoder.token_embedding.weight", {cfg_.n_vocab, d}, tok_emb_);
+  tok_emb_ = new_h16((size_t)cfg_.n_vocab * d);
+  to_h16_into("decoder.token_embedding.weight", {cfg_.n_vocab, d}, tok_emb_);
   dec_pos_ = to_f32("decoder.positional_embedding", {cfg_.n_text_ctx, d});
   dec_ln_w_ = to_f32("decoder.ln.weight", {d});
   dec_ln_b_ = to_f32("decoder.ln.bias", {d});
   // fragment-major copies of the decoder weights for the batched (MFMA) decode path (decode_gemm.hip)
-  auto pack = [&](const bf16* w, int N, int K) {
-    bf16* wp = new_bf16((size_t)((N + 15) / 16) * 16 * K);
+  auto pack = [&](const h16* w, int N, int K) {
+    h16* wp = new_h16((size_t)((N + 15) / 16) * 16 * K);
     launch_pack_weight_frag(w, wp, N, K, s);
-    return (const bf16*)wp;
+    return (const h16*)wp;
   };
   dec_packed_.resize(L);
   for (int i = 0; i < L; ++i) {
@@ -439,27 +455,27 @@ void Engine::ensure_capacity(int batch) {
   d_gmax_ = (unsigned*)A((size_t)B * 4);
   d_logmel_ = (float*)A((size_t)B * kFramesOut * nm * 4);
   d_mel_ref_ = (float*)A((size_t)B * nm * kFramesOut * 4);
-  d_mel_tm_ = (bf16*)A((size_t)B * mel_rows_ * nm * 2 + 4096, true);
-  d_h1_ = (bf16*)A((size_t)B * h1_rows_ * d * 2 + 4096, true);
+  d_mel_tm_ = (h16*)A((size_t)B * mel_rows_ * nm * 2 + 4096, true);
+  d_h1_ = (h16*)A((size_t)B * h1_rows_ * d * 2 + 4096, true);
   d_x_ = (float*)A((size_t)B * T * d * 4);
-  d_ln_ = (bf16*)A((size_t)B * T * d * 2);
-  d_q_ = (bf16*)A((size_t)B * T * d * 2);
-  d_k_ = (bf16*)A((size_t)B * T * d * 2);
-  d_vt_ = (bf16*)A((size_t)B * d * t_pad_ * 2, true);
-  d_attn_ = (bf16*)A((size_t)B * T * d * 2);
-  d_ffn_ = (bf16*)A((size_t)B * T * 4 * d * 2);
-  d_cross_k_ = (bf16*)A((size_t)L * B * H * t_pad_ * 64 * 2, true);
-  d_cross_v_ = (bf16*)A((size_t)L * B * H * t_pad_ * 64 * 2, true);
-  d_self_k_ = (bf16*)A((size_t)L * B * H * Tc * 64 * 2, true);
-  d_self_v_ = (bf16*)A((size_t)L * B * H * Tc * 64 * 2, true);
+  d_ln_ = (h16*)A((size_t)B * T * d * 2);
+  d_q_ = (h16*)A((size_t)B * T * d * 2);
+  d_k_ = (h16*)A((size_t)B * T * d * 2);
+  d_vt_ = (h16*)A((size_t)B * d * t_pad_ * 2, true);
+  d_attn_ = (h16*)A((size_t)B * T * d * 2);
+  d_ffn_ = (h16*)A((size_t)B * T * 4 * d * 2);
+  d_cross_k_ = (h16*)A((size_t)L * B * H * t_pad_ * 64 * 2, true);
+  d_cross_v_ = (h16*)A((size_t)L * B * H * t_pad_ * 64 * 2, true);
+  d_self_k_ = (h16*)A((size_t)L * B * H * Tc * 64 * 2, true);
+  d_self_v_ = (h16*)A((size_t)L * B * H * Tc * 64 * 2, true);
   d_xdec_ = (float*)A((size_t)B * d * 4, true);
   d_qdec_ = (float*)A((size_t)B * d * 4, true);
   d_hid_ = (float*)A((size_t)B * 4 * d * 4, true);
   nbs_ = (B + 15) / 16;
-  for (int i = 0; i < 2; ++i) {  // fragment-major bf16 (hi, lo) activation pairs of the batched (MFMA) decode path
-    d_act_[i] = (bf16*)A((size_t)nbs_ * 16 * d * 2, true);
-    d_att_[i] = (bf16*)A((size_t)nbs_ * 16 * d * 2, true);
-    d_hidp_[i] = (bf16*)A((size_t)nbs_ * 16 * 4 * d * 2, true);
+  for (int i = 0; i < 2; ++i) {  // fragment-major h16 (hi, lo) activation pairs of the batched (MFMA) decode path
+    d_act_[i] = (h16*)A((size_t)nbs_ * 16 * d * 2, true);
+    d_att_[i] = (h16*)A((size_t)nbs_ * 16 * d * 2, true);
+    d_hidp_[i] = (h16*)A((size_t)nbs_ * 16 * 4 * d * 2, true);
   }
   split_cross_ = B <= 2 ? 8 : 3;  // the VALU path serves <= 4 clips; larger batches use one split per (clip, head)
   split_self_ = 2;
@@ -541,7 +557,7 @@ void Engine::run_encoder(int batch) {
   g.M = T; g.N = d; g.K = 3 * d; g.batch = batch; g.d_model = d; g.epilogue = EPI_GELU_POS_F32;
   launch_gemm(g, s);
 
-  auto linear = [&](const bf16* A, int K, const bf16* W, const float* bias, void* C, int N, int epi) {
+  auto linear = [&](const h16* A, int K, const h16* W, const float* bias, void* C, int N, int epi) {
     GemmParams q{};
     q.A = A; q.lda = K; q.a_batch_stride = (long)T * K;
     q.W = W; q.bias = bias; q.C = C; q.ldc = N; q.c_batch_stride = (long)T * N;
@@ -615,7 +631,7 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
       if (step_mask_ & 1) launch_gemv(q, s);
     }
   };
-  auto attn = [&](const bf16* kc, const bf16* vc, long stride, int n_keys, int cap_blocks, float* part, int n_split) {
+  auto attn = [&](const h16* kc, const h16* vc, long stride, int n_keys, int cap_blocks, float* part, int n_split) {
     DecAttnParams a{};
     a.q = d_qdec_; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = part; a.n_split = n_split;
     a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
@@ -626,10 +642,10 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
   const long self_stride = (long)H * Tc * 64, cross_stride = (long)H * t_pad_ * 64;
   for (int l = 0; l < L; ++l) {
     const DecLayerW& w = dec_[l];
-    bf16* sk = d_self_k_ + (size_t)l * cap_ * self_stride;
-    bf16* sv = d_self_v_ + (size_t)l * cap_ * self_stride;
-    const bf16* ck = d_cross_k_ + (size_t)l * cap_ * cross_stride;
-    const bf16* cv = d_cross_v_ + (size_t)l * cap_ * cross_stride;
+    h16* sk = d_self_k_ + (size_t)l * cap_ * self_stride;
+    h16* sv = d_self_v_ + (size_t)l * cap_ * self_stride;
+    const h16* ck = d_cross_k_ + (size_t)l * cap_ * cross_stride;
+    const h16* cv = d_cross_v_ + (size_t)l * cap_ * cross_stride;
     GemvParams p{};
     // q,k,v = Linear(attn_ln(x)); k,v appended to the self cache at row `step` (export_onnx.py:245-247, Whisper.cpp:328-342)
     p.W = w.w_qkv; p.bias = w.b_qkv; p.N = 3 * d; p.K = d;
@@ -689,7 +705,7 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
 
 // Decoder layers of clips [b0, b0 + nb) as clip-block GEMMs (decode_cgemm_kernel): LayerNorm is the prologue of its
 // consumer and the residual add the epilogue of its producer, so a layer is 7 launches instead of 11
-// (AX_WHISPER_BATCHED_LN=0: the older sequence with a separate LayerNorm/bf16-pair preparation launch and split-K
+// (AX_WHISPER_BATCHED_LN=0: the older sequence with a separate LayerNorm/h16-pair preparation launch and split-K
 // partials). b0 is a multiple of 16: every per-clip buffer of the range starts at a whole clip block.
 void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
   const int d = cfg_.n_text_state, H = cfg_.n_text_head, L = cfg_.n_text_layer, Tc = cfg_.n_text_ctx;
@@ -697,9 +713,9 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
   const long frag0 = (long)(b0 / 16) * 512;  // fragment-major pair layouts: clip blocks are 512 elements apart within a k-step
   float* x = d_xdec_ + (long)b0 * d;
   float* qd = d_qdec_ + (long)b0 * d;
-  bf16 *att_hi = d_att_[0] + frag0, *att_lo = d_att_[1] + frag0, *hid_hi = d_hidp_[0] + frag0, *hid_lo = d_hidp_[1] + frag0;
+  h16 *att_hi = d_att_[0] + frag0, *att_lo = d_att_[1] + frag0, *hid_hi = d_hidp_[0] + frag0, *hid_lo = d_hidp_[1] + frag0;
   const int* done = forced ? nullptr : d_done_ + b0;
-  auto cgemm = [&](const bf16* W, const float* bias, int N, int K, int epi, int rt) {
+  auto cgemm = [&](const h16* W, const float* bias, int N, int K, int epi, int rt) {
     DecCGemmParams c{};
     c.W = W; c.bias = bias; c.N = N; c.K = K; c.batch = nb; c.nbs = nbs_; c.epilogue = epi; c.rt = rt;
     c.d_model = d; c.n_ctx_pad = Tc; c.state = d_state_;
@@ -707,7 +723,7 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
   };
   static const bool fuse_cq = [] { const char* e = getenv("AX_WHISPER_FUSE_CQ"); return !(e && e[0] == '0'); }();
   auto cgo = [&](const DecCGemmParams& c) { if (step_mask_ & 1) launch_decode_cgemm(c, s); };
-  auto attn = [&](const bf16* kc, const bf16* vc, long stride, int n_keys, int cap_blocks) {
+  auto attn = [&](const h16* kc, const h16* vc, long stride, int n_keys, int cap_blocks) {
     DecAttnParams a{};
     a.q = qd; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = nullptr; a.n_split = 1;
     a.batch = nb; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
@@ -722,10 +738,10 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
   for (int l = 0; l < L; ++l) {
     const DecLayerW& w = dec_[l];
     const DecLayerWP& wq = dec_packed_[l];
-    bf16* sk = d_self_k_ + ((size_t)l * cap_ + b0) * self_stride;
-    bf16* sv = d_self_v_ + ((size_t)l * cap_ + b0) * self_stride;
-    const bf16* ck = d_cross_k_ + ((size_t)l * cap_ + b0) * cross_stride;
-    const bf16* cv = d_cross_v_ + ((size_t)l * cap_ + b0) * cross_stride;
+    h16* sk = d_self_k_ + ((size_t)l * cap_ + b0) * self_stride;
+    h16* sv = d_self_v_ + ((size_t)l * cap_ + b0) * self_stride;
+    const h16* ck = d_cross_k_ + ((size_t)l * cap_ + b0) * cross_stride;
+    const h16* cv = d_cross_v_ + ((size_t)l * cap_ + b0) * cross_stride;
     DecCGemmParams c = cgemm(wq.w_qkv, w.b_qkv, 3 * d, d, GEPI_QKV_CACHE, rt_for(3 * d));
     c.x = x; c.ln_w = w.attn_ln_w; c.ln_b = w.attn_ln_b;
     c.out = qd; c.k_cache = sk; c.v_cache = sv; c.kv_batch_stride = self_stride;
@@ -767,7 +783,7 @@ int Engine::decode_branches(int batch) const {
   return std::max(n, 1);
 }
 
-// Batched variant (5+ clips): LayerNorm -> bf16 pairs (act_prep), MFMA GEMMs that read the weights once for the
+// Batched variant (5+ clips): LayerNorm -> h16 pairs (act_prep), MFMA GEMMs that read the weights once for the
 // whole batch, one attention workgroup per (clip, head) writing its output directly (no split partials).
 void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits,
                                          long logits_stride, int* d_argmax) {
@@ -800,7 +816,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
       if (KS % k == 0 && KS / k >= 8) return k;
     return 1;
   };
-  auto resid = [&](const bf16* W, const float* bias, int K, const bf16* ahi, const bf16* alo) {
+  auto resid = [&](const h16* W, const float* bias, int K, const h16* ahi, const h16* alo) {
     DecGemmParams p{};
     p.W = W; p.bias = nullptr; p.N = d; p.K = K; p.a_hi = ahi; p.a_lo = alo; p.epilogue = GEPI_PARTIAL; p.rt = 1;
     p.d_model = d; p.n_ctx_pad = Tc; p.state = d_state_; p.out = d_part_; p.ksplit = ksplit_for(K); p.part_batch = cap_;
@@ -808,7 +824,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     pend_n = p.ksplit;
     pend_bias = bias;
   };
-  auto attn = [&](const bf16* kc, const bf16* vc, long stride, int n_keys, int cap_blocks) {
+  auto attn = [&](const h16* kc, const h16* vc, long stride, int n_keys, int cap_blocks) {
     DecAttnParams a{};
     a.q = d_qdec_; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = nullptr; a.n_split = 1;
     a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
@@ -816,7 +832,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     a.out_hi = d_att_[0]; a.out_lo = d_att_[1]; a.nbs = nbs_;
     if (step_mask_ & 2) launch_decode_attention(a, s);
   };
-  auto base = [&](const bf16* W, const float* bias, int N, int K, const bf16* ahi, const bf16* alo, int epi) {
+  auto base = [&](const h16* W, const float* bias, int N, int K, const h16* ahi, const h16* alo, int epi) {
     DecGemmParams p{};
     p.W = W; p.bias = bias; p.N = N; p.K = K; p.a_hi = ahi; p.a_lo = alo; p.epilogue = epi; p.rt = 1;
     p.d_model = d; p.n_ctx_pad = Tc; p.state = d_state_;
@@ -849,10 +865,10 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
   }
   for (int l = 0; l < L && !batched_ln_; ++l) {
     const DecLayerW& w = dec_[l];
-    bf16* sk = d_self_k_ + (size_t)l * cap_ * self_stride;
-    bf16* sv = d_self_v_ + (size_t)l * cap_ * self_stride;
-    const bf16* ck = d_cross_k_ + (size_t)l * cap_ * cross_stride;
-    const bf16* cv = d_cross_v_ + (size_t)l * cap_ * cross_stride;
+    h16* sk = d_self_k_ + (size_t)l * cap_ * self_stride;
+    h16* sv = d_self_v_ + (size_t)l * cap_ * self_stride;
+    const h16* ck = d_cross_k_ + (size_t)l * cap_ * cross_stride;
+    const h16* cv = d_cross_v_ + (size_t)l * cap_ * cross_stride;
     ln(w.attn_ln_w, w.attn_ln_b);
     const DecLayerWP& wp = dec_packed_[l];
     DecGemmParams p = base(wp.w_qkv, w.b_qkv, 3 * d, d, d_act_[0], d_act_[1], GEPI_QKV_CACHE);
@@ -1126,11 +1142,9 @@ void Engine::get_cross_kv(int slot, float* k_out, float* v_out) {
     for (int h = 0; h < H; ++h)
       for (int t = 0; t < T; ++t)
         for (int c = 0; c < 64; ++c) {
-          uint32_t kb = (uint32_t)hk[(size_t)h * t_pad_ * 64 + (size_t)(t >> 6) * 4096 + (c >> 3) * 512 + (t & 63) * 8 + (c & 7)] << 16;
-          uint32_t vb = (uint32_t)hv[(size_t)h * t_pad_ * 64 + (size_t)t * 64 + c] << 16;
-          float kf, vf;
-          memcpy(&kf, &kb, 4);
-          memcpy(&vf, &vb, 4);
+          const uint16_t kbits = hk[(size_t)h * t_pad_ * 64 + (size_t)(t >> 6) * 4096 + (c >> 3) * 512 + (t & 63) * 8 + (c & 7)];
+          const uint16_t vbits = hv[(size_t)h * t_pad_ * 64 + (size_t)t * 64 + c];
+          const float kf = h16_bits_to_float(kbits), vf = h16_bits_to_float(vbits);
           k_out[((size_t)l * T + t) * d + h * 64 + c] = kf;
           v_out[((size_t)l * T + t) * d + h * 64 + c] = vf;
         }
@@ -1232,4 +1246,15 @@ float Engine::bench(const std::string& what, int batch, int arg, int iters) {
   return ms;
 }
 
+}  // inline namespace AXW_NS
+
+#if AXW_F16
+IEngine* make_engine_f16(const std::string& model_type, const std::string& model_path, const std::string& language, int device, int max_batch) {
+  return new hf::Engine(model_type, model_path, language, device, max_batch);
+}
+#else
+IEngine* make_engine_bf16(const std::string& model_type, const std::string& model_path, const std::string& language, int device, int max_batch) {
+  return new bf::Engine(model_type, model_path, language, device, max_batch);
+}
+#endif
 }  // namespace axw

@@ -14,52 +14,38 @@
 #include <vector>
 
 #include "common.hpp"
+#include "iengine.hpp"
 #include "t2s.hpp"
 
 namespace axw {
+inline namespace AXW_NS {
 
-struct ModelConfig {
-  int n_mels = 0, n_audio_ctx = 1500, n_audio_state = 0, n_audio_head = 0, n_audio_layer = 0;
-  int n_vocab = 0, n_text_ctx = 448, n_text_state = 0, n_text_head = 0, n_text_layer = 0;
-  int sot = 0, eot = 0, transcribe = 0, translate = 0, no_timestamps = 0;
-  std::vector<int> lang_tokens;
-  std::vector<std::string> lang_codes;
-  std::map<std::string, long> ints;  // every integer-valued key of the config file
-};
-
-class Engine {
+class Engine final : public IEngine {
  public:
   Engine(const std::string& model_type, const std::string& model_path, const std::string& language, int device, int max_batch);
-  ~Engine();
+  ~Engine() override;
   Engine(const Engine&) = delete;
 
-  // full path, host PCM or device PCM; ids [batch][n_text_ctx], n_ids [batch]
   void run_tokens(const float* const* pcm, const float* d_pcm, int d_stride, const int* n_samples, int batch, int max_new,
-                  int32_t* ids, int* n_ids);
-  std::string detokenize(const int32_t* ids, int n) const;
-  // detokenize + the reference's zh post-pass (Traditional -> Simplified, Whisper.cpp:231-236) when its OpenCC data files were found
-  std::string transcript(const int32_t* ids, int n) const;
+                  int32_t* ids, int* n_ids) override;
+  std::string detokenize(const int32_t* ids, int n) const override;
+  std::string transcript(const int32_t* ids, int n) const override;
   bool has_t2s() const { return (bool)t2s_; }
-
-  // stage-level
-  void compute_mel(const float* pcm, int n_samples, float* mel_out);
-  void encode_mel(const float* mel, int batch);
-  void get_cross_kv(int slot, float* k_out, float* v_out);
-  void decode_forced(int batch, const int32_t* forced, int n_forced, float* logits, int32_t* argmax_ids);
-  // max_new_clip: optional host [batch] per-clip id budgets (<= 0: none), each capped by max_new
-  void decode_greedy(int batch, int max_new, const int* max_new_clip, int32_t* ids, int* n_ids);
-  float bench(const std::string& what, int batch, int arg, int iters);
-
-  void set_stream(hipStream_t s) { user_stream_ = s; }
-  const ModelConfig& config() const { return cfg_; }
+  void compute_mel(const float* pcm, int n_samples, float* mel_out) override;
+  void encode_mel(const float* mel, int batch) override;
+  void get_cross_kv(int slot, float* k_out, float* v_out) override;
+  void decode_forced(int batch, const int32_t* forced, int n_forced, float* logits, int32_t* argmax_ids) override;
+  void decode_greedy(int batch, int max_new, const int* max_new_clip, int32_t* ids, int* n_ids) override;
+  float bench(const std::string& what, int batch, int arg, int iters) override;
+  void set_stream(void* s) override { user_stream_ = static_cast<hipStream_t>(s); }
+  const ModelConfig& config() const override { return cfg_; }
+  const char* dtype_name() const override { return kDtypeName; }
   const int* sot_seq() const { return sot_seq_; }
-  std::mutex& mutex() { return mu_; }
-  float timings[5] = {0, 0, 0, 0, 0};
 
  private:
   struct EncLayer {
     float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
-    bf16 *w_qkv, *w_o, *w_fc1, *w_fc2;
+    h16 *w_qkv, *w_o, *w_fc1, *w_fc2;
     float *b_qkv, *b_o, *b_fc1, *b_fc2;
   };
 
@@ -93,7 +79,6 @@ class Engine {
   std::vector<std::string> tokens_;
   std::unique_ptr<T2SConverter> t2s_;  // zh only
   std::string effective_lang_;
-  std::mutex mu_;
   int device_ = 0;
   bool device_set_ = false;
   void* load_stage_ = nullptr;  // staging buffer of load_weights
@@ -105,16 +90,16 @@ class Engine {
   std::vector<void*> slot_allocs_;  // capacity-dependent buffers
 
   // weights
-  bf16 *conv1_w_ = nullptr, *conv2_w_ = nullptr, *w_cross_kv_ = nullptr, *tok_emb_ = nullptr;
+  h16 *conv1_w_ = nullptr, *conv2_w_ = nullptr, *w_cross_kv_ = nullptr, *tok_emb_ = nullptr;
   float *conv1_b_ = nullptr, *conv2_b_ = nullptr, *enc_pos_ = nullptr, *ln_post_w_ = nullptr, *ln_post_b_ = nullptr;
   float *b_cross_kv_ = nullptr, *dec_pos_ = nullptr, *dec_ln_w_ = nullptr, *dec_ln_b_ = nullptr;
   int conv1_k_ = 0;
   std::vector<EncLayer> enc_;
   std::vector<DecLayerW> dec_;       // per-layer views into the two arenas below
-  bf16* dec_w_arena_ = nullptr; float* dec_f_arena_ = nullptr;
-  struct DecLayerWP { const bf16 *w_qkv, *w_o, *w_cq, *w_co, *w_fc1, *w_fc2; };
+  h16* dec_w_arena_ = nullptr; float* dec_f_arena_ = nullptr;
+  struct DecLayerWP { const h16 *w_qkv, *w_o, *w_cq, *w_co, *w_fc1, *w_fc2; };
   std::vector<DecLayerWP> dec_packed_;  // fragment-major copies for the batched decode path
-  const bf16* tok_emb_packed_ = nullptr;
+  const h16* tok_emb_packed_ = nullptr;
   int nbs_ = 1;                         // allocated clip blocks of 16
   // front-end constants
   float *twiddle_ = nullptr, *window_ = nullptr, *mel_basis_t_ = nullptr;
@@ -125,12 +110,12 @@ class Engine {
   int t_pad_ = 1536, mel_rows_ = 3004, h1_rows_ = 3002;
   float* d_pcm_ = nullptr; long pcm_stride_ = 0; float* h_pcm_ = nullptr;
   int* d_nsamp_ = nullptr; unsigned* d_gmax_ = nullptr; float* d_logmel_ = nullptr; float* d_mel_ref_ = nullptr;
-  bf16 *d_mel_tm_ = nullptr, *d_h1_ = nullptr, *d_ln_ = nullptr, *d_q_ = nullptr, *d_k_ = nullptr, *d_vt_ = nullptr,
+  h16 *d_mel_tm_ = nullptr, *d_h1_ = nullptr, *d_ln_ = nullptr, *d_q_ = nullptr, *d_k_ = nullptr, *d_vt_ = nullptr,
        *d_attn_ = nullptr, *d_ffn_ = nullptr;
   float* d_x_ = nullptr;
-  bf16 *d_cross_k_ = nullptr, *d_cross_v_ = nullptr, *d_self_k_ = nullptr, *d_self_v_ = nullptr;
+  h16 *d_cross_k_ = nullptr, *d_cross_v_ = nullptr, *d_self_k_ = nullptr, *d_self_v_ = nullptr;
   float *d_xdec_ = nullptr, *d_qdec_ = nullptr, *d_hid_ = nullptr, *d_part_self_ = nullptr, *d_part_cross_ = nullptr;
-  bf16 *d_act_[2] = {nullptr, nullptr}, *d_att_[2] = {nullptr, nullptr}, *d_hidp_[2] = {nullptr, nullptr};
+  h16 *d_act_[2] = {nullptr, nullptr}, *d_att_[2] = {nullptr, nullptr}, *d_hidp_[2] = {nullptr, nullptr};
   float* d_part_ = nullptr;
   float* d_amax_val_ = nullptr; int* d_amax_idx_ = nullptr; int n_amax_part_ = 0;
   int *d_tok_ = nullptr, *d_done_ = nullptr, *d_nout_ = nullptr, *d_out_ids_ = nullptr, *d_max_new_clip_ = nullptr;
@@ -151,4 +136,5 @@ class Engine {
   hipEvent_t ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
+}  // inline namespace AXW_NS
 }  // namespace axw

@@ -9,12 +9,13 @@
 // frames are staged in LDS ([32][400] f32, 51 KB), the 400-point DFT is evaluated directly with
 // a 400-entry twiddle table in LDS (each lane owns up to 4 bins x 8 frames = 64 accumulators),
 // the power spectrum goes back to LDS and the mel projection + log10 + clip maximum are fused in.
-// Kernel 2 (mel_normalize_kernel): clamp/scale/zero-fill and layout: time-major bf16 rows for the
+// Kernel 2 (mel_normalize_kernel): clamp/scale/zero-fill and layout: time-major h16 rows for the
 // encoder's conv-as-GEMM (and the reference's [n_mels][3000] f32 layout when a caller asks for it).
-// HBM traffic per clip: 1.92 MB PCM in, 0.96 MB log-mel scratch out+in, 0.48 MB bf16 out.
+// HBM traffic per clip: 1.92 MB PCM in, 0.96 MB log-mel scratch out+in, 0.48 MB h16 out.
 #include "common.hpp"
 
 namespace axw {
+inline namespace AXW_NS {
 
 constexpr int FR = 32;        // frames per workgroup
 constexpr int PW_LD = 208;    // power row stride in LDS
@@ -121,18 +122,18 @@ __global__ __launch_bounds__(256) void mel_normalize_kernel(FrontendParams p) {
     float v = 0.f;
     if (f < n_frames) v = (fmaxf(p.logmel[(long)b * total + i], floor_v) + 4.0f) * 0.25f;
     if (p.mel_ref) p.mel_ref[((long)b * nm + m) * kFramesOut + f] = v;
-    if (p.mel_tm) p.mel_tm[((long)b * p.mel_rows + f + 1) * nm + m] = (bf16)v;  // row 0 = conv left pad
+    if (p.mel_tm) p.mel_tm[((long)b * p.mel_rows + f + 1) * nm + m] = (h16)v;  // row 0 = conv left pad
   }
 }
 
 // host-supplied mel [B][n_mels][3000] f32 -> encoder input layout (used by AX_WHISPER_EncodeMel)
-__global__ __launch_bounds__(256) void mel_to_tm_kernel(const float* __restrict__ mel_ref, bf16* __restrict__ mel_tm, int n_mels,
+__global__ __launch_bounds__(256) void mel_to_tm_kernel(const float* __restrict__ mel_ref, h16* __restrict__ mel_tm, int n_mels,
                                                         int mel_rows) {
   const int b = blockIdx.y;
   const long total = (long)kFramesOut * n_mels;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     int f = (int)(i / n_mels), m = (int)(i - (long)f * n_mels);
-    mel_tm[((long)b * mel_rows + f + 1) * n_mels + m] = (bf16)mel_ref[((long)b * n_mels + m) * kFramesOut + f];
+    mel_tm[((long)b * mel_rows + f + 1) * n_mels + m] = (h16)mel_ref[((long)b * n_mels + m) * kFramesOut + f];
   }
 }
 
@@ -150,8 +151,9 @@ void launch_frontend(const FrontendParams& p, hipStream_t s) {
   hipLaunchKernelGGL(mel_normalize_kernel, dim3(64, p.batch), dim3(256), 0, s, p);
 }
 
-void launch_mel_to_tm(const float* mel_ref, bf16* mel_tm, int batch, int n_mels, int mel_rows, hipStream_t s) {
+void launch_mel_to_tm(const float* mel_ref, h16* mel_tm, int batch, int n_mels, int mel_rows, hipStream_t s) {
   hipLaunchKernelGGL(mel_to_tm_kernel, dim3(64, batch), dim3(256), 0, s, mel_ref, mel_tm, n_mels, mel_rows);
 }
 
+}  // inline namespace AXW_NS
 }  // namespace axw

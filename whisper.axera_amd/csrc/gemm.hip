@@ -1,6 +1,6 @@
-// gemm.hip — bf16 MFMA GEMM with fused epilogues for the encoder (K3, K4, K6, K8 of SURVEY §8a).
+// gemm.hip — h16 MFMA GEMM with fused epilogues for the encoder (K3, K4, K6, K8 of SURVEY §8a).
 //
-// C[M,N] = A[M,K] * W[N,K]^T, A and W bf16 with K contiguous (nn.Linear weights are [out][in],
+// C[M,N] = A[M,K] * W[N,K]^T, A and W h16 with K contiguous (nn.Linear weights are [out][in],
 // so no transposition is ever needed), fp32 accumulation in v_mfma_f32_32x32x16_bf16.
 //
 // Replaces, inside the reference's opaque encoder blob (cpp/src/ax_model_runner/
@@ -21,6 +21,7 @@
 #include "common.hpp"
 
 namespace axw {
+inline namespace AXW_NS {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KB per operand tile
@@ -59,12 +60,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&accw
           const int n = nb + j * 32 + 8 * q + 4 * h;
           const int l = n / d, c = n - l * d;
           const int head = c >> 6, dd = c & 63;
-          bf16x4 pk;
+          h16x4 pk;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) pk[e] = (bf16)(acc[i][j][4 * q + e] + (p.bias ? p.bias[n + e] : 0.f));
+          for (int e = 0; e < 4; ++e) pk[e] = (h16)(acc[i][j][4 * q + e] + (p.bias ? p.bias[n + e] : 0.f));
           const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + head;
-          bf16* dst = reinterpret_cast<bf16*>(p.C) + slot * p.t_pad * 64 + (long)(m >> 6) * 4096 + (dd >> 3) * 512 + (m & 63) * 8 + (dd & 7);
-          *reinterpret_cast<bf16x4*>(dst) = pk;
+          h16* dst = reinterpret_cast<h16*>(p.C) + slot * p.t_pad * 64 + (long)(m >> 6) * 4096 + (dd >> 3) * 512 + (m & 63) * 8 + (dd & 7);
+          *reinterpret_cast<h16x4*>(dst) = pk;
         }
       }
     }
@@ -111,27 +112,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&accw
             for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]) + pos[e];
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n) = v;
           } else {
-            bf16x4 o;
+            h16x4 o;
             if constexpr (EPI == EPI_BIAS_GELU_BF16) {
               const f32x2_t g0 = gelu_erf_fast2(f32x2_t{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2_t{v[2], v[3]});
-              o[0] = (bf16)g0[0]; o[1] = (bf16)g0[1]; o[2] = (bf16)g1[0]; o[3] = (bf16)g1[1];
+              o[0] = (h16)g0[0]; o[1] = (h16)g0[1]; o[2] = (h16)g1[0]; o[3] = (h16)g1[1];
             } else {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+              for (int e = 0; e < 4; ++e) o[e] = (h16)v[e];
             }
-            bf16* dst;
-            if constexpr (EPI == EPI_QKV) {  // Q (n < d) or K (d <= n < 2d), both bf16 [m][d]
-              dst = n < d ? reinterpret_cast<bf16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * d + n
-                          : reinterpret_cast<bf16*>(p.C2) + (long)bz * p.c2_batch_stride + (long)m * d + (n - d);
+            h16* dst;
+            if constexpr (EPI == EPI_QKV) {  // Q (n < d) or K (d <= n < 2d), both h16 [m][d]
+              dst = n < d ? reinterpret_cast<h16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * d + n
+                          : reinterpret_cast<h16*>(p.C2) + (long)bz * p.c2_batch_stride + (long)m * d + (n - d);
             } else if constexpr (EPI == EPI_CROSS_KV) {  // V rows [n_layer*d, 2*n_layer*d): [l][slot][head][t_pad][64]
               const int nv = n - p.n_layer * d;
               const int l = nv / d, c = nv - l * d;
               const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + (c >> 6);
-              dst = reinterpret_cast<bf16*>(p.C2) + (slot * p.t_pad + m) * 64 + (c & 63);
+              dst = reinterpret_cast<h16*>(p.C2) + (slot * p.t_pad + m) * 64 + (c & 63);
             } else {
-              dst = reinterpret_cast<bf16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n;
+              dst = reinterpret_cast<h16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n;
             }
-            *reinterpret_cast<bf16x4*>(dst) = o;
+            *reinterpret_cast<h16x4*>(dst) = o;
           }
         }
       }
@@ -144,10 +145,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&accw
           const int row = 4 * t + rr, n = nb + row;
           const float bias = p.bias ? p.bias[n] : 0.f;
           const f32x4 v = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc);
-          bf16x4 o;
+          h16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] + bias);
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C3) + (long)bz * p.c3_batch_stride + (long)(n - 2 * d) * p.t_pad + m) = o;
+          for (int e = 0; e < 4; ++e) o[e] = (h16)(v[e] + bias);
+          *reinterpret_cast<h16x4*>(reinterpret_cast<h16*>(p.C3) + (long)bz * p.c3_batch_stride + (long)(n - 2 * d) * p.t_pad + m) = o;
         }
       }
     }
@@ -178,16 +179,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     bz = rest / mt;
   }
 
-  const bf16* A = p.A + (long)bz * p.a_batch_stride;
-  const bf16* W = p.W;
+  const h16* A = p.A + (long)bz * p.a_batch_stride;
+  const h16* W = p.W;
 
   // Staging: LDS-DMA (global_load_lds, 16 B per lane). One wave-instruction lands 1 KiB = 8 tile rows x 128 B
   // LINEARLY in LDS (hardware: wave-uniform base + lane*16), so the bank-conflict swizzle is applied on the SOURCE
   // side: LDS chunk position c of row `row` receives global chunk c ^ ((row>>1)&7), and fragment reads look for
   // global chunk g at position g ^ ((row>>1)&7) (the same involution; swz()). No VGPR staging, no ds_write.
   const int ld_row = tid >> 3, ld_c = tid & 7;   // lane l of wave w: row 8w + l/8 (+32 i), position l%8
-  const bf16* a_src[4];
-  const bf16* w_src[4];
+  const h16* a_src[4];
+  const h16* w_src[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = ld_row + 32 * i;
@@ -223,12 +224,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   auto compute = [&](int cur) {
     const char* Ab = As + cur * TILE_BYTES;
     const char* Wb = Ws + cur * TILE_BYTES;
-    bf16x8 af[2][2], wf[2][2];
+    h16x8 af[2][2], wf[2][2];
     auto frags = [&](int s, int set) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[set][i] = *reinterpret_cast<const bf16x8*>(Ab + swz(wm * 64 + i * 32 + r, 2 * s + h));
+      for (int i = 0; i < 2; ++i) af[set][i] = *reinterpret_cast<const h16x8*>(Ab + swz(wm * 64 + i * 32 + r, 2 * s + h));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) wf[set][j] = *reinterpret_cast<const bf16x8*>(Wb + swz(wn * 64 + j * 32 + r, 2 * s + h));
+      for (int j = 0; j < 2; ++j) wf[set][j] = *reinterpret_cast<const h16x8*>(Wb + swz(wn * 64 + j * 32 + r, 2 * s + h));
     };
     frags(0, 0);
 #pragma unroll
@@ -238,8 +239,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = SWAPPED ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0)
-                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], wf[s & 1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = SWAPPED ? AXW_MFMA_32x32x16(wf[s & 1][j], af[s & 1][i], acc[i][j])
+                              : AXW_MFMA_32x32x16(af[s & 1][i], wf[s & 1][j], acc[i][j]);
     }
   };
   // k-tile kt+1 streams into the other LDS buffer while k-tile kt is multiplied; one drain + barrier per k-tile.
@@ -287,12 +288,12 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
     m0 = (rest % mt) * BM2;
     bz = rest / mt;
   }
-  const bf16* A = p.A + (long)bz * p.a_batch_stride;
-  const bf16* W = p.W;
+  const h16* A = p.A + (long)bz * p.a_batch_stride;
+  const h16* W = p.W;
 
   const int ld_row = tid >> 3, ld_c = tid & 7;  // lane l of wave w: tile row 8w + l/8 (+64 i), chunk position l%8
-  const bf16* a_src[4];
-  const bf16* w_src[2];
+  const h16* a_src[4];
+  const h16* w_src[2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = ld_row + 64 * i;
@@ -324,12 +325,12 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
   auto compute = [&](int buf) {
     const char* Ab = smem + buf * STAGE2_BYTES;
     const char* Wb = Ab + A2_BYTES;
-    bf16x8 af[2][2], wf[2][2];
+    h16x8 af[2][2], wf[2][2];
     auto frags = [&](int s, int set) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[set][i] = *reinterpret_cast<const bf16x8*>(Ab + swz(wm * 64 + i * 32 + r, 2 * s + h));
+      for (int i = 0; i < 2; ++i) af[set][i] = *reinterpret_cast<const h16x8*>(Ab + swz(wm * 64 + i * 32 + r, 2 * s + h));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) wf[set][j] = *reinterpret_cast<const bf16x8*>(Wb + swz(wn * 64 + j * 32 + r, 2 * s + h));
+      for (int j = 0; j < 2; ++j) wf[set][j] = *reinterpret_cast<const h16x8*>(Wb + swz(wn * 64 + j * 32 + r, 2 * s + h));
     };
     frags(0, 0);
 #pragma unroll
@@ -339,8 +340,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = SWAPPED ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0)
-                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], wf[s & 1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = SWAPPED ? AXW_MFMA_32x32x16(wf[s & 1][j], af[s & 1][i], acc[i][j])
+                              : AXW_MFMA_32x32x16(af[s & 1][i], wf[s & 1][j], acc[i][j]);
     }
   };
 
@@ -406,12 +407,12 @@ __global__ __launch_bounds__(512) void gemm256sq_bf16_kernel(GemmParams p) {
     m0 = (rest % mt) * BM3;
     bz = rest / mt;
   }
-  const bf16* A = p.A + (long)bz * p.a_batch_stride;
-  const bf16* W = p.W;
+  const h16* A = p.A + (long)bz * p.a_batch_stride;
+  const h16* W = p.W;
 
   const int ld_row = tid >> 3, ld_c = tid & 7;  // lane l of wave w: tile row 8w + l/8 (+64 i), chunk position l%8
-  const bf16* a_src[4];
-  const bf16* w_src[4];
+  const h16* a_src[4];
+  const h16* w_src[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = ld_row + 64 * i;
@@ -439,12 +440,12 @@ __global__ __launch_bounds__(512) void gemm256sq_bf16_kernel(GemmParams p) {
   auto compute = [&](int buf) {
     const char* Ab = smem + buf * STAGE3_BYTES;
     const char* Wb = Ab + A3_BYTES;
-    bf16x8 af[2][4], wf[2][2];
+    h16x8 af[2][4], wf[2][2];
     auto frags = [&](int s, int set) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) wf[set][j] = *reinterpret_cast<const bf16x8*>(Wb + swz(wn * 64 + j * 32 + r, 2 * s + h));
+      for (int j = 0; j < 2; ++j) wf[set][j] = *reinterpret_cast<const h16x8*>(Wb + swz(wn * 64 + j * 32 + r, 2 * s + h));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[set][i] = *reinterpret_cast<const bf16x8*>(Ab + swz(wm * 128 + i * 32 + r, 2 * s + h));
+      for (int i = 0; i < 4; ++i) af[set][i] = *reinterpret_cast<const h16x8*>(Ab + swz(wm * 128 + i * 32 + r, 2 * s + h));
     };
     frags(0, 0);
 #pragma unroll
@@ -454,8 +455,8 @@ __global__ __launch_bounds__(512) void gemm256sq_bf16_kernel(GemmParams p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = SWAPPED ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0)
-                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], wf[s & 1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = SWAPPED ? AXW_MFMA_32x32x16(wf[s & 1][j], af[s & 1][i], acc[i][j])
+                              : AXW_MFMA_32x32x16(af[s & 1][i], wf[s & 1][j], acc[i][j]);
     }
   };
 
@@ -527,9 +528,9 @@ void launch_gemm(const GemmParams& p, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------- LayerNorm
-// fp32 rows -> bf16 rows, eps 1e-5, biased variance (nn.LayerNorm [upstream]); one wave per row.
+// fp32 rows -> h16 rows, eps 1e-5, biased variance (nn.LayerNorm [upstream]); one wave per row.
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                             const float* __restrict__ b, bf16* __restrict__ y, long rows, int d) {
+                                                             const float* __restrict__ b, h16* __restrict__ y, long rows, int d) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -558,18 +559,19 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
     int c = lane + 64 * i;
     if (c < nv) {
       float4 gg = reinterpret_cast<const float4*>(g)[c], bb = reinterpret_cast<const float4*>(b)[c];
-      bf16x4 o;
-      o[0] = (bf16)((v[i].x - mean) * rstd * gg.x + bb.x);
-      o[1] = (bf16)((v[i].y - mean) * rstd * gg.y + bb.y);
-      o[2] = (bf16)((v[i].z - mean) * rstd * gg.z + bb.z);
-      o[3] = (bf16)((v[i].w - mean) * rstd * gg.w + bb.w);
-      reinterpret_cast<bf16x4*>(y + row * d)[c] = o;
+      h16x4 o;
+      o[0] = (h16)((v[i].x - mean) * rstd * gg.x + bb.x);
+      o[1] = (h16)((v[i].y - mean) * rstd * gg.y + bb.y);
+      o[2] = (h16)((v[i].z - mean) * rstd * gg.z + bb.z);
+      o[3] = (h16)((v[i].w - mean) * rstd * gg.w + bb.w);
+      reinterpret_cast<h16x4*>(y + row * d)[c] = o;
     }
   }
 }
 
-void launch_layernorm_bf16(const float* x, const float* g, const float* b, bf16* y, long rows, int d, hipStream_t s) {
+void launch_layernorm_bf16(const float* x, const float* g, const float* b, h16* y, long rows, int d, hipStream_t s) {
   hipLaunchKernelGGL(layernorm_bf16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, g, b, y, rows, d);
 }
 
+}  // inline namespace AXW_NS
 }  // namespace axw

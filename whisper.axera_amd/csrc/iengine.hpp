@@ -1,0 +1,56 @@
+// iengine.hpp — the dtype-independent face of the engine, as the C ABI (api.cpp) sees it.
+//
+// engine.{hpp,cpp} and every kernel file are compiled twice (bfloat16 and IEEE-half storage, see common.hpp); each
+// build defines axw::<ns>::Engine : IEngine and one factory below. api.cpp picks the factory from the dtype of the
+// model's weights file, so one libax_whisper.so serves "Whisper-small bf16" and "Whisper-turbo fp16" alike.
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace axw {
+
+struct ModelConfig {
+  int n_mels = 0, n_audio_ctx = 1500, n_audio_state = 0, n_audio_head = 0, n_audio_layer = 0;
+  int n_vocab = 0, n_text_ctx = 448, n_text_state = 0, n_text_head = 0, n_text_layer = 0;
+  int sot = 0, eot = 0, transcribe = 0, translate = 0, no_timestamps = 0;
+  std::vector<int> lang_tokens;
+  std::vector<std::string> lang_codes;
+  std::map<std::string, long> ints;  // every integer-valued key of the config file
+};
+
+class IEngine {
+ public:
+  virtual ~IEngine() {}
+  // full path, host PCM or device PCM; ids [batch][n_text_ctx], n_ids [batch]
+  virtual void run_tokens(const float* const* pcm, const float* d_pcm, int d_stride, const int* n_samples, int batch, int max_new,
+                          int32_t* ids, int* n_ids) = 0;
+  virtual std::string detokenize(const int32_t* ids, int n) const = 0;
+  // detokenize + the reference's zh post-pass (Traditional -> Simplified, Whisper.cpp:231-236) when its OpenCC data files were found
+  virtual std::string transcript(const int32_t* ids, int n) const = 0;
+  // stage-level
+  virtual void compute_mel(const float* pcm, int n_samples, float* mel_out) = 0;
+  virtual void encode_mel(const float* mel, int batch) = 0;
+  virtual void get_cross_kv(int slot, float* k_out, float* v_out) = 0;
+  virtual void decode_forced(int batch, const int32_t* forced, int n_forced, float* logits, int32_t* argmax_ids) = 0;
+  // max_new_clip: optional host [batch] per-clip id budgets (<= 0: none), each capped by max_new
+  virtual void decode_greedy(int batch, int max_new, const int* max_new_clip, int32_t* ids, int* n_ids) = 0;
+  virtual float bench(const std::string& what, int batch, int arg, int iters) = 0;
+  virtual void set_stream(void* hip_stream) = 0;
+  virtual const ModelConfig& config() const = 0;
+  virtual const char* dtype_name() const = 0;  // "bf16" | "fp16"
+
+  std::mutex& mutex() { return mu_; }
+  float timings[5] = {0, 0, 0, 0, 0};
+
+ protected:
+  std::mutex mu_;
+};
+
+IEngine* make_engine_bf16(const std::string& model_type, const std::string& model_path, const std::string& language, int device, int max_batch);
+IEngine* make_engine_f16(const std::string& model_type, const std::string& model_path, const std::string& language, int device, int max_batch);
+
+}  // namespace axw
