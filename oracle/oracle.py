@@ -55,6 +55,8 @@ def lib():
         L.orc_log_mel.restype = C.c_int
         L.orc_log_mel.argtypes = [fp, C.c_int, C.c_int, fp, fp]
         L.orc_mel_filterbank.argtypes = [C.c_int, fp]
+        L.orc_log_mel_openai.restype = None
+        L.orc_log_mel_openai.argtypes = [fp, C.c_int, C.c_int, fp, fp]
         L.orc_sinusoids.argtypes = [C.c_int, C.c_int, fp]
         L.orc_encoder.argtypes = [C.POINTER(OrcModel), C.POINTER(OrcPolicy), fp, fp, fp]
         L.orc_decoder_step.argtypes = [C.POINTER(OrcModel), C.POINTER(OrcPolicy), C.c_int, C.c_int,
@@ -104,6 +106,15 @@ def log_mel(pcm: np.ndarray, n_mels: int = 80, use_ref: bool = False):
     fn = L.ref_log_mel if use_ref else L.orc_log_mel
     n = fn(_p(pcm), len(pcm), n_mels, _p(out), C.byref(mmax))
     return out, n, mmax.value
+
+
+def log_mel_openai(pcm: np.ndarray, n_mels: int = 80):
+    """feature_mode "openai" (generate_data.py:162-176 lineage) -> (mel [n_mels, 3000] f32, mmax)."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+    out = np.empty((n_mels, 3000), dtype=np.float32)
+    mmax = C.c_float()
+    lib().orc_log_mel_openai(_p(pcm), len(pcm), n_mels, _p(out), C.byref(mmax))
+    return out, mmax.value
 
 
 def mel_filterbank(n_mels: int, use_ref: bool = False) -> np.ndarray:

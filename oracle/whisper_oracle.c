@@ -171,6 +171,90 @@ int orc_log_mel(const float *pcm, int n_samples, int n_mels, float *out, float *
   return n_frames;
 }
 
+/* librosa.filters.mel(sr=16000, n_fft=400, n_mels) as upstream's assets/mel_filters.npz was generated (comment in
+ * openai-whisper 20240930 whisper/audio.py mel_filters()): Slaney scale + Slaney norm like librosa.h:102-144, but the
+ * ramps are evaluated in float64, narrowed to float32, then scaled by the float64 norm and narrowed again. */
+static void mel_filterbank_librosa_f64(int n_mels, float *out) {
+  const int n_f = ORC_N_BINS;
+  const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+  const double max_mel = min_log_mel + log(8000.0 / min_log_hz) / logstep;
+  double *mel_f = (double *)malloc(sizeof(double) * (size_t)(n_mels + 2));
+  for (int i = 0; i < n_mels + 2; ++i) {
+    const double mel = max_mel * (double)i / (double)(n_mels + 1);
+    mel_f[i] = mel >= min_log_mel ? min_log_hz * exp(logstep * (mel - min_log_mel)) : f_sp * mel;
+  }
+  for (int m = 0; m < n_mels; ++m) {
+    const double fd0 = mel_f[m + 1] - mel_f[m], fd1 = mel_f[m + 2] - mel_f[m + 1];
+    const double enorm = 2.0 / (mel_f[m + 2] - mel_f[m]);
+    for (int k = 0; k < n_f; ++k) {
+      const double freq = (double)k * 16000.0 / (2.0 * (n_f - 1));
+      const double lower = -(mel_f[m] - freq) / fd0, upper = (mel_f[m + 2] - freq) / fd1;
+      const double w = lower < upper ? lower : upper;
+      const float w32 = (float)(w > 0.0 ? w : 0.0);
+      out[(size_t)m * n_f + k] = (float)((double)w32 * enorm);
+    }
+  }
+  free(mel_f);
+}
+
+/* The fp32 ONNX / PyTorch lineage's front-end (SURVEY A.1 column 3; call sites model_convert/generate_data.py:162-176
+ * and export_onnx.py:557; arithmetic = upstream openai-whisper 20240930 whisper/audio.py pad_or_trim +
+ * log_mel_spectrogram, third-party and absent from the reference tree): audio zero-padded / trimmed to 30 s BEFORE
+ * the STFT, torch.stft(400, 160, periodic Hann, center, reflect), the LAST frame dropped, |X|^2, mel_filters.npz,
+ * log10(clamp 1e-10), max over the 3000 kept frames, max(., gmax - 8), (. + 4) / 4. No zero fill: the padded region
+ * holds the clamp floor. out: [n_mels][3000]. Pinned by tests/test_oracle_frontend.py against torch.stft. */
+void orc_log_mel_openai(const float *pcm, int n_samples, int n_mels, float *out, float *mmax_out) {
+  const int n_fft = ORC_N_FFT, hop = ORC_HOP, n_f = ORC_N_BINS, pad = n_fft / 2, N = 480000, n_frames = ORC_N_FRAMES_OUT;
+  float *xp = (float *)calloc((size_t)N + 2 * pad, sizeof(float));
+  memcpy(xp + pad, pcm, sizeof(float) * (size_t)(n_samples < N ? n_samples : N));
+  for (int i = 0; i < pad; ++i) xp[i] = xp[2 * pad - i];                       /* reflect: x[pad - i] of the padded clip */
+  for (int i = 0; i < pad; ++i) xp[pad + N + i] = xp[pad + N - 2 - i];
+  float window[ORC_N_FFT];
+  for (int n = 0; n < n_fft; ++n) window[n] = (float)(0.5 * (1.0 - cos(2.0 * M_PI * n / n_fft)));  /* torch.hann_window */
+  double *ctab = (double *)malloc(sizeof(double) * n_fft * 2);
+  for (int i = 0; i < n_fft; ++i) { ctab[2 * i] = cos(2.0 * M_PI * i / n_fft); ctab[2 * i + 1] = sin(2.0 * M_PI * i / n_fft); }
+  float *basis = (float *)malloc(sizeof(float) * (size_t)n_mels * n_f);
+  mel_filterbank_librosa_f64(n_mels, basis);
+  float *mel = (float *)malloc(sizeof(float) * (size_t)n_mels * n_frames);
+#pragma omp parallel
+  {
+    float frame[ORC_N_FFT];
+    float power[ORC_N_BINS];
+#pragma omp for schedule(static)
+    for (int f = 0; f < n_frames; ++f) {  /* frame 3000 of torch.stft's 3001 is dropped (stft[..., :-1]) */
+      const float *seg = xp + (size_t)f * hop;
+      for (int n = 0; n < n_fft; ++n) frame[n] = window[n] * seg[n];
+      for (int k = 0; k < n_f; ++k) {
+        double re = 0.0, im = 0.0;
+        int idx = 0;
+        for (int n = 0; n < n_fft; ++n) {
+          re += (double)frame[n] * ctab[2 * idx];
+          im -= (double)frame[n] * ctab[2 * idx + 1];
+          idx += k;
+          if (idx >= n_fft) idx -= n_fft;
+        }
+        power[k] = (float)(re * re + im * im);
+      }
+      for (int m = 0; m < n_mels; ++m) {
+        double acc = 0.0;
+        const float *b = basis + (size_t)m * n_f;
+        for (int k = 0; k < n_f; ++k) acc += (double)b[k] * (double)power[k];
+        mel[(size_t)m * n_frames + f] = (float)acc;
+      }
+    }
+  }
+  float mmax = -3.402823466e38f;
+  for (size_t i = 0; i < (size_t)n_mels * n_frames; ++i) {
+    const float v = log10f(mel[i] > 1e-10f ? mel[i] : 1e-10f);
+    mel[i] = v;
+    if (v > mmax) mmax = v;
+  }
+  const float floor_v = mmax - 8.0f;
+  for (size_t i = 0; i < (size_t)n_mels * n_frames; ++i) out[i] = ((mel[i] > floor_v ? mel[i] : floor_v) + 4.0f) / 4.0f;
+  if (mmax_out) *mmax_out = mmax;
+  free(mel); free(basis); free(ctab); free(xp);
+}
+
 /* upstream whisper/model.py sinusoids() [openai-whisper 20240930]. */
 void orc_sinusoids(int length, int channels, float *out) {
   int half = channels / 2;

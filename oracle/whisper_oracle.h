@@ -79,6 +79,10 @@ void orc_mel_filterbank(int n_mels, float *out);
  * writes the global max (log10 power) to *mmax if non-NULL. */
 int orc_log_mel(const float *pcm, int n_samples, int n_mels, float *out, float *mmax);
 
+/* feature_mode "openai" (SURVEY A.1 column 3; model_convert/generate_data.py:162-176): pad/trim to 30 s, drop the
+ * last STFT frame, clamp floor instead of zeros in the padded region. out: [n_mels, 3000]. */
+void orc_log_mel_openai(const float *pcm, int n_samples, int n_mels, float *out, float *mmax);
+
 /* upstream sinusoids(length, channels) — encoder positional embedding. */
 void orc_sinusoids(int length, int channels, float *out);
 

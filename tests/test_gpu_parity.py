@@ -235,3 +235,52 @@ def test_detokenizer_bytes(engine):
     ids = [0, 1, 255, 1000, 30000, 50255, 50256, 50257, 51864]  # the last two are specials: skipped
     want = b"".join(base64.b64decode(lines[i].split()[0]) for i in ids if i < 50257)
     assert engine.detokenize(ids) == want
+
+
+def test_feature_mode_openai_front_end(built_lib, micro_case, oracle_mod, monkeypatch, tmp_path):
+    """SURVEY A.1 column 3 behind a switch (config key "feature_mode" / env AX_WHISPER_FEATURE_MODE): the front-end of the
+    fp32 ONNX lineage (model_convert/generate_data.py:162-176) — 30 s zero padding before the STFT, last frame
+    dropped, clamp floor instead of zeros behind the clip. Default stays the C++ runtime's pipeline."""
+    import json
+    import shutil
+
+    import modelgen
+
+    e = built_lib.Whisper("micro", micro_case.root, "zh", device=0)
+    assert e.L.AX_WHISPER_GetConfigInt(e.h, b"feature_mode_openai") == 0
+    e.close()
+    monkeypatch.setenv("AX_WHISPER_FEATURE_MODE", "openai")
+    e = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=3)
+    try:
+        assert e.L.AX_WHISPER_GetConfigInt(e.h, b"feature_mode_openai") == 1
+        clips = [load_demo_pcm(), modelgen.synth_clip(1, 480000), modelgen.synth_clip(2, 500321), modelgen.synth_clip(3, 401)]
+        for pcm in clips:
+            want, _ = oracle_mod.log_mel_openai(pcm, 80)
+            got = e.compute_mel(pcm)
+            err = float(np.abs(got - want).max())
+            print("openai-mode mel err", len(pcm), err)
+            assert err < 2e-4
+        # end to end: ids follow the openai-mode mel (oracle fed with the same mel)
+        pcm = clips[0]
+        mel, _ = oracle_mod.log_mel_openai(pcm, 80)
+        ck, cv = micro_case.oracle_bf16.encoder(mel)
+        ids, lg = micro_case.oracle_bf16.greedy(ck, cv, "zh", max_new=10, want_logits=True)
+        assert_ids_equal_or_tie(e, mel, e.run_tokens(pcm, max_new=10), ids, lg, "openai feature mode")
+        assert e.run_tokens_batch(clips[:3], max_new=6)[0] == e.run_tokens(pcm, max_new=6)
+    finally:
+        e.close()
+    monkeypatch.delenv("AX_WHISPER_FEATURE_MODE")
+    # the same through the config file; and a wrong value is an Init failure, not a silent default
+    root = tmp_path / "m"
+    shutil.copytree(micro_case.root, root)
+    cfgp = root / "micro" / "micro_config.json"
+    cfg = json.load(open(cfgp))
+    cfg["feature_mode"] = "openai"
+    json.dump(cfg, open(cfgp, "w"))
+    e = built_lib.Whisper("micro", str(root), "zh", device=0)
+    assert e.L.AX_WHISPER_GetConfigInt(e.h, b"feature_mode_openai") == 1
+    e.close()
+    cfg["feature_mode"] = "kaldi"
+    json.dump(cfg, open(cfgp, "w"))
+    with pytest.raises(RuntimeError, match="feature_mode"):
+        built_lib.Whisper("micro", str(root), "zh", device=0)

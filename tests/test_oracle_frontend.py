@@ -64,3 +64,36 @@ def test_against_live_reference_build(oracle_mod):
         b, nfb, mb = oracle_mod.log_mel(x, 80, use_ref=True)
         assert nfa == nfb and abs(ma - mb) < 1e-5
         assert np.abs(a - b).max() < TOL
+
+
+def test_openai_feature_mode_matches_torch_stft(oracle_mod, demo_pcm):
+    """feature_mode "openai" (SURVEY A.1 column 3, the fp32 ONNX lineage's front-end, model_convert/generate_data.py:
+    162-176): the oracle's restatement against an independent evaluation of the same published recipe with torch.stft
+    (openai-whisper's own module is not importable here): pad to 30 s, STFT(400, 160, Hann, center/reflect), drop the
+    last frame, |X|^2, Slaney mel, log10/clamp/scale."""
+    import modelgen
+    import torch
+
+    for pcm, n_mels in ((demo_pcm, 80), (modelgen.synth_clip(2, 480000), 128), (modelgen.synth_clip(3, 500123), 80)):
+        got, mmax = oracle_mod.log_mel_openai(pcm, n_mels)
+        x = torch.zeros(480000, dtype=torch.float32)
+        n = min(len(pcm), 480000)
+        x[:n] = torch.from_numpy(pcm[:n])
+        st = torch.stft(x, 400, 160, window=torch.hann_window(400), return_complex=True)
+        mag = st[..., :-1].abs() ** 2
+        assert mag.shape == (201, 3000)
+        # Slaney filterbank: the C++ front-end's (float32 arithmetic) agrees with the float64 one to ~1e-7 relative
+        fb = torch.from_numpy(oracle_mod.mel_filterbank(n_mels))
+        mel = fb @ mag
+        lg = torch.clamp(mel, min=1e-10).log10()
+        lg = torch.maximum(lg, lg.max() - 8.0)
+        want = ((lg + 4.0) / 4.0).numpy()
+        assert abs(float(lg.max()) - mmax) < 1e-4
+        err = np.abs(got - want).max()
+        assert err < 2e-4, err
+    # versus the C++ pipeline on a short clip: real frames agree except next to the clip's end (reflection of the real
+    # end vs zeros) — and the padded region is the clamp floor, not 0
+    a, nfr, _ = oracle_mod.log_mel(demo_pcm, 80)
+    b, mmax = oracle_mod.log_mel_openai(demo_pcm, 80)
+    assert np.abs(a[:, : nfr - 3] - b[:, : nfr - 3]).max() < 2e-4
+    assert np.all(a[:, nfr:] == 0.0) and np.allclose(b[:, nfr + 2:], (mmax - 8.0 + 4.0) / 4.0, atol=1e-6)

@@ -159,6 +159,8 @@ struct FrontendParams {
   h16* mel_tm;            // device [batch][mel_rows][n_mels] h16 time-major, row 0 = left pad, or nullptr
   int mel_rows;
   int max_frames;          // frames computed per clip (<= 3001)
+  int openai;              // 1: the fp32 ONNX lineage's front-end (SURVEY A.1 column 3, generate_data.py:162-176): clip
+                           // zero-padded / trimmed to 30 s before the STFT, last frame dropped, no zero fill
 };
 void launch_frontend(const FrontendParams& p, hipStream_t s);
 void launch_mel_to_tm(const float* mel_ref, h16* mel_tm, int batch, int n_mels, int mel_rows, hipStream_t s);

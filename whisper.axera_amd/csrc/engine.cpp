@@ -160,6 +160,16 @@ void Engine::load_config(const std::string& dir, const std::string& type, const 
   for (auto& kv : j.obj)
     if (kv.second.kind == JsonValue::Number) cfg_.ints[kv.first] = kv.second.as_int();
   auto geti = [&](const char* k) { return (int)j.at(k).as_int(); };
+  // feature_mode: "axera_cpp" (default) = the C++ runtime's pipeline, the drop-in target (Whisper.cpp:
+  // 151-184); "openai" = the front-end of the fp32 ONNX / PyTorch lineage (generate_data.py:162-176), for comparing
+  // against that lineage. From the config file (key "feature_mode"), overridden by env AX_WHISPER_FEATURE_MODE.
+  {
+    std::string fm = j.has("feature_mode") && j.at("feature_mode").kind == JsonValue::String ? j.at("feature_mode").as_str() : "axera_cpp";
+    if (const char* e = getenv("AX_WHISPER_FEATURE_MODE")) fm = e;
+    if (fm != "axera_cpp" && fm != "openai") throw std::runtime_error("feature_mode must be axera_cpp or openai, not '" + fm + "'");
+    feature_openai_ = fm == "openai";
+    cfg_.ints["feature_mode_openai"] = feature_openai_ ? 1 : 0;
+  }
   cfg_.n_mels = geti("n_mels");
   cfg_.n_vocab = geti("n_vocab");
   cfg_.n_text_state = geti("n_text_state");
@@ -196,6 +206,29 @@ void Engine::load_config(const std::string& dir, const std::string& type, const 
 }
 
 // Slaney mel filterbank, arithmetic as librosa.h:102-144 (fp32), stored transposed [201][n_mels].
+// librosa.filters.mel as upstream's mel_filters.npz was generated (feature_mode openai): ramps in float64, narrowed,
+// scaled by the float64 Slaney norm, narrowed again; stored transposed [201][n_mels].
+static std::vector<float> make_mel_basis_t_librosa(int n_mels) {
+  const int n_f = kBins;
+  const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+  const double max_mel = min_log_mel + std::log(8000.0 / min_log_hz) / logstep;
+  std::vector<double> mel_f(n_mels + 2);
+  for (int i = 0; i < n_mels + 2; ++i) {
+    const double mel = max_mel * (double)i / (double)(n_mels + 1);
+    mel_f[i] = mel >= min_log_mel ? min_log_hz * std::exp(logstep * (mel - min_log_mel)) : f_sp * mel;
+  }
+  std::vector<float> out((size_t)n_f * n_mels);
+  for (int m = 0; m < n_mels; ++m) {
+    const double fd0 = mel_f[m + 1] - mel_f[m], fd1 = mel_f[m + 2] - mel_f[m + 1], enorm = 2.0 / (mel_f[m + 2] - mel_f[m]);
+    for (int k = 0; k < n_f; ++k) {
+      const double freq = (double)k * 16000.0 / kNFFT;
+      const double w = std::min(-(mel_f[m] - freq) / fd0, (mel_f[m + 2] - freq) / fd1);
+      out[(size_t)k * n_mels + m] = (float)((double)(float)std::max(w, 0.0) * enorm);
+    }
+  }
+  return out;
+}
+
 static std::vector<float> make_mel_basis_t(int n_mels) {
   const int sr = 16000, n_fft = kNFFT, n_f = kBins, fmin = 0, fmax = 8000;
   const float f_min = 0.f, f_sp = 200.f / 3.f, min_log_hz = 1000.f;
@@ -417,9 +450,10 @@ void Engine::load_weights(const std::string& path) {
   for (int i = 0; i < kNFFT; ++i) {
     tw[2 * i] = (float)cos(2.0 * M_PI * i / kNFFT);
     tw[2 * i + 1] = (float)sin(2.0 * M_PI * i / kNFFT);
-    win[i] = 0.5f * (1.f - cosf((float)i * 2.f * (float)M_PI / (float)kNFFT));
+    win[i] = feature_openai_ ? (float)(0.5 * (1.0 - cos(2.0 * M_PI * i / kNFFT)))  // torch.hann_window
+                             : 0.5f * (1.f - cosf((float)i * 2.f * (float)M_PI / (float)kNFFT));  // librosa.h:81
   }
-  std::vector<float> mb = make_mel_basis_t(nm);
+  std::vector<float> mb = feature_openai_ ? make_mel_basis_t_librosa(nm) : make_mel_basis_t(nm);
   twiddle_ = new_f32(tw.size());
   window_ = new_f32(win.size());
   mel_basis_t_ = new_f32(mb.size());
@@ -527,6 +561,7 @@ void Engine::run_frontend(const float* d_pcm, int stride, const int* n_samples, 
     ns[b] = std::min(n_samples[b], stride);
     max_frames = std::max(max_frames, 1 + ns[b] / kHop);
   }
+  if (feature_openai_) max_frames = kFramesOut;
   HIP_CHECK(hipMemcpyAsync(d_nsamp_, ns.data(), (size_t)batch * 4, hipMemcpyHostToDevice, stream()));
   HIP_CHECK(hipStreamSynchronize(stream()));  // ns is a stack vector
   FrontendParams p{};
@@ -534,7 +569,7 @@ void Engine::run_frontend(const float* d_pcm, int stride, const int* n_samples, 
   p.twiddle = twiddle_; p.window = window_; p.mel_basis = mel_basis_t_;
   p.logmel = d_logmel_; p.gmax = d_gmax_;
   p.mel_ref = want_ref_layout ? d_mel_ref_ : nullptr;
-  p.mel_tm = d_mel_tm_; p.mel_rows = mel_rows_; p.max_frames = max_frames;
+  p.mel_tm = d_mel_tm_; p.mel_rows = mel_rows_; p.max_frames = max_frames; p.openai = feature_openai_ ? 1 : 0;
   launch_frontend(p, stream());
 }
 

@@ -79,6 +79,7 @@ class Engine final : public IEngine {
   std::vector<std::string> tokens_;
   std::unique_ptr<T2SConverter> t2s_;  // zh only
   std::string effective_lang_;
+  bool feature_openai_ = false;  // feature_mode "openai" (engine.cpp load_config)
   int device_ = 0;
   bool device_set_ = false;
   void* load_stage_ = nullptr;  // staging buffer of load_weights

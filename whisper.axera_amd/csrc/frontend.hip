@@ -35,8 +35,11 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(FrontendParams p, const f
   __shared__ float red[4];
 
   const int b = blockIdx.y;
-  const int n = p.n_samples[b];
-  const int n_frames = 1 + n / kHop;  // 1 + (n + 400 - 400) / 160   (librosa.h:87)
+  const int n_real = p.n_samples[b];
+  // openai mode: the clip is (virtually) zero-padded or trimmed to 480000 samples before the STFT and frame 3000 of
+  // its 3001 frames is dropped (upstream pad_or_trim + stft[..., :-1]; call site generate_data.py:162-176)
+  const int n = p.openai ? kFramesOut * kHop : n_real;
+  const int n_frames = p.openai ? kFramesOut : 1 + n / kHop;  // 1 + (n + 400 - 400) / 160   (librosa.h:87)
   const int f0 = blockIdx.x * FR;
   if (f0 >= n_frames) return;  // uniform per workgroup
   const float* x = p.pcm + (long)b * p.stride;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(FrontendParams p, const f
       if (j < 0) j = -j;                              // librosa.h:51  x[left - i]
       if (j >= n) j = 2 * n - 2 - j;                  // librosa.h:54  x[size - 2 - i + left]
       j = min(max(j, 0), n - 1);                      // clips shorter than the pad: stay in bounds
-      v = x[j] * p.window[k];                         // librosa.h:92
+      v = (j < n_real ? x[j] : 0.f) * p.window[k];    // librosa.h:92 (openai mode: zeros behind the clip's end)
     }
     xw[i] = v;
   }
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(FrontendParams p, const f
 __global__ __launch_bounds__(256) void mel_normalize_kernel(FrontendParams p) {
   const int b = blockIdx.y;
   const int nm = p.n_mels;
-  const int n_frames = min(1 + p.n_samples[b] / kHop, kFramesOut);
+  const int n_frames = p.openai ? kFramesOut : min(1 + p.n_samples[b] / kHop, kFramesOut);
   const float floor_v = ordered_to_float(p.gmax[b]) - 8.0f;
   const long total = (long)kFramesOut * nm;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
