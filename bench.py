@@ -162,8 +162,9 @@ def roofline_for(eng, dims, model, B, dec_steps, decode_ms_per_step, dtype_bytes
         # 5+ clips: the step is dominated by decode_attention_kernel (cross + self attention, one workgroup per
         # (clip, head)), which streams every clip's K/V once per step: algorithmic bytes = B * (55.3 MB cross +
         # (t+1) * 36.9 KB self) at t = 224 (the mid-utterance step this leg replays), over 2 launches per layer.
-        n_attn = 2 * dims["dec_layers"]
-        roof = {"kernel": "decode_attention_kernel (self + cross attention of one decoder step, %d launches)" % n_attn,
+        branches = max(1, eng.L.AX_WHISPER_GetConfigInt(eng.h, b"decode_branches"))  # clip blocks run as parallel graph branches
+        n_attn = 2 * dims["dec_layers"] * branches
+        roof = {"kernel": "decode_attention_kernel (self + cross attention of one decoder step, %d launches in %d parallel graph branches)" % (n_attn, branches),
                 "bound": "hbm", "achieved": round(attn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(attn_gbs / HBM_PEAK_GBS, 4), "traffic": traffic("decode_attention_kernel"),
                 "avg_launch_us": round(ms_attn * 1e3 / n_attn, 3), "bytes_per_launch": int((c_bytes + s_bytes) / n_attn),

@@ -50,7 +50,7 @@ def main():
         res[fam] = {"launches_sampled": nf[fam], "fetch_size_kib_raw_per_launch": round(f_kib, 2),
                     "write_size_kib_per_launch": round(w_kib, 2),
                     "hbm_bytes_per_launch": int((2 * f_kib + w_kib) * 1024)}
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "r01_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), sys.argv[3] if len(sys.argv) > 3 else "r02_pmc_traffic.json")
     allres = json.load(open(path)) if os.path.exists(path) else {}
     allres[key] = res
     json.dump(allres, open(path, "w"), indent=1, sort_keys=True)

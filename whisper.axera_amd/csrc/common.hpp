@@ -115,6 +115,8 @@ enum GemmEpilogue : int {
   EPI_RESID_F32 = 3,       // C f32 += acc + bias                        (out-proj / FFN2 residual)
   EPI_QKV = 4,             // n<d: Q h16 [m][d]; d<=n<2d: K h16 [m][d]; else V^T h16 [h][64][Tp]
   EPI_CROSS_KV = 5,        // decode layouts: K blocked [l][b][h][blk][8][64][8], V [l][b][h][Tp][64]
+  EPI_PARTIAL_F32 = 6,     // split-K: part[split][batch*M + m][n] f32 = acc over this split's k range (no bias); the
+                           // LayerNorm that follows folds the partials (+ bias) into the residual stream, in fixed order
 };
 
 struct GemmParams {
@@ -133,11 +135,17 @@ struct GemmParams {
   int n_begin;                       // set by launch_gemm: first output column of this launch
   int n_tiles;                       // set by launch_gemm: 128-column tiles of this launch
   int epilogue;
+  int qkv_part;                      // EPI_QKV: 0 both launches, 1 only Q,K columns, 2 only V columns (run side by side on two streams)
+  int ksplit;                        // EPI_PARTIAL_F32: K slices (grid.y), K / 64 divisible by it
+  float* part; long part_stride;     // EPI_PARTIAL_F32: partial sums, one [batch*M][N] slab per slice
 };
 void launch_gemm(const GemmParams& p, hipStream_t s);
 
 // fp32 [rows][d] -> h16 [rows][d] LayerNorm (eps 1e-5)
-void launch_layernorm_bf16(const float* x, const float* g, const float* b, h16* y, long rows, int d, hipStream_t s);
+// n_part > 0: first x[row] += bias + part[0][row] + ... + part[n_part-1][row] (split-K partials of the GEMM before, slab
+// stride part_stride), written back to x
+void launch_layernorm_bf16(float* x, const float* g, const float* b, h16* y, long rows, int d, hipStream_t s,
+                           const float* part = nullptr, int n_part = 0, long part_stride = 0, const float* part_bias = nullptr);
 
 // encoder self-attention (non-causal, T keys), Q/K h16 [B][T][d], V^T h16 [B][H][64][Tp] -> O h16 [B][T][d]
 void launch_encoder_attention(const h16* q, const h16* k, const h16* vt, h16* o, int batch, int T, int t_pad,

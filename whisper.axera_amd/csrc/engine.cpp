@@ -114,6 +114,10 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
     batched_ln_ = !(e && e[0] == '0') && d % 128 == 0 && d <= 1024;
     cfg_.ints["batched_ln"] = batched_ln_ ? 1 : 0;
   }
+  {
+    const char* e = getenv("AX_WHISPER_ENC_SPLITK");
+    enc_split_k_ = !(e && e[0] == '0');
+  }
   cfg_.ints["t2s"] = t2s_ ? 1 : 0;
   cfg_.ints["fp16"] = AXW_F16;  // 16-bit storage / MFMA operand type of this engine: 0 bfloat16, 1 IEEE half
   ensure_capacity(std::max(1, max_batch));
@@ -498,6 +502,7 @@ void Engine::ensure_capacity(int batch) {
   d_vt_ = (h16*)A((size_t)B * d * t_pad_ * 2, true);
   d_attn_ = (h16*)A((size_t)B * T * d * 2);
   d_ffn_ = (h16*)A((size_t)B * T * 4 * d * 2);
+  d_enc_part_ = (float*)A((size_t)4 * kEncPartClips * T * d * 4);  // split-K partials of the encoder's residual GEMMs (few clips only)
   d_cross_k_ = (h16*)A((size_t)L * B * H * t_pad_ * 64 * 2, true);
   d_cross_v_ = (h16*)A((size_t)L * B * H * t_pad_ * 64 * 2, true);
   d_self_k_ = (h16*)A((size_t)L * B * H * Tc * 64 * 2, true);
@@ -599,9 +604,32 @@ void Engine::run_encoder(int batch) {
     q.M = T; q.N = N; q.K = K; q.batch = batch; q.d_model = d; q.epilogue = epi;
     launch_gemm(q, s);
   };
+  // Residual GEMMs of a one-clip encoder pass have 72 tiles of 128x128 for 256 CUs: split K (2-4 slices along grid.y)
+  // and let the LayerNorm that always follows fold the fp32 partials into x in fixed order (deterministic, no atomics).
+  int pend_n = 0;
+  const float* pend_bias = nullptr;
+  auto resid = [&](const h16* A, int K, const h16* W, const float* bias) {
+    const int tiles = (d / 128) * ((T + 127) / 128) * batch, nk = K / 64;
+    int split = 1;
+    if (enc_split_k_ && d % 128 == 0 && batch <= kEncPartClips && tiles * 2 <= 256)
+      for (int sp = 4; sp > 1; --sp)
+        if (nk % sp == 0 && nk / sp >= 4 && tiles * sp <= 512) { split = sp; break; }
+    if (split == 1) { linear(A, K, W, bias, d_x_, d, EPI_RESID_F32); return; }
+    GemmParams q{};
+    q.A = A; q.lda = K; q.a_batch_stride = (long)T * K;
+    q.W = W; q.M = T; q.N = d; q.K = K; q.batch = batch; q.d_model = d; q.epilogue = EPI_PARTIAL_F32;
+    q.ksplit = split; q.part = d_enc_part_; q.part_stride = (long)kEncPartClips * T * d;
+    launch_gemm(q, s);
+    pend_n = split;
+    pend_bias = bias;
+  };
+  auto layernorm = [&](const float* g, const float* be) {
+    launch_layernorm_bf16(d_x_, g, be, d_ln_, (long)batch * T, d, s, d_enc_part_, pend_n, (long)kEncPartClips * T * d, pend_bias);
+    pend_n = 0;
+  };
   for (int l = 0; l < cfg_.n_audio_layer; ++l) {
     const EncLayer& e = enc_[l];
-    launch_layernorm_bf16(d_x_, e.ln1_w, e.ln1_b, d_ln_, (long)batch * T, d, s);
+    layernorm(e.ln1_w, e.ln1_b);
     GemmParams q{};
     q.A = d_ln_; q.lda = d; q.a_batch_stride = (long)T * d;
     q.W = e.w_qkv; q.bias = e.b_qkv;
@@ -609,14 +637,26 @@ void Engine::run_encoder(int batch) {
     q.C2 = d_k_; q.c2_batch_stride = (long)T * d;
     q.C3 = d_vt_; q.c3_batch_stride = (long)d * t_pad_;
     q.M = T; q.N = 3 * d; q.K = d; q.batch = batch; q.d_model = d; q.t_pad = t_pad_; q.epilogue = EPI_QKV;
-    launch_gemm(q, s);
+    if (enc_split_k_ && (3 * d / 128) * ((T + 127) / 128) * batch <= 256) {
+      // few tiles (one clip: 144 + 72): the Q,K launch and the V launch (swapped operands) run side by side
+      HIP_CHECK(hipEventRecord(ev_fork_, s));
+      HIP_CHECK(hipStreamWaitEvent(branch_stream_[0], ev_fork_, 0));
+      q.qkv_part = 1;
+      launch_gemm(q, s);
+      q.qkv_part = 2;
+      launch_gemm(q, branch_stream_[0]);
+      HIP_CHECK(hipEventRecord(ev_join_[0], branch_stream_[0]));
+      HIP_CHECK(hipStreamWaitEvent(s, ev_join_[0], 0));
+    } else {
+      launch_gemm(q, s);
+    }
     launch_encoder_attention(d_q_, d_k_, d_vt_, d_attn_, batch, T, t_pad_, d, H, s);
-    linear(d_attn_, d, e.w_o, e.b_o, d_x_, d, EPI_RESID_F32);
-    launch_layernorm_bf16(d_x_, e.ln2_w, e.ln2_b, d_ln_, (long)batch * T, d, s);
+    resid(d_attn_, d, e.w_o, e.b_o);
+    layernorm(e.ln2_w, e.ln2_b);
     linear(d_ln_, d, e.w_fc1, e.b_fc1, d_ffn_, 4 * d, EPI_BIAS_GELU_BF16);
-    linear(d_ffn_, 4 * d, e.w_fc2, e.b_fc2, d_x_, d, EPI_RESID_F32);
+    resid(d_ffn_, 4 * d, e.w_fc2, e.b_fc2);
   }
-  launch_layernorm_bf16(d_x_, ln_post_w_, ln_post_b_, d_ln_, (long)batch * T, d, s);
+  layernorm(ln_post_w_, ln_post_b_);
   // cross K/V of all decoder layers (export_onnx.py:205-210), written in the decoder's layouts
   GemmParams c{};
   c.A = d_ln_; c.lda = d; c.a_batch_stride = (long)T * d;

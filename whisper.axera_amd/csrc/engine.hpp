@@ -114,6 +114,9 @@ class Engine final : public IEngine {
   h16 *d_mel_tm_ = nullptr, *d_h1_ = nullptr, *d_ln_ = nullptr, *d_q_ = nullptr, *d_k_ = nullptr, *d_vt_ = nullptr,
        *d_attn_ = nullptr, *d_ffn_ = nullptr;
   float* d_x_ = nullptr;
+  static constexpr int kEncPartClips = 2;  // split-K of the encoder's residual GEMMs pays for at most this many clips
+  float* d_enc_part_ = nullptr;
+  bool enc_split_k_ = true;
   h16 *d_cross_k_ = nullptr, *d_cross_v_ = nullptr, *d_self_k_ = nullptr, *d_self_v_ = nullptr;
   float *d_xdec_ = nullptr, *d_qdec_ = nullptr, *d_hid_ = nullptr, *d_part_self_ = nullptr, *d_part_cross_ = nullptr;
   h16 *d_act_[2] = {nullptr, nullptr}, *d_att_[2] = {nullptr, nullptr}, *d_hidp_[2] = {nullptr, nullptr};

@@ -87,7 +87,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&accw
       const int n = nb + cc;
       f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-      if constexpr (EPI == EPI_RESID_F32) {
+      if constexpr (EPI == EPI_PARTIAL_F32) {
+        float* slab = p.part + (long)blockIdx.y * p.part_stride + (long)bz * p.M * p.N;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int row = 4 * t + rr, m = mb + row;
+          if (m < p.M) *reinterpret_cast<f32x4*>(slab + (long)m * p.N + n) = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc);
+        }
+      } else if constexpr (EPI == EPI_RESID_F32) {
         f32x4 cur[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -214,8 +221,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = p.K / BK;
-  stage(0, 0);
+  // split-K (EPI_PARTIAL_F32, grid.y slices): this workgroup multiplies k-tiles [k_first, k_first + nk)
+  const int nk = EPI == EPI_PARTIAL_F32 ? p.K / BK / p.ksplit : p.K / BK;
+  const int k_first = EPI == EPI_PARTIAL_F32 ? (int)blockIdx.y * nk : 0;
+  stage(0, k_first);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   // k-tile kt+1 streams into the other LDS buffer while k-tile kt is multiplied; one drain + barrier per k-tile.
   for (int kt = 0; kt + 1 < nk; ++kt) {
     const int cur = kt & 1;
-    stage(cur ^ 1, kt + 1);
+    stage(cur ^ 1, k_first + kt + 1);
     compute(cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -515,10 +524,19 @@ void launch_gemm(const GemmParams& p, hipStream_t s) {
     case EPI_BIAS_GELU_BF16: launch_one<EPI_BIAS_GELU_BF16, false>(p, 0, p.N, s); break;
     case EPI_GELU_POS_F32: launch_one<EPI_GELU_POS_F32, false>(p, 0, p.N, s); break;
     case EPI_RESID_F32: launch_one<EPI_RESID_F32, false>(p, 0, p.N, s); break;
+    case EPI_PARTIAL_F32: {  // few-tile launches only: always the 128x128 kernel, K slices along grid.y
+      if (p.ksplit < 1 || (p.K / BK) % p.ksplit != 0 || p.N % BN != 0) { fprintf(stderr, "[ax_whisper] launch_gemm: bad split-K (K=%d, ksplit=%d)\n", p.K, p.ksplit); abort(); }
+      GemmParams q = p;
+      q.n_begin = 0;
+      q.n_tiles = p.N / BN;
+      dim3 grid(q.n_tiles * ((p.M + BM - 1) / BM) * p.batch, p.ksplit);
+      hipLaunchKernelGGL((gemm_bf16_kernel<EPI_PARTIAL_F32, false>), grid, dim3(256), 4 * TILE_BYTES, s, q);
+      break;
+    }
     case EPI_QKV:  // Q,K rows normal; V rows with swapped operands (V^T output, four consecutive frames per lane)
       if (p.M % 4 != 0) { fprintf(stderr, "[ax_whisper] launch_gemm: EPI_QKV needs M %% 4 == 0 (M=%d)\n", p.M); abort(); }
-      launch_one<EPI_QKV, false>(p, 0, 2 * p.d_model, s);
-      launch_one<EPI_QKV, true>(p, 2 * p.d_model, 3 * p.d_model, s);
+      if (p.qkv_part != 2) launch_one<EPI_QKV, false>(p, 0, 2 * p.d_model, s);
+      if (p.qkv_part != 1) launch_one<EPI_QKV, true>(p, 2 * p.d_model, 3 * p.d_model, s);
       break;
     case EPI_CROSS_KV:  // weight rows: all layers' K first (swapped, blocked layout), then all layers' V
       launch_one<EPI_CROSS_KV, true>(p, 0, p.n_layer * p.d_model, s);
@@ -529,19 +547,35 @@ void launch_gemm(const GemmParams& p, hipStream_t s) {
 
 // ---------------------------------------------------------------------------- LayerNorm
 // fp32 rows -> h16 rows, eps 1e-5, biased variance (nn.LayerNorm [upstream]); one wave per row.
-__global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                             const float* __restrict__ b, h16* __restrict__ y, long rows, int d) {
+// n_part > 0: the row first takes in the split-K partials of the GEMM before it (x += bias + part[0] + part[1] + ...,
+// always in that order: deterministic) and is written back — the residual add of an EPI_PARTIAL_F32 launch.
+__global__ __launch_bounds__(256) void layernorm_bf16_kernel(float* __restrict__ x, const float* __restrict__ g,
+                                                             const float* __restrict__ b, h16* __restrict__ y, long rows, int d,
+                                                             const float* __restrict__ part, int n_part, long part_stride,
+                                                             const float* __restrict__ part_bias) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float4* xr = reinterpret_cast<const float4*>(x + row * d);
+  float4* xr = reinterpret_cast<float4*>(x + row * d);
   const int nv = d >> 2;  // float4 per row
   float4 v[8];            // d <= 2048
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     int c = lane + 64 * i;
-    if (c < nv) { v[i] = xr[c]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+    if (c < nv) {
+      v[i] = xr[c];
+      if (n_part > 0) {
+        const float4 bb = reinterpret_cast<const float4*>(part_bias)[c];
+        v[i].x += bb.x; v[i].y += bb.y; v[i].z += bb.z; v[i].w += bb.w;
+        for (int q = 0; q < n_part; ++q) {
+          const float4 pp = reinterpret_cast<const float4*>(part + q * part_stride + row * d)[c];
+          v[i].x += pp.x; v[i].y += pp.y; v[i].z += pp.z; v[i].w += pp.w;
+        }
+        xr[c] = v[i];
+      }
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
   }
   const float mean = wave_sum(s) / d;
   float q = 0.f;
@@ -569,8 +603,10 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
   }
 }
 
-void launch_layernorm_bf16(const float* x, const float* g, const float* b, h16* y, long rows, int d, hipStream_t s) {
-  hipLaunchKernelGGL(layernorm_bf16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, g, b, y, rows, d);
+void launch_layernorm_bf16(float* x, const float* g, const float* b, h16* y, long rows, int d, hipStream_t s, const float* part,
+                           int n_part, long part_stride, const float* part_bias) {
+  hipLaunchKernelGGL(layernorm_bf16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, g, b, y, rows, d, part, n_part,
+                     part_stride, part_bias);
 }
 
 }  // inline namespace AXW_NS
