@@ -689,7 +689,12 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     // the grid; otherwise the 4d-wide layer keeps the even deal over all workgroups.
     constexpr int SLD = CT / LD, NP_Q = (3 * D + SLD - 1) / SLD, NP_F = (F + SLD - 1) / SLD;
     const int pk_qkv = NP_Q <= P ? P - NP_Q : -1;
-    const int pk_f = (NP_F <= P && NP_Q <= P && NP_F + NP_Q >= P) ? 0 : -1;
+    // The 4d-wide layer's producers start BEHIND the NP_D workgroups that produce the three d-wide layers (those are
+    // the busiest: their mlp.0 rows could only be requested after their cross-attention-output publish, ~2 us before
+    // use, and arrived late — every consumer of the hidden vector waited for them: 1.2 us of skew per layer).
+    const int pk_f = (NP_D + NP_F <= P && NP_Q <= P && NP_D + NP_F + NP_Q >= P) ? NP_D : ((NP_F <= P && NP_Q <= P && NP_F + NP_Q >= P) ? 0 : -1);
+    const bool is_fc1 = pk_f < 0 || (wg >= pk_f && wg < pk_f + NP_F);
+    const bool early_fc2 = in_f2 && !is_fc1;  // its mlp.2 rows can be requested a phase earlier (no mlp.0 rows in the way)
     const int pk_d = 0;  // d rows in passes of CT/LD (or CT/LF) rows: never more producers than workgroups (P <= d)
     // two register sets for the d-wide layers are enough: a phase computes from one while the next phase's rows land
     // in the other (qkv A, o B, cq A, co B, mlp.0 A, [mlp.2 F], next qkv / vocabulary A)
@@ -839,6 +844,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           rb.publish(ctid, res, pk, ctl + 2, G + O_Y2, tag, [](float v) { return v; });
         }
         ra.prefetch(w_fc1, b_fc1, D, F, wg, P, ctid, pk_f);
+        if (early_fc2) rs_fc2.prefetch(w_fc2, b_fc2, F, D, wg, P, ctid, pk_d);
         kv_piece(8, 11);
         AXW_STAMP(25)
         AXW_TL(15)
@@ -849,7 +855,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_TL(22)
         ra.run(w_fc1, b_fc1, D, act, ctid, res);
         ra.publish(ctid, res, pk, ctl + 2, G + O_HID, tag, [](float v) { return gelu_erf(v); });
-        rs_fc2.prefetch(w_fc2, b_fc2, F, D, wg, P, ctid, pk_d);
+        if (!early_fc2) rs_fc2.prefetch(w_fc2, b_fc2, F, D, wg, P, ctid, pk_d);
         kv_piece(11, 13);
         AXW_STAMP(27)
         AXW_TL(16)
