@@ -52,6 +52,15 @@ void launch_embed(const h16* tok_emb, const float* pos, const int* tok, const De
 // h16 weights, export_onnx.py:221-230), instead of reading them from a preceding GEMM launch: the 98 KB of weight rows
 // come from L2 (the 64 clips of a head share them) while the first K/V block is already in flight, and a decoder
 // layer loses one dependent launch.
+// K/V blocks are read once per decoder step and a step streams 4 GB of them at 64 clips: the loads are non-temporal
+// (do not keep the lines), so that the 198 MB of layer weights the GEMMs in between re-read every step stay in the
+// Infinity Cache. Measured at 64 clips: decode 552 -> 522 ms, the attention launches 5.1 -> 5.5 TB/s.
+__device__ __forceinline__ uint4 ld_kv(const uint4* p) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 template <bool FUSE_Q>
 __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, int cap_blocks) {
   __shared__ float s_part[4][kPartStride];
@@ -74,9 +83,9 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
   int blk = blk_begin + wave;
   auto load_block = [&](int bk) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) kn[i] = *reinterpret_cast<const uint4*>(kb + (long)bk * 4096 + i * 512 + lane * 8);
+    for (int i = 0; i < 8; ++i) kn[i] = ld_kv(reinterpret_cast<const uint4*>(kb + (long)bk * 4096 + i * 512 + lane * 8));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) vn[i] = *reinterpret_cast<const uint4*>(vb + ((long)bk * 64 + 8 * i + (lane >> 3)) * 64 + (lane & 7) * 8);
+    for (int i = 0; i < 8; ++i) vn[i] = ld_kv(reinterpret_cast<const uint4*>(vb + ((long)bk * 64 + 8 * i + (lane >> 3)) * 64 + (lane & 7) * 8));
   };
   if (blk < blk_cap_end) load_block(blk);
   float qv[64];
