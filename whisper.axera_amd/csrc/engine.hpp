@@ -71,7 +71,7 @@ class Engine final : public IEngine {
   hipGraphExec_t step_graph(int batch, int max_new);
   int greedy_loop(int batch, int max_new, const int* max_new_clip = nullptr);
   // batch 1: the whole loop as one persistent launch (decode_persistent.hip); returns steps run, -1 if it gave up
-  int run_persistent(int max_new, const int* d_forced, int n_forced, float* d_logits, int* d_argmax);
+  int run_persistent(int max_new, const int* d_forced, int n_forced, float* d_logits, int* d_argmax, int slot = 0);
   void fetch_ids(int batch, int32_t* ids, int* n_ids);
 
   ModelConfig cfg_;
