@@ -134,8 +134,64 @@ def test_server_asr_round_trip(built_lib, micro_case):
         [t.start() for t in th]
         [t.join() for t in th]
         assert all(o[0] == 200 and o[1]["text"] == js["text"] for o in out)  # micro-batched requests agree with a single one
+        # a poisoned request (NaN samples) gets its 400 without failing the strangers batched with it
+        bad = pcm.copy()
+        bad[77] = np.nan
+        out = [None] * 5
+        th = [threading.Thread(target=lambda i=i: out.__setitem__(i, post((bad if i == 2 else pcm).tobytes()))) for i in range(5)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert out[2][0] == 400 and all(o[0] == 200 and o[1]["text"] == js["text"] for i, o in enumerate(out) if i != 2)
     finally:
         proc.kill()
+
+
+def test_server_one_batcher_per_device(built_lib, micro_case):
+    """whisper_srv --devices a,b,...: one handle and one batcher thread per listed device on the shared queue (a one-GPU
+    box lists its device twice: two engines, two batchers)."""
+    import json
+    import socket
+    import threading
+    import time
+    import urllib.request
+
+    from conftest import load_demo_pcm
+
+    srv = os.path.join(os.path.dirname(built_lib.LIB_PATH), "whisper_srv")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    proc = subprocess.Popen([srv, "--port", str(port), "-t", "micro", "-p", micro_case.root, "-l", "zh", "--max_batch", "2",
+                             "--devices", "0,0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        base = f"http://127.0.0.1:{port}"
+        for _ in range(200):
+            try:
+                if json.load(urllib.request.urlopen(base + "/health", timeout=2))["status"] == "ok":
+                    break
+            except Exception:
+                time.sleep(0.1)
+        else:
+            raise AssertionError("server did not come up")
+        pcm = load_demo_pcm()
+        e = built_lib.Whisper("micro", micro_case.root, "zh", device=0)
+        want = e.run(pcm)
+        e.close()
+
+        def post(body):
+            req = urllib.request.Request(base + "/asr", data=body, headers={"Content-Type": "application/octet-stream"}, method="POST")
+            r = urllib.request.urlopen(req, timeout=120)
+            return r.status, json.load(r)
+
+        out = [None] * 9
+        th = [threading.Thread(target=lambda i=i: out.__setitem__(i, post(pcm.tobytes()))) for i in range(9)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert all(o[0] == 200 and o[1]["text"] == want for o in out)
+    finally:
+        proc.kill()
+        head = proc.stdout.read(400)
+        assert "devices: 2" in head
 
 
 def test_zh_transcript_goes_through_t2s(built_lib, micro_case, monkeypatch, tmp_path):

@@ -270,7 +270,9 @@ AX_WHISPER_API int AX_WHISPER_GetConfigInt(AX_WHISPER_HANDLE handle, const char*
   Handle* h = H(handle);
   if (!h || !key || h->group.size() == 0) return INT_MIN;
   if (!strcmp(key, "n_devices")) return h->group.size();
-  auto& m = h->group.primary().config().ints;
+  Engine& e = h->group.primary();
+  std::lock_guard<std::mutex> lock(e.mutex());  // a few values change while the engine runs (persistent_decode, ...)
+  auto& m = e.config().ints;
   auto it = m.find(key);
   return it == m.end() ? INT_MIN : (int)it->second;
 }
