@@ -13,11 +13,12 @@ CSRC = os.path.join(ROOT, "whisper.axera_amd", "csrc")
 KERNEL_FILES = ["frontend", "gemm", "encoder_attn", "decoder", "decode_gemv", "decode_gemm", "decode_persistent"]
 
 
+@pytest.mark.parametrize("f16", [0, 1], ids=["bf16", "fp16"])  # both builds of every kernel file (csrc/common.hpp AXW_F16)
 @pytest.mark.parametrize("name", KERNEL_FILES)
-def test_no_scratch_no_spills(name, tmp_path):
+def test_no_scratch_no_spills(name, f16, tmp_path):
     out = tmp_path / f"{name}.s"
     r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-                        "--cuda-device-only", "-S", "-o", str(out), os.path.join(CSRC, name + ".hip")],
+                        f"-DAXW_F16={f16}", "--cuda-device-only", "-S", "-o", str(out), os.path.join(CSRC, name + ".hip")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     text = out.read_text()

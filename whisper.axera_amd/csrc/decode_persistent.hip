@@ -711,7 +711,10 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     // use, and arrived late — every consumer of the hidden vector waited for them: 1.2 us of skew per layer).
     const int pk_f = (NP_D + NP_F <= P && NP_Q <= P && NP_D + NP_F + NP_Q >= P) ? NP_D : ((NP_F <= P && NP_Q <= P && NP_F + NP_Q >= P) ? 0 : -1);
     const bool is_fc1 = pk_f < 0 || (wg >= pk_f && wg < pk_f + NP_F);
-    const bool early_fc2 = in_f2 && !is_fc1;  // its mlp.2 rows can be requested a phase earlier (no mlp.0 rows in the way)
+    // its mlp.2 rows can be requested a phase earlier (no mlp.0 rows in the way); not for wide models: 10 chunks per lane
+    // held across the mlp.0 phase do not fit the register budget (the d=1280 instantiation went to scratch)
+    constexpr bool kEarlyFc2 = CF <= 6;
+    const bool early_fc2 = kEarlyFc2 && in_f2 && !is_fc1;
     const int pk_d = 0;  // d rows in passes of CT/LD (or CT/LF) rows: never more producers than workgroups (P <= d)
     // two register sets for the d-wide layers are enough: a phase computes from one while the next phase's rows land
     // in the other (qkv A, o B, cq A, co B, mlp.0 A, [mlp.2 F], next qkv / vocabulary A)
@@ -861,7 +864,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           rb.publish(ctid, res, pk, ctl + 2, G + O_Y2, tag, [](float v) { return v; });
         }
         ra.prefetch(w_fc1, b_fc1, D, F, wg, P, ctid, pk_f);
-        if (early_fc2) rs_fc2.prefetch(w_fc2, b_fc2, F, D, wg, P, ctid, pk_d);
+        if constexpr (kEarlyFc2) {
+          if (early_fc2) rs_fc2.prefetch(w_fc2, b_fc2, F, D, wg, P, ctid, pk_d);
+        }
         kv_piece(8, 11);
         AXW_STAMP(25)
         AXW_TL(15)
