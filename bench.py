@@ -411,6 +411,8 @@ def run_rank(args) -> int:
                    "collective": (f"{backend} all_gather of int32 [count, ids] rows, once per step" if use_dist else "none")},
         "rtf": round(dt / args.steps / (B * 30.0), 6),
     }
+    if os.environ.get("AXW_BENCH_ONE_DEVICE") == "1" and world > 1:
+        out["data"] = "synthetic; REHEARSAL on ONE device (AXW_BENCH_ONE_DEVICE=1): all ranks share GPU 0 — not a multi-GPU measurement"
     if rehearsal:
         out["data"] = "REHEARSAL (AXW_BENCH_REHEARSAL=1): no GPU and no engine ran — plumbing test of the N>1 path only"
         out["value"] = None

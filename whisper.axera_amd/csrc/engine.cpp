@@ -544,14 +544,9 @@ void Engine::upload_pcm(const float* const* pcm, const int* n_samples, int batch
     // reference); NaN / Inf samples turn every mel value, hence every logit, into NaN: refuse them here (-1 at the ABI)
     // instead of decoding garbage. Finite out-of-range samples pass through as they do in the reference.
     float* dst = h_pcm_ + (size_t)b * pcm_stride_;
-    const float* src = pcm[b];
+    memcpy(dst, pcm[b], (size_t)n * 4);
     unsigned bad = 0;
-    for (int i = 0; i < n; ++i) {
-      uint32_t u;
-      memcpy(&u, src + i, 4);
-      bad |= ((u & 0x7f800000u) == 0x7f800000u);
-      memcpy(dst + i, &u, 4);
-    }
+    for (int i = 0; i < n; ++i) bad |= !std::isfinite(dst[i]);  // vectorises: ~0.1 ms per 30 s clip
     if (bad) throw std::runtime_error("clip " + std::to_string(b) + ": non-finite PCM sample (NaN or Inf)");
     HIP_CHECK(hipMemcpyAsync(d_pcm_ + (size_t)b * pcm_stride_, h_pcm_ + (size_t)b * pcm_stride_, (size_t)n * 4,
                              hipMemcpyHostToDevice, stream()));
