@@ -50,15 +50,21 @@ constexpr int CT = NCW * 64;       // compute threads
 // rows, 55 MB of cross K/V against 256 MB of Infinity Cache + 32 MB of L2). The layer weights are the latency-critical
 // loads (requested one hand-off ahead of their use) and are re-read every step: default policy, so that they are served
 // from the Infinity Cache. The vocabulary rows are a once-per-step bandwidth-bound stream and the cross K/V tiles are
-// requested a whole layer ahead: both non-temporal, so that they do not evict the layer weights. Measured, decode of
-// one clip: all default 121.0 ms; vocabulary rows nt 118.1 ms; every weight row nt 129.1 ms.
+// requested a whole layer ahead: both non-temporal, so that they do not evict the layer weights. Measured (decode of
+// one clip, A/B/A/B inside one GPU call): on one box all-default 121.0 / vocabulary nt 118.1 / both 118.1 ms, on
+// another all-default 121.2 / vocabulary nt 121.2 / cross K/V nt 118.9 / both 119.1 ms — which of the two streams
+// matters differs between boxes (allocation placement), both together are within 0.3 ms of the better everywhere.
+// Every weight row nt: 129.1 ms (the layer weights do live in the cache between steps).
 #ifndef AXW_VOCAB_NT
 #define AXW_VOCAB_NT 1
 #endif
 #ifndef AXW_KV_NT_LDS
-#define AXW_KV_NT_LDS 0
+#define AXW_KV_NT_LDS 1
 #endif
 constexpr bool kVocabNT = AXW_VOCAB_NT != 0;
+#ifndef AXW_VOCAB_CACHED_PCT
+#define AXW_VOCAB_CACHED_PCT 0   // experiment: this share of every workgroup's vocabulary rows keeps the default policy
+#endif
 constexpr int kKvAux = AXW_KV_NT_LDS ? 2 : 0;  // aux bits of global_load_lds: 2 = nt
 constexpr int kSpinFree = 1024;
 constexpr long long kSpinTicks = 5000000;
@@ -192,6 +198,11 @@ __device__ __forceinline__ void rows_load(u32x4 (&w)[CH], const h16* W, int K, i
     if constexpr (NT) w[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + (j + LPR * i) * 8));
     else w[i] = *reinterpret_cast<const u32x4*>(wr + (j + LPR * i) * 8);
   }
+}
+template <int LPR, int CH>
+__device__ __forceinline__ void rows_load_sel(u32x4 (&w)[CH], const h16* W, int K, int row, int tid, bool nt) {
+  if (nt) rows_load<LPR, CH, true>(w, W, K, row, tid);
+  else rows_load<LPR, CH, false>(w, W, K, row, tid);
 }
 #define AXW_FMA8(ACC0, ACC1, U, X0, X1)                       \
   ACC0 = fmaf(h16lo(U[0]), X0.x, ACC0);       \
@@ -952,14 +963,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           u32x4 wn[CD];
           {
             const int nrow = r0 + slot + SD;
-            rows_load<LD, CD, kVocabNT>(wn, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid);
+            rows_load_sel<LD, CD>(wn, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid, kVocabNT && (nrow - r0) * 100 >= (r1 - r0) * AXW_VOCAB_CACHED_PCT);
           }
           for (int row = r0 + slot; row < r1; row += SD) {
             u32x4 wr[CD];
 #pragma unroll
             for (int i = 0; i < CD; ++i) { wr[i] = ra.w[i]; ra.w[i] = wn[i]; }
             const int nrow = row + 2 * SD;
-            rows_load<LD, CD, kVocabNT>(wn, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid);
+            rows_load_sel<LD, CD>(wn, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid, kVocabNT && (nrow - r0) * 100 >= (r1 - r0) * AXW_VOCAB_CACHED_PCT);
             consume(wr, row);
           }
         } else {  // wide rows: one pass ahead (register budget)
@@ -968,7 +979,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
 #pragma unroll
             for (int i = 0; i < CD; ++i) wr[i] = ra.w[i];
             const int nrow = row + SD;
-            rows_load<LD, CD, kVocabNT>(ra.w, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid);
+            rows_load_sel<LD, CD>(ra.w, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid, kVocabNT && (nrow - r0) * 100 >= (r1 - r0) * AXW_VOCAB_CACHED_PCT);
             consume(wr, row);
           }
         }
