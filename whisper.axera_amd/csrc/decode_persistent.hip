@@ -62,9 +62,6 @@ constexpr int CT = NCW * 64;       // compute threads
 #define AXW_KV_NT_LDS 1
 #endif
 constexpr bool kVocabNT = AXW_VOCAB_NT != 0;
-#ifndef AXW_VOCAB_CACHED_PCT
-#define AXW_VOCAB_CACHED_PCT 0   // experiment: this share of every workgroup's vocabulary rows keeps the default policy
-#endif
 constexpr int kKvAux = AXW_KV_NT_LDS ? 2 : 0;  // aux bits of global_load_lds: 2 = nt
 constexpr int kSpinFree = 1024;
 constexpr long long kSpinTicks = 5000000;
@@ -198,11 +195,6 @@ __device__ __forceinline__ void rows_load(u32x4 (&w)[CH], const h16* W, int K, i
     if constexpr (NT) w[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + (j + LPR * i) * 8));
     else w[i] = *reinterpret_cast<const u32x4*>(wr + (j + LPR * i) * 8);
   }
-}
-template <int LPR, int CH>
-__device__ __forceinline__ void rows_load_sel(u32x4 (&w)[CH], const h16* W, int K, int row, int tid, bool nt) {
-  if (nt) rows_load<LPR, CH, true>(w, W, K, row, tid);
-  else rows_load<LPR, CH, false>(w, W, K, row, tid);
 }
 #define AXW_FMA8(ACC0, ACC1, U, X0, X1)                       \
   ACC0 = fmaf(h16lo(U[0]), X0.x, ACC0);       \
@@ -963,14 +955,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           u32x4 wn[CD];
           {
             const int nrow = r0 + slot + SD;
-            rows_load_sel<LD, CD>(wn, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid, kVocabNT && (nrow - r0) * 100 >= (r1 - r0) * AXW_VOCAB_CACHED_PCT);
+            rows_load<LD, CD, kVocabNT>(wn, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid);
           }
           for (int row = r0 + slot; row < r1; row += SD) {
             u32x4 wr[CD];
 #pragma unroll
             for (int i = 0; i < CD; ++i) { wr[i] = ra.w[i]; ra.w[i] = wn[i]; }
             const int nrow = row + 2 * SD;
-            rows_load_sel<LD, CD>(wn, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid, kVocabNT && (nrow - r0) * 100 >= (r1 - r0) * AXW_VOCAB_CACHED_PCT);
+            rows_load<LD, CD, kVocabNT>(wn, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid);
             consume(wr, row);
           }
         } else {  // wide rows: one pass ahead (register budget)
@@ -979,7 +971,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
 #pragma unroll
             for (int i = 0; i < CD; ++i) wr[i] = ra.w[i];
             const int nrow = row + SD;
-            rows_load_sel<LD, CD>(ra.w, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid, kVocabNT && (nrow - r0) * 100 >= (r1 - r0) * AXW_VOCAB_CACHED_PCT);
+            rows_load<LD, CD, kVocabNT>(ra.w, AXW_COLD(tok_emb), D, nrow < r1 ? nrow : r0, ctid);
             consume(wr, row);
           }
         }
