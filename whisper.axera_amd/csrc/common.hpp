@@ -60,6 +60,24 @@ __device__ __forceinline__ float h16hi(unsigned u) { return __uint_as_float(u & 
 #define AXW_MFMA_32x32x16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
 #define AXW_MFMA_16x16x32(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
 #endif
+// fp32 accumulate of a 2-element dot product of packed h16 pairs (v_dot2c_f32_bf16 / v_dot2c_f32_f16), and the split of
+// two fp32 values into packed (hi, lo) h16 pairs: x = hi + lo to 16 (bfloat16) / 22 (half) significant bits
+#if AXW_F16
+__device__ __forceinline__ float h16dot2(unsigned a, unsigned b, float c) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(axw_half2, a), __builtin_bit_cast(axw_half2, b), c, false);
+}
+#else
+typedef __bf16 axw_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float h16dot2(unsigned a, unsigned b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(axw_bf2, a), __builtin_bit_cast(axw_bf2, b), c, false);
+}
+#endif
+__device__ __forceinline__ void h16split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const h16 h0 = (h16)x0, h1 = (h16)x1;
+  const h16 l0 = (h16)(x0 - (float)h0), l1 = (h16)(x1 - (float)h1);
+  hi = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+  lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

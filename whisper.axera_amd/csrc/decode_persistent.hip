@@ -308,57 +308,114 @@ __device__ __forceinline__ float sum_hi3(float v) {
   return v;
 }
 
-// One wave, one block of 64 keys in LDS: kblk = [8 (d/8)][64 keys][8] h16 (lane = key for the scores),
-// vblk = [64 keys][64] h16. Writes the softmax partial (m, l, o[64]) to part[0..66).
-// pw: 64 floats of wave-private LDS scratch that transposes the probabilities (no cross-lane shuffles).
-__device__ __forceinline__ void attn_block(const h16* kblk, const h16* vblk, const float* qs, bool valid, float* pw, float* part, int lane) {
-  float sc0 = 0.f, sc1 = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const u32x4 kq = *reinterpret_cast<const u32x4*>(kblk + i * 512 + lane * 8);
-    const float4 q0 = *reinterpret_cast<const float4*>(qs + i * 8), q1 = *reinterpret_cast<const float4*>(qs + i * 8 + 4);
-    AXW_FMA8(sc0, sc1, kq, q0, q1)
-  }
-  float sc = (sc0 + sc1) * 0.125f;  // (64^-0.25)^2, export_onnx.py:116,124-126
-  if (!valid) sc = -INFINITY;
-  const float m = wmax(sc);  // -inf only for a block without a single valid key
-  const float pk = m > -INFINITY ? __expf(sc - m) : 0.f;
-  const float lsum = wsum(pk);
-  pw[(lane & 7) * 8 + (lane >> 3)] = pk;  // key k = 8i + r -> pw[r*8 + i]
-  __builtin_amdgcn_wave_barrier();
-  const float4 p0 = *reinterpret_cast<const float4*>(pw + (lane >> 3) * 8), p1 = *reinterpret_cast<const float4*>(pw + (lane >> 3) * 8 + 4);
-  const float pr[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-  float o[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {  // V row of key 8i + (lane>>3), dims (lane&7)*8 .. +8
-    const u32x4 vv = *reinterpret_cast<const u32x4*>(vblk + (8 * i + (lane >> 3)) * 64 + (lane & 7) * 8);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      o[2 * e] = fmaf(pr[i], h16lo(vv[e]), o[2 * e]);
-      o[2 * e + 1] = fmaf(pr[i], h16hi(vv[e]), o[2 * e + 1]);
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = sum_hi3(o[e]);
-  if (lane == 0) { part[0] = m; part[1] = lsum; }
+// One wave, one block of 64 keys in LDS: kblk = [8 (d/8)][64 keys][8] h16 (lane = key for the scores). Writes the
+// softmax partial (m, l, o[64]) to part[0..66). qp: the query as packed h16 pairs, [32] hi then [32] lo (q = hi + lo).
+// pw: 64 dwords of wave-private LDS scratch.
+// The block is VALU-bound (two compute waves share a SIMD; skipping its arithmetic altogether shortens the decode of
+// one clip by 12.6 %), so it is written for instruction count: the scores are v_dot2c dot products of the packed K
+// dwords with the packed query (2 instructions per 2 dims instead of 4), and for the self-attention cache, whose LDS
+// layout is this kernel's own, V is kept TRANSPOSED (VT: vblk = [8 (key/8)][64 dims][8 keys]) so that lane = dim
+// accumulates o[dim] with dot2 over key pairs against the packed probabilities — no unpacking, no cross-lane sums.
+// Cross-attention V tiles arrive by LDS-DMA in the HBM layout [64 keys][64 dims] and keep the lane = (key row, dim
+// chunk) form.
+template <bool VT>
+__device__ __forceinline__ void attn_block(const h16* kblk, const h16* vblk, const unsigned* qp, bool valid, float* pw, float* part, int lane) {
+#ifdef AXW_ATTN_SKIP  // timing-only build (wrong results): bounds what any speed-up of this block's arithmetic can buy
+  if (lane == 0) { part[0] = 0.f; part[1] = 1.f; }
   if (lane < 8) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) part[2 + lane * 8 + e] = o[e];
+    for (int e = 0; e < 8; ++e) part[2 + lane * 8 + e] = 0.f;
+  }
+  return;
+#endif
+  float sc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int i = 0; i < 8; ++i) {
+    const u32x4 kq = *reinterpret_cast<const u32x4*>(kblk + i * 512 + lane * 8);
+    const u32x4 qh = *reinterpret_cast<const u32x4*>(qp + i * 4), ql = *reinterpret_cast<const u32x4*>(qp + 32 + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sc[e] = h16dot2(kq[e], qh[e], sc[e]);
+      sc[e] = h16dot2(kq[e], ql[e], sc[e]);
+    }
+  }
+  float s = ((sc[0] + sc[1]) + (sc[2] + sc[3])) * 0.125f;  // (64^-0.25)^2, export_onnx.py:116,124-126
+  if (!valid) s = -INFINITY;
+  const float m = wmax(s);  // -inf only for a block without a single valid key
+  const float pk = m > -INFINITY ? __expf(s - m) : 0.f;
+  const float lsum = wsum(pk);
+  if constexpr (VT) {
+    // probabilities as packed (hi, lo) h16 in wave-private LDS: key k -> half-word k of ph (dwords 0..31) / pl (32..63)
+    const h16 ph = (h16)pk, pl = (h16)(pk - (float)ph);
+    reinterpret_cast<h16*>(pw)[lane] = ph;
+    reinterpret_cast<h16*>(pw + 32)[lane] = pl;
+    __builtin_amdgcn_wave_barrier();
+    float o0 = 0.f, o1 = 0.f;
+    const unsigned* pwu = reinterpret_cast<const unsigned*>(pw);
+#pragma unroll 2
+    for (int i = 0; i < 8; ++i) {  // keys 8i..8i+7 of dim `lane`
+      const u32x4 vv = *reinterpret_cast<const u32x4*>(vblk + i * 512 + lane * 8);
+      const u32x4 h4 = *reinterpret_cast<const u32x4*>(pwu + i * 4), l4 = *reinterpret_cast<const u32x4*>(pwu + 32 + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        o0 = h16dot2(vv[e], h4[e], o0);
+        o0 = h16dot2(vv[e], l4[e], o0);
+        o1 = h16dot2(vv[e + 1], h4[e + 1], o1);
+        o1 = h16dot2(vv[e + 1], l4[e + 1], o1);
+      }
+    }
+    if (lane == 0) { part[0] = m; part[1] = lsum; }
+    part[2 + lane] = o0 + o1;
+  } else {
+    pw[(lane & 7) * 8 + (lane >> 3)] = pk;  // key k = 8i + r -> pw[r*8 + i]
+    __builtin_amdgcn_wave_barrier();
+    const float4 p0 = *reinterpret_cast<const float4*>(pw + (lane >> 3) * 8), p1 = *reinterpret_cast<const float4*>(pw + (lane >> 3) * 8 + 4);
+    const float pr[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // V row of key 8i + (lane>>3), dims (lane&7)*8 .. +8
+      const u32x4 vv = *reinterpret_cast<const u32x4*>(vblk + (8 * i + (lane >> 3)) * 64 + (lane & 7) * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[2 * e] = fmaf(pr[i], h16lo(vv[e]), o[2 * e]);
+        o[2 * e + 1] = fmaf(pr[i], h16hi(vv[e]), o[2 * e + 1]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = sum_hi3(o[e]);
+    if (lane == 0) { part[0] = m; part[1] = lsum; }
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part[2 + lane * 8 + e] = o[e];
+    }
   }
 }
 
-// merge nb wave partials (m, l, o[64]) in LDS: returns (l, o[c]) rescaled to the common maximum *m_out
+// merge nb (<= NCW) wave partials (m, l, o[64]) in LDS: returns (l, o[c]) rescaled to the common maximum *m_out.
+// Unrolled over all NCW records with blocks >= nb masked: every LDS read goes out at once and the exponentials are
+// independent (as a loop over a run-time nb this was nb dependent read -> exp -> FMA round trips on the one wave
+// that every consumer of the attention output waits for).
 __device__ __forceinline__ void merge_partials(const float* wpart, int nb, int c, float* m_out, float* l_out, float* o_out) {
-  float m = -INFINITY;
-  for (int b = 0; b < nb; ++b) m = fmaxf(m, wpart[b * kPS]);
+  float mb[NCW], lb[NCW], ob[NCW];
+#pragma unroll
+  for (int b = 0; b < NCW; ++b) {
+    const float mv = wpart[b * kPS], lv = wpart[b * kPS + 1], ov = wpart[b * kPS + 2 + c];
+    const bool on = b < nb;
+    mb[b] = on ? mv : -INFINITY;
+    lb[b] = on ? lv : 0.f;
+    ob[b] = on ? ov : 0.f;
+  }
+  float m = mb[0];
+#pragma unroll
+  for (int b = 1; b < NCW; ++b) m = fmaxf(m, mb[b]);
   float lt = 0.f, ov = 0.f;
-  for (int b = 0; b < nb; ++b) {
-    const float mb = wpart[b * kPS];
-    const float f = mb > -INFINITY ? __expf(mb - m) : 0.f;
-    lt += f * wpart[b * kPS + 1];
-    ov += f * wpart[b * kPS + 2 + c];
+#pragma unroll
+  for (int b = 0; b < NCW; ++b) {
+    const float f = mb[b] > -INFINITY ? __expf(mb[b] - m) : 0.f;
+    lt = fmaf(f, lb[b], lt);
+    ov = fmaf(f, ob[b], ov);
   }
   *m_out = m; *l_out = lt; *o_out = ov;
 }
@@ -382,12 +439,12 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   h16* sK = reinterpret_cast<h16*>(smem);                  // [8 blk][8][64 keys][8]  (blocked, lane = key)
-  h16* sV = sK + NCW * 4096;                                // [512 keys][64]
+  h16* sV = sK + NCW * 4096;                                // cross tiles: [512 keys][64]; self-attention cache: per block [8 (key/8)][64 dims][8 keys]
   float* act = reinterpret_cast<float*>(smem + kKvBytes);    // [F + D/8] input vector of the current rows phase
   float* wpart = act + F + D / 8;                            // [NCW][kPS] per-wave attention partials
   float* red = wpart + NCW * kPS;                            // [2*NPW] LayerNorm partial sums
-  float* qs = red + 2 * NPW;                                 // [64] query of the attention phase
-  float* am_v = qs + 64;                                     // [16] argmax scratch
+  unsigned* qs = reinterpret_cast<unsigned*>(red + 2 * NPW);  // [64] query of the attention phase as packed h16 pairs: [32] hi, [32] lo
+  float* am_v = reinterpret_cast<float*>(qs) + 64;           // [16] argmax scratch
   int* am_i = reinterpret_cast<int*>(am_v + 16);             // [16]
   int* ctl = am_i + 16;                                      // [16]: 0 give-up flag, 1 argmax of the step
   float* pk = reinterpret_cast<float*>(ctl + 16);            // [64] this workgroup's rows of the phase, assembled for the one-instruction publish
@@ -527,15 +584,20 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         if (l == sa_layer) {
           unsigned v[2];  // lanes 0-31: q, 32-63: k, 64-95: v of the head, two adjacent dims each
           const bool fail = gather2<1>(GR, tag, v, p.err, ctl, [&](int) { return tid < 96 ? O_QKV + (tid >> 5) * D + sa_head * 64 + 2 * (tid & 31) : -1; });
-          if (tid < 96) {
+          if (tid < 32) {  // the query: dims 2 tid, 2 tid + 1 as one packed (hi, lo) pair
+            unsigned hi, lo;
+            h16split2(__uint_as_float(v[0]), __uint_as_float(v[1]), hi, lo);
+            qs[tid] = hi;
+            qs[32 + tid] = lo;
+          } else if (tid < 96) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
               const int dd = 2 * (tid & 31) + e;
               const float val = __uint_as_float(v[e]);
-              if (tid < 32) qs[dd] = val;
-              else if (tid < 64)  // K row `step`, blocked [blk][d/8][key%64][8]
+              if (tid < 64)  // K row `step`, blocked [blk][d/8][key%64][8]
                 sK[(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (h16)val;
-              else sV[step * 64 + dd] = (h16)val;
+              else           // V row `step`, TRANSPOSED per block: [blk][key%64 / 8][dim][8 keys]
+                sV[(step >> 6) * 4096 + ((step >> 3) & 7) * 512 + dd * 8 + (step & 7)] = (h16)val;
             }
           }
           if (fail) ctl[0] = 1;
@@ -571,7 +633,12 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           const int ca_head = cu / kCrossSplit;
           unsigned v[2];
           const bool fail = gather2<1>(GR, tag, v, p.err, ctl, [&](int) { return tid < 32 ? O_CQ + ca_head * 64 + 2 * tid : -1; });
-          if (tid < 32) { qs[2 * tid] = __uint_as_float(v[0]); qs[2 * tid + 1] = __uint_as_float(v[1]); }
+          if (tid < 32) {
+            unsigned hi, lo;
+            h16split2(__uint_as_float(v[0]), __uint_as_float(v[1]), hi, lo);
+            qs[tid] = hi;
+            qs[32 + tid] = lo;
+          }
           if (fail) ctl[0] = 1;
           AXW_STAMP(7)
           AXW_BARRIER_CHECK(0x500 + l)
@@ -783,7 +850,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_BARRIER_CHECK(0x200 + l)
           const int nblk = (step >> 6) + 1;
           if (cw < nblk)
-            attn_block(sK + cw * 4096, sV + cw * 4096, qs, cw * 64 + lane <= step, pscr + cw * 64, wpart + cw * kPS, lane);
+            attn_block<true>(sK + cw * 4096, sV + cw * 4096, qs, cw * 64 + lane <= step, pscr + cw * 64, wpart + cw * kPS, lane);
           // no second workgroup barrier: the compute wave that arrives last merges the block partials and publishes
           __builtin_amdgcn_wave_barrier();
           int old = 0;
@@ -829,7 +896,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
           asm volatile("" ::: "memory");
           const int key = (ca_split * NCW + cw) * 64 + lane;
-          attn_block(sK + cw * 4096, sV + cw * 4096, qs, key < p.n_audio_ctx, pscr + cw * 64, wpart + cw * kPS, lane);
+          attn_block<false>(sK + cw * 4096, sV + cw * 4096, qs, key < p.n_audio_ctx, pscr + cw * 64, wpart + cw * kPS, lane);
           __builtin_amdgcn_wave_barrier();
           int old = 0;
           if (lane == 0) old = __hip_atomic_fetch_add(ctl + 3, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
