@@ -111,7 +111,7 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
     const int d = cfg_.n_text_state;
     // measured on MI355X: faster for d_model 768 at 16-64 clips (+2..8 %); slower for 1280 at 16-32 clips (-3..6 %, also
     // with eight k-steps in flight per wave) and equal at 64, which keeps the split-K sequence
-    batched_ln_ = !(e && e[0] == '0') && d % 128 == 0 && d <= 1024;
+    batched_ln_ = !(e && e[0] == '0') && d % 128 == 0 && (d <= 1024 || (e && e[0] == '2' && d <= 1280));  // '2': force (A/B runs)
     cfg_.ints["batched_ln"] = batched_ln_ ? 1 : 0;
   }
   {
@@ -820,7 +820,7 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
     c = cgemm(wq.w_o, w.b_o, d, d, GEPI_RESID, 1);
     c.a_hi = att_hi; c.a_lo = att_lo; c.out = x;
     cgo(c);
-    if (fuse_cq) {  // the cross-attention workgroups project their own queries (decode_attention_kernel<true>)
+    if (fuse_cq && d <= 1024) {  // the cross-attention workgroups project their own queries (decode_attention_kernel<true>)
       DecAttnParams a = attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64);
       a.q = nullptr;
       a.x = x; a.ln_w = w.cross_ln_w; a.ln_b = w.cross_ln_b; a.wq = w.w_cq; a.bq = w.b_cq;
