@@ -105,10 +105,18 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     mel_demo = demo_mel(80)
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":  # only the cases added in round 2 (the others are unchanged)
+        run_case("small_demo", "small", 0, mel_demo, 6)
+        run_case("miniturbo_synth", "miniturbo", 21, synth_mel(9, 128, 2500), 8, language_idx=99)
+        return
     run_case("micro_demo", "micro", 11, mel_demo, 12)
     run_case("micro_synth", "micro", 12, synth_mel(5, 80, 3000), 12, language_idx=0)
     run_case("mini_synth", "mini", 13, synth_mel(6, 80, 1777), 10)
     run_case("tiny_demo", "tiny", 14, mel_demo, 8)
+    # round 2: the benchmark's own model (Whisper-small dims, the seed-0 weights bench.py runs: BASELINE configs[1], [2])
+    # and the turbo layout (128 mels, 100 languages, n_vocab 51866, enc_layers != dec_layers) at reduced width
+    run_case("small_demo", "small", 0, mel_demo, 6)
+    run_case("miniturbo_synth", "miniturbo", 21, synth_mel(9, 128, 2500), 8, language_idx=99)
 
 
 if __name__ == "__main__":

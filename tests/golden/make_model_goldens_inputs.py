@@ -23,4 +23,5 @@ def demo_mel(n_mels=80):
 
 def golden_mel(name):
     return {"micro_demo": lambda: demo_mel(80), "micro_synth": lambda: synth_mel(5, 80, 3000),
-            "mini_synth": lambda: synth_mel(6, 80, 1777), "tiny_demo": lambda: demo_mel(80)}[name]()
+            "mini_synth": lambda: synth_mel(6, 80, 1777), "tiny_demo": lambda: demo_mel(80),
+            "small_demo": lambda: demo_mel(80), "miniturbo_synth": lambda: synth_mel(9, 128, 2500)}[name]()

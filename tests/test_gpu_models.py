@@ -11,14 +11,18 @@ from conftest import GOLDEN, ModelCase, assert_ids_equal_or_tie, load_demo_pcm
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("model_type,golden,seed", [("mini", "mini_synth", 13), ("tiny", "tiny_demo", 14)])
+@pytest.mark.parametrize("model_type,golden,seed", [("mini", "mini_synth", 13), ("tiny", "tiny_demo", 14), ("small", "small_demo", 0),
+                                                    ("miniturbo", "miniturbo_synth", 21)])
 def test_model_vs_oracle_and_transformers(built_lib, oracle_mod, tmp_path, model_type, golden, seed):
     from make_model_goldens_inputs import golden_mel
 
     case = ModelCase(tmp_path, model_type, seed)
     g = np.load(os.path.join(GOLDEN, f"model_{golden}.npz"))
     mel = golden_mel(golden)
-    e = built_lib.Whisper(model_type, case.root, "zh", device=0)
+    codes, toks = case.cfg["all_language_codes"].split(","), [int(t) for t in case.cfg["all_language_tokens"].split(",")]
+    lang = codes[toks.index(int(g["sot_seq"][1]))]  # the language the golden was generated with (miniturbo: yue)
+    e = built_lib.Whisper(model_type, case.root, lang, device=0)
+    assert e.sot_seq == [int(x) for x in g["sot_seq"]]
     e.encode_mel(mel)
     k, v = e.get_cross_kv(0)
     kb, vb = case.oracle_bf16.encoder(mel)
@@ -32,7 +36,7 @@ def test_model_vs_oracle_and_transformers(built_lib, oracle_mod, tmp_path, model
     err = np.abs(top - g["top_vals"][: n_new + 1]).max()
     print(model_type, "logits err vs transformers golden", err)
     assert err < 6e-2
-    ids_o, lg_o = case.oracle_bf16.greedy(kb, vb, "zh", max_new=n_new, forced=hf_ids, want_logits=True)
+    ids_o, lg_o = case.oracle_bf16.greedy(kb, vb, lang, max_new=n_new, forced=hf_ids, want_logits=True)
     assert np.abs(logits[0] - lg_o).max() < 2.5e-2
     e.close()
 
