@@ -112,6 +112,30 @@ static void check_errors() {
   assert(t2);
 }
 
+static void check_rotation() {
+  // fewer clips than devices: consecutive calls start at consecutive devices (concurrent 1-clip requests spread out)
+  axw::DeviceGroup<FakeEngine> g;
+  for (int d = 0; d < 3; ++d) g.add(std::unique_ptr<FakeEngine>(new FakeEngine(d)));
+  std::vector<float> clip(4, 7.f);
+  const float* ptr = clip.data();
+  int len = 4, n = 0;
+  std::vector<int32_t> ids(448);
+  for (int call = 0; call < 7; ++call) g.run_tokens(&ptr, &len, 1, 0, 448, ids.data(), &n);
+  assert(g.at(0).calls.size() == 3 && g.at(1).calls.size() == 2 && g.at(2).calls.size() == 2);
+  // two clips on three devices: devices (1, 2) after seven 1-clip calls, then (0, 1)
+  const float* two[2] = {ptr, ptr};
+  int lens[2] = {4, 4}, ns[2];
+  std::vector<int32_t> ids2(2 * 448);
+  g.run_tokens(two, lens, 2, 0, 448, ids2.data(), ns);
+  assert(g.at(1).calls.size() == 3 && g.at(2).calls.size() == 3 && g.at(0).calls.size() == 3);
+  // a full batch always uses every device, block w on device w
+  const float* six[6] = {ptr, ptr, ptr, ptr, ptr, ptr};
+  int lens6[6] = {4, 4, 4, 4, 4, 4}, ns6[6];
+  std::vector<int32_t> ids6(6 * 448);
+  g.run_tokens(six, lens6, 6, 0, 448, ids6.data(), ns6);
+  for (int d = 0; d < 3; ++d) assert(g.at(d).calls.size() == 4 && g.at(d).calls.back().first == 2);
+}
+
 static void check_device_lists() {
   using axw::parse_device_list;
   assert((parse_device_list("all", 3) == std::vector<int>{0, 1, 2}));
@@ -129,6 +153,7 @@ int main() {
   for (int G : {1, 2, 3, 8})
     for (int B : {1, 2, 5, 8, 64, 65}) run_case(G, B, B % 2 ? 0 : 3);
   check_errors();
+  check_rotation();
   check_device_lists();
   printf("multi_device ok\n");
   return 0;

@@ -10,6 +10,7 @@
 // engine under plain g++ to check the sharding and the joining on a box without a GPU.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <exception>
 #include <memory>
@@ -79,9 +80,12 @@ class DeviceGroup {
   // serialised by its own mutex (a handle may be shared between threads), engines of different devices run concurrently.
   void run_tokens(const float* const* pcm, const int* n_samples, int batch, int max_new, int n_ctx, int32_t* ids, int* n_ids) {
     if (batch < 1) throw std::runtime_error("batch must be >= 1");
-    const int world = size() < batch ? size() : batch;
+    const int G = size(), world = G < batch ? G : batch;
+    // calls with fewer clips than devices start at a rotating device, so that concurrent small requests on one handle
+    // (a server thread pool calling AX_WHISPER_RunPCM) spread over the GPUs instead of queueing on the first engine
+    const unsigned first = world < G ? next_.fetch_add((unsigned)world) % (unsigned)G : 0u;
     run_sharded(batch, world, [&](int w, int lo, int hi) {
-      E& e = *engines_[w];
+      E& e = *engines_[(first + (unsigned)w) % (unsigned)G];
       std::lock_guard<std::mutex> lock(e.mutex());
       e.run_tokens(pcm + lo, nullptr, 0, n_samples + lo, hi - lo, max_new, ids + (size_t)lo * n_ctx, n_ids + lo);
     });
@@ -89,6 +93,7 @@ class DeviceGroup {
 
  private:
   std::vector<std::unique_ptr<E>> engines_;
+  std::atomic<unsigned> next_{0};
 };
 
 // "0,2,5" / "all" / "" -> device ordinals (all = 0..n_visible-1). Throws on a malformed list or an ordinal out of range.
