@@ -130,6 +130,30 @@ def test_wav_ingest_formats(built_lib, micro_case, tmp_path):
     p = str(tmp_path / "stereo.wav")
     _write_wav(p, st, fmt="int16")
     assert e.run(p) == e.run(mono)
+    # AIFF (the reference's AudioFile reads it as well, AudioFile.h:643-776): big-endian, COMM + SSND chunks
+    import aifc
+
+    for width in (2, 3):
+        p = str(tmp_path / f"mono_{width * 8}.aiff")
+        with aifc.open(p, "wb") as a:
+            a.setnchannels(1); a.setsampwidth(width); a.setframerate(16000)
+            v = np.round(q16 * (1 << (8 * width - 1))).astype(np.int64)
+            a.writeframes(b"".join(int(x).to_bytes(width, "big", signed=True) for x in v))
+        assert e.run(p) == want, width
+    p = str(tmp_path / "stereo.aiff")
+    with aifc.open(p, "wb") as a:
+        a.setnchannels(2); a.setsampwidth(2); a.setframerate(16000)
+        a.writeframes(np.round(st * 32768).clip(-32768, 32767).astype(">i2").tobytes())
+    assert e.run(p) == e.run(mono)
+    (tmp_path / "bad.aiff").write_bytes(b"FORM\x00\x00\x00\x04AIFF")
+    with pytest.raises(RuntimeError):
+        e.run(str(tmp_path / "bad.aiff"))
+    cli = os.path.join(os.path.dirname(built_lib.LIB_PATH), "whisper_cli")
+    import subprocess
+
+    r = subprocess.run([cli, "-w", str(tmp_path / "mono_16.aiff"), "-t", "micro", "-p", micro_case.root, "--language", "zh"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and f"Result: {want}" in r.stdout, r.stdout + r.stderr
     e.close()
 
 

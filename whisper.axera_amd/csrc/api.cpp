@@ -201,7 +201,7 @@ AX_WHISPER_API int AX_WHISPER_RunFile(AX_WHISPER_HANDLE handle, const char* wav_
   *result = nullptr;
   axw::WavData wav;
   std::string err;
-  if (!axw::load_wav(wav_file, wav, err)) {
+  if (!axw::load_audio_file(wav_file, wav, err)) {
     H(handle)->set_error("load wav failed: " + err);
     fprintf(stderr, "[ax_whisper] load wav failed: %s\n", err.c_str());
     return -1;

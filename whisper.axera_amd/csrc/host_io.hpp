@@ -5,10 +5,12 @@
 //   * a safetensors reader (mmap) for {type}.safetensors
 //   * {type}-tokens.txt: "<base64> <rank>" lines (cpp/src/Whisper.cpp:115-127) + base64 decode
 //     (cpp/src/base64.cpp:84-120), bounds-checked (fixes SURVEY B8)
-//   * a WAV reader with the reference's sample conventions (cpp/src/AudioFile.h:1241-1243:
-//     int16 -> /32768; ax_whisper_api.cpp:105-113: stereo -> (L+R)/2)
+//   * WAV and AIFF readers with the reference's sample conventions (cpp/src/AudioFile.h:1241-1243:
+//     int16 -> /32768; ax_whisper_api.cpp:105-113: stereo -> (L+R)/2; AIFF: AudioFile.h:643-776)
 #pragma once
 
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -296,6 +298,73 @@ inline bool load_wav(const std::string& path, WavData& out, std::string& err) {
   for (size_t i = 0; i < frames; ++i)
     out.mono[i] = (ch == 2) ? (sample(i, 0) + sample(i, 1)) / 2 : sample(i, 0);  // api.cpp:105-113
   return true;
+}
+
+// AIFF / AIFF-C (the reference's AudioFile reads both, cpp/src/AudioFile.h:643-776; RunFile hands it whatever the caller
+// names): FORM container, big-endian chunk sizes, COMM = channels / frames / bits / 80-bit extended sample rate, SSND =
+// offset + big-endian samples. Conventions as the reference: 8-bit signed / 128, 16-bit / 32768, 24-bit / 8388608, 32-bit
+// integer / INT32_MAX (AIFF) or IEEE float (AIFF-C), stereo averaged by the caller's rule (ax_whisper_api.cpp:105-113).
+inline bool load_aiff(const std::vector<uint8_t>& d, WavData& out, std::string& err) {
+  auto be16 = [&](size_t o) { return ((uint32_t)d[o] << 8) | d[o + 1]; };
+  auto be32 = [&](size_t o) { return (be16(o) << 16) | be16(o + 2); };
+  if (d.size() < 12 || memcmp(d.data(), "FORM", 4)) { err = "not a FORM/AIFF file"; return false; }
+  const bool aifc = !memcmp(d.data() + 8, "AIFC", 4);
+  if (!aifc && memcmp(d.data() + 8, "AIFF", 4)) { err = "not a FORM/AIFF file"; return false; }
+  size_t p = 12, comm = 0, ssnd = 0, ssnd_len = 0;
+  while (p + 8 <= d.size()) {
+    const uint32_t len = be32(p + 4);
+    if (!memcmp(d.data() + p, "COMM", 4) && p + 8 + 18 <= d.size()) comm = p;
+    else if (!memcmp(d.data() + p, "SSND", 4) && p + 16 <= d.size()) { ssnd = p; ssnd_len = len; }
+    p += 8 + (size_t)len + (len & 1);
+  }
+  if (!comm || !ssnd) { err = "AIFF file lacks a COMM or SSND chunk"; return false; }
+  const int ch = (int)be16(comm + 8), bits = (int)be16(comm + 14);
+  const size_t frames_decl = be32(comm + 10);
+  // sample rate: 80-bit IEEE 754 extended, big-endian (sign/exponent 16 bits, 64-bit mantissa with explicit integer bit)
+  const int expo = (int)(be16(comm + 16) & 0x7fff) - 16383;
+  uint64_t mant = ((uint64_t)be32(comm + 18) << 32) | be32(comm + 22);
+  const double rate = mant == 0 ? 0.0 : std::ldexp((double)mant, expo - 63);
+  if (ch < 1 || ch > 2) { err = "AIFF file is neither mono nor stereo"; return false; }
+  if (bits != 8 && bits != 16 && bits != 24 && bits != 32) { err = "unsupported bit depth"; return false; }
+  if (aifc) {  // only uncompressed AIFF-C: 'NONE' (big-endian integers) or 32-bit 'fl32' / 'FL32' floats
+    if (comm + 8 + 22 > d.size()) { err = "truncated AIFF-C COMM chunk"; return false; }
+    const uint8_t* ct = d.data() + comm + 26;
+    const bool none = !memcmp(ct, "NONE", 4), fl32 = !memcmp(ct, "fl32", 4) || !memcmp(ct, "FL32", 4);
+    if (!(none || (fl32 && bits == 32))) { err = "compressed AIFF-C is not supported"; return false; }
+    if (none && bits == 32) { /* integers */ } else if (fl32) { /* floats, below */ }
+  }
+  const bool is_float = aifc && bits == 32 && (!memcmp(d.data() + comm + 26, "fl32", 4) || !memcmp(d.data() + comm + 26, "FL32", 4));
+  const size_t offset = be32(ssnd + 8), start = ssnd + 16 + offset, bps = (size_t)bits / 8;
+  if (start > d.size()) { err = "AIFF sound data offset out of bounds"; return false; }
+  const size_t avail = std::min<size_t>(d.size() - start, ssnd_len >= 8 + offset ? ssnd_len - 8 - offset : 0);
+  const size_t frames = std::min(frames_decl, avail / (bps * ch));
+  out.sample_rate = (int)(rate + 0.5); out.channels = ch; out.mono.resize(frames);
+  auto sample = [&](size_t frame, int c) -> float {
+    const uint8_t* s = d.data() + start + (frame * ch + c) * bps;
+    if (bps == 1) return (float)(int8_t)s[0] / 128.f;
+    if (bps == 2) return (float)(int16_t)((s[0] << 8) | s[1]) / 32768.f;
+    if (bps == 3) { int32_t v = (s[0] << 16) | (s[1] << 8) | s[2]; if (v & 0x800000) v |= ~0xFFFFFF; return (float)v / 8388608.f; }
+    const uint32_t u = ((uint32_t)s[0] << 24) | ((uint32_t)s[1] << 16) | ((uint32_t)s[2] << 8) | s[3];
+    if (is_float) { float f; memcpy(&f, &u, 4); return f; }
+    return (float)(int32_t)u / 2147483647.f;
+  };
+  for (size_t i = 0; i < frames; ++i) out.mono[i] = (ch == 2) ? (sample(i, 0) + sample(i, 1)) / 2 : sample(i, 0);
+  return true;
+}
+
+// RIFF/WAVE or FORM/AIFF by the file's magic (AudioFile.h:450-501 decides the same way)
+inline bool load_audio_file(const std::string& path, WavData& out, std::string& err) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f.is_open()) { err = "cannot open " + path; return false; }
+  char magic[4] = {0, 0, 0, 0};
+  f.read(magic, 4);
+  f.close();
+  if (!memcmp(magic, "FORM", 4)) {
+    std::ifstream g(path, std::ios::binary);
+    std::vector<uint8_t> d((std::istreambuf_iterator<char>(g)), std::istreambuf_iterator<char>());
+    return load_aiff(d, out, err);
+  }
+  return load_wav(path, out, err);
 }
 
 }  // namespace axw

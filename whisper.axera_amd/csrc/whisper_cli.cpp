@@ -25,13 +25,29 @@ static void usage(const char* prog) {
           prog);
 }
 
-// frame count of a RIFF/WAVE file (the reference loads the file with AudioFile only to get
+// frame count of a RIFF/WAVE or FORM/AIFF file (the reference loads the file with AudioFile only to get
 // duration = n_samples / 16000, whisper_cli.cpp:68-76)
 static bool wav_frames(const char* path, long* frames) {
   FILE* f = fopen(path, "rb");
   if (!f) return false;
   unsigned char h[12];
-  if (fread(h, 1, 12, f) != 12 || memcmp(h, "RIFF", 4) || memcmp(h + 8, "WAVE", 4)) { fclose(f); return false; }
+  if (fread(h, 1, 12, f) != 12) { fclose(f); return false; }
+  if (!memcmp(h, "FORM", 4) && (!memcmp(h + 8, "AIFF", 4) || !memcmp(h + 8, "AIFC", 4))) {  // AIFF: frames from the COMM chunk
+    for (;;) {
+      unsigned char c[8];
+      if (fread(c, 1, 8, f) != 8) { fclose(f); return false; }
+      const unsigned len = ((unsigned)c[4] << 24) | (c[5] << 16) | (c[6] << 8) | c[7];
+      if (!memcmp(c, "COMM", 4)) {
+        unsigned char cm[6];
+        if (len < 18 || fread(cm, 1, 6, f) != 6) { fclose(f); return false; }
+        fclose(f);
+        *frames = (long)(((unsigned)cm[2] << 24) | (cm[3] << 16) | (cm[4] << 8) | cm[5]);
+        return true;
+      }
+      fseek(f, (long)(len + (len & 1)), SEEK_CUR);
+    }
+  }
+  if (memcmp(h, "RIFF", 4) || memcmp(h + 8, "WAVE", 4)) { fclose(f); return false; }
   int ch = 0, bits = 0;
   for (;;) {
     unsigned char c[8];
