@@ -38,7 +38,8 @@ typedef void* AX_WHISPER_HANDLE;
 AX_WHISPER_API AX_WHISPER_HANDLE AX_WHISPER_Init(const char* model_type, const char* model_path,
                                                  const char* language);
 AX_WHISPER_API void AX_WHISPER_Uninit(AX_WHISPER_HANDLE handle);
-/** 16 kHz WAV (int16/int24/int32/float32 PCM; stereo is averaged). 0 ok, -1 error. */
+/** 16 kHz WAV (int16/int24/int32/float32 PCM) or AIFF / uncompressed AIFF-C (the reference's AudioFile reads both,
+ *  AudioFile.h:450-501); stereo is averaged. 0 ok, -1 error. */
 AX_WHISPER_API int AX_WHISPER_RunFile(AX_WHISPER_HANDLE handle, const char* wav_file, char** result);
 /** 16 kHz mono f32 PCM in [-1, 1]. *result is malloc'd; caller frees. 0 ok, -1 error. */
 AX_WHISPER_API int AX_WHISPER_RunPCM(AX_WHISPER_HANDLE handle, float* pcm_data, int num_samples,
