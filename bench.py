@@ -499,6 +499,7 @@ def run_rank(args) -> int:
             out["cpu_baseline"] = cpu_baseline(args, dims, mdir, clips[0], ids[0], dec_steps, dtype)
 
     if use_dist:
+        barrier()  # rank 0 has run its roofline legs meanwhile: leave together
         dist.destroy_process_group()
     sys.stdout.flush()
     if saved_stdout is not None:
