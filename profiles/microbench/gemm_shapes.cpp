@@ -20,7 +20,7 @@ struct Shape { const char* name; int M, batch, N, K, epi; };
 
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 10;
-  gemm_force_tile = argc > 2 ? atoi(argv[2]) : 0;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256
+  gemm_force_tile = argc > 2 ? atoi(argv[2]) : 0;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 phased
   printf("tile selection %d\n", gemm_force_tile);
   const Shape shapes[] = {
       {"attn.out / cq  (N=768  K=768,  resid f32)", 1500, 64, 768, 768, EPI_RESID_F32},
@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
     for (auto& v : hW) v = f_to_bf16(U(rng) * 0.05f);
     std::vector<float> hb(sh.N);
     for (auto& v : hb) v = U(rng);
-    bf16 *dA, *dW; float* db; void* dC;
+    h16 *dA, *dW; float* db; void* dC;
     const bool f32out = sh.epi == EPI_RESID_F32;
     const size_t cbytes = (size_t)rows * sh.N * (f32out ? 4 : 2);
     CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dW, hW.size() * 2)); CK(hipMalloc(&db, sh.N * 4)); CK(hipMalloc(&dC, cbytes));

@@ -107,20 +107,21 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 #ifdef __HIPCC__
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2_t gelu_erf_fast2(f32x2_t x) {
+  // 0.5 x (1 + erf(x / sqrt 2)) = 0.5 x + |x| (0.5 - 0.5 poly(t) exp(-x^2 / 2)),  t = 1 / (1 + p |x| / sqrt 2): erf is odd, so
+  // the sign needs no copysign; 1/sqrt 2, the 0.5 and log2(e) are folded into the constants (17 instructions per pair)
   const f32x2_t ax = {fabsf(x[0]), fabsf(x[1])};
-  const f32x2_t z = ax * 0.70710678118654752440f;
-  const f32x2_t den = z * 0.3275911f + 1.f;
+  const f32x2_t den = ax * (0.3275911f * 0.70710678118654752440f) + 1.f;
   const f32x2_t t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-  f32x2_t poly = t * 1.061405429f + -1.453152027f;
-  poly = poly * t + 1.421413741f;
-  poly = poly * t + -0.284496736f;
-  poly = poly * t + 0.254829592f;
+  f32x2_t poly = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
+  poly = poly * t + (0.5f * 1.421413741f);
+  poly = poly * t + (0.5f * -0.284496736f);
+  poly = poly * t + (0.5f * 0.254829592f);
   poly = poly * t;
-  const f32x2_t mz2 = -z * z;
-  const f32x2_t ex = {__expf(mz2[0]), __expf(mz2[1])};
-  const f32x2_t e = 1.f - poly * ex;
-  const f32x2_t se = {copysignf(e[0], x[0]), copysignf(e[1], x[1])};
-  return (x * 0.5f) * (se + 1.f);
+  const f32x2_t u = ax * 0.84932180028801904272f;  // sqrt(0.5 log2 e): exp(-x^2 / 2) = exp2(-u^2)
+  const f32x2_t mu2 = -u * u;
+  const f32x2_t ex = {__builtin_amdgcn_exp2f(mu2[0]), __builtin_amdgcn_exp2f(mu2[1])};
+  const f32x2_t e = 0.5f - poly * ex;
+  return ax * e + x * 0.5f;
 }
 #endif
 

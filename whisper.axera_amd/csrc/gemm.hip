@@ -20,6 +20,8 @@
 // swapped so lanes run along M. Row-major outputs leave through LDS (gemm_epilogue): 16-byte row accesses.
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace axw {
 inline namespace AXW_NS {
 
@@ -29,6 +31,91 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KB per operand tile
 __device__ __forceinline__ int swz(int row, int chunk) { return row * (BK * 2) + 16 * (chunk ^ ((row >> 1) & 7)); }
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
+
+// Second half of the LDS epilogue: the wave's parked 64x64 fp32 sub-tile (lw[row * 64 + column], row = the output's
+// strided axis) leaves as whole rows. Shared by the 32x32 and the 16x16 accumulator layouts (they differ in the parking).
+template <int EPI, bool SWAPPED>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* lw, int mb, int nb, int bz, int lane) {
+  const int d = p.d_model;
+  // read back rows: lane -> row 4t + (lane>>4), columns 4*(lane&15) .. +3
+  const int rr = lane >> 4, cc = (lane & 15) * 4;
+  if constexpr (!SWAPPED) {  // rows = m, columns = n
+    const int n = nb + cc;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+    if constexpr (EPI == EPI_PARTIAL_F32) {
+      float* slab = p.part + (long)blockIdx.y * p.part_stride + (long)bz * p.M * p.N;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = 4 * t + rr, m = mb + row;
+        if (m < p.M) *reinterpret_cast<f32x4*>(slab + (long)m * p.N + n) = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc);
+      }
+    } else if constexpr (EPI == EPI_RESID_F32) {
+      f32x4 cur[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int m = min(mb + 4 * t + rr, p.M - 1);
+        cur[t] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = 4 * t + rr, m = mb + row;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc) + bias4 + cur[t];
+        if (m < p.M) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n) = v;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = 4 * t + rr, m = mb + row;
+        if (m >= p.M) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc) + bias4;
+        if constexpr (EPI == EPI_GELU_POS_F32) {
+          const f32x4 pos = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.N + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]) + pos[e];
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n) = v;
+        } else {
+          h16x4 o;
+          if constexpr (EPI == EPI_BIAS_GELU_BF16) {
+            const f32x2_t g0 = gelu_erf_fast2(f32x2_t{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2_t{v[2], v[3]});
+            o[0] = (h16)g0[0]; o[1] = (h16)g0[1]; o[2] = (h16)g1[0]; o[3] = (h16)g1[1];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (h16)v[e];
+          }
+          h16* dst;
+          if constexpr (EPI == EPI_QKV) {  // Q (n < d) or K (d <= n < 2d), both h16 [m][d]
+            dst = n < d ? reinterpret_cast<h16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * d + n
+                        : reinterpret_cast<h16*>(p.C2) + (long)bz * p.c2_batch_stride + (long)m * d + (n - d);
+          } else if constexpr (EPI == EPI_CROSS_KV) {  // V rows [n_layer*d, 2*n_layer*d): [l][slot][head][t_pad][64]
+            const int nv = n - p.n_layer * d;
+            const int l = nv / d, c = nv - l * d;
+            const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + (c >> 6);
+            dst = reinterpret_cast<h16*>(p.C2) + (slot * p.t_pad + m) * 64 + (c & 63);
+          } else {
+            dst = reinterpret_cast<h16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n;
+          }
+          *reinterpret_cast<h16x4*>(dst) = o;
+        }
+      }
+    }
+  } else {  // EPI_QKV swapped: rows = n (V^T [head][64][t_pad]: row c = n - 2d), columns = m (4 consecutive frames per lane)
+    static_assert(EPI == EPI_QKV, "swapped row epilogue: V^T only");
+    const int m = mb + cc;
+    if (m < p.M) {  // M % 4 == 0 (checked by launch_gemm)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = 4 * t + rr, n = nb + row;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc);
+        h16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (h16)(v[e] + bias);
+        *reinterpret_cast<h16x4*>(reinterpret_cast<h16*>(p.C3) + (long)bz * p.c3_batch_stride + (long)(n - 2 * d) * p.t_pad + m) = o;
+      }
+    }
+  }
+}
 
 // Epilogue of one wave's 64x64 sub-tile (2x2 accumulator tiles), shared by both tile shapes.
 //   normal:  acc[i][j][e] = C[m = mb + i*32 + row(e,h)][n = nb + j*32 + r]
@@ -81,84 +168,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&accw
           const int lane_ax = (SWAPPED ? i : j) * 32 + r;
           lw[reg_ax * 64 + lane_ax] = acc[i][j][e];
         }
-    // read back rows: lane -> row 4t + (lane>>4), columns 4*(lane&15) .. +3
-    const int rr = lane >> 4, cc = (lane & 15) * 4;
-    if constexpr (!SWAPPED) {  // rows = m, columns = n
-      const int n = nb + cc;
-      f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-      if constexpr (EPI == EPI_PARTIAL_F32) {
-        float* slab = p.part + (long)blockIdx.y * p.part_stride + (long)bz * p.M * p.N;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int row = 4 * t + rr, m = mb + row;
-          if (m < p.M) *reinterpret_cast<f32x4*>(slab + (long)m * p.N + n) = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc);
-        }
-      } else if constexpr (EPI == EPI_RESID_F32) {
-        f32x4 cur[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int m = min(mb + 4 * t + rr, p.M - 1);
-          cur[t] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n);
-        }
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int row = 4 * t + rr, m = mb + row;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc) + bias4 + cur[t];
-          if (m < p.M) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n) = v;
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int row = 4 * t + rr, m = mb + row;
-          if (m >= p.M) continue;
-          f32x4 v = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc) + bias4;
-          if constexpr (EPI == EPI_GELU_POS_F32) {
-            const f32x4 pos = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.N + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]) + pos[e];
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n) = v;
-          } else {
-            h16x4 o;
-            if constexpr (EPI == EPI_BIAS_GELU_BF16) {
-              const f32x2_t g0 = gelu_erf_fast2(f32x2_t{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2_t{v[2], v[3]});
-              o[0] = (h16)g0[0]; o[1] = (h16)g0[1]; o[2] = (h16)g1[0]; o[3] = (h16)g1[1];
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (h16)v[e];
-            }
-            h16* dst;
-            if constexpr (EPI == EPI_QKV) {  // Q (n < d) or K (d <= n < 2d), both h16 [m][d]
-              dst = n < d ? reinterpret_cast<h16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * d + n
-                          : reinterpret_cast<h16*>(p.C2) + (long)bz * p.c2_batch_stride + (long)m * d + (n - d);
-            } else if constexpr (EPI == EPI_CROSS_KV) {  // V rows [n_layer*d, 2*n_layer*d): [l][slot][head][t_pad][64]
-              const int nv = n - p.n_layer * d;
-              const int l = nv / d, c = nv - l * d;
-              const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + (c >> 6);
-              dst = reinterpret_cast<h16*>(p.C2) + (slot * p.t_pad + m) * 64 + (c & 63);
-            } else {
-              dst = reinterpret_cast<h16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n;
-            }
-            *reinterpret_cast<h16x4*>(dst) = o;
-          }
-        }
-      }
-    } else {  // EPI_QKV swapped: rows = n (V^T [head][64][t_pad]: row c = n - 2d), columns = m (4 consecutive frames per lane)
-      static_assert(EPI == EPI_QKV, "swapped row epilogue: V^T only");
-      const int m = mb + cc;
-      if (m < p.M) {  // M % 4 == 0 (checked by launch_gemm)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int row = 4 * t + rr, n = nb + row;
-          const float bias = p.bias ? p.bias[n] : 0.f;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc);
-          h16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (h16)(v[e] + bias);
-          *reinterpret_cast<h16x4*>(reinterpret_cast<h16*>(p.C3) + (long)bz * p.c3_batch_stride + (long)(n - 2 * d) * p.t_pad + m) = o;
-        }
-      }
-    }
+    epilogue_rows<EPI, SWAPPED>(p, lw, mb, nb, bz, lane);
   }
 }
 
@@ -490,7 +500,276 @@ __global__ __launch_bounds__(512) void gemm256sq_bf16_kernel(GemmParams p) {
   gemm_epilogue<EPI, SWAPPED, 4, 2>(p, acc, lw, m0 + wm * 128 + 64, n0 + wn * 64, bz, lane);
 }
 
-int gemm_force_tile = 0;  // 0: by tile count; 1: 128x128, 2: 256x128, 3: 256x256 (microbenchmarks)
+// ---------------------------------------------------------------------------- 256 x 256 tile, phased k-loop
+// The batched encoder's kernel (launches with at least one 256-square tile per CU and an even number of k-tiles).
+// Same tile, same 128x64 per wave and the same swizzled LDS rows as above; what changes is the k-loop (the "8-phase"
+// schedule of the CDNA4 guide, section 5): v_mfma_f32_16x16x32 instead of 32x32x16, a k-tile cut into FOUR phases of 16
+// MFMAs per wave (one 64x32 quadrant of the wave's sub-tile), every phase = [fragment reads + one 16 KB half-tile of
+// LDS-DMA prefetch] -> barrier -> [16 MFMAs] -> barrier, and the two wave groups (rows 0-127 / 128-255 of the tile:
+// one wave of each per SIMD) run ONE BARRIER APART, so a SIMD's matrix pipe always has one group's MFMA cluster while
+// the other group's reads and DMA issues run in its shadow. The LDS-DMA is never drained inside the loop: one counted
+// wait per k-tile (vmcnt(6) = three half-tiles stay in flight across the barriers).
+//
+// An operand's k-tile (256 rows x 64 k) is staged as two half-tiles of 128 rows, cut by what a PHASE reads, not by tile
+// half: A half h = rows {wr*128 + h*64 + 0..63}, W half h = rows {wc*64 + h*32 + 0..31} (wr, wc: wave row / column), so
+//   phase 1 reads W half 0 (4 ds_read_b128, kept for phase 4) then A half 0 (8)   -> quadrant (0,0)
+//   phase 2 reads W half 1 (4)                                                   -> quadrant (0,1)
+//   phase 3 reads A half 1 (8, over A half 0's registers)                        -> quadrant (1,1)
+//   phase 4 reads nothing                                                        -> quadrant (1,0)
+// and a half-tile's LDS is free for the k-tile after next as soon as its phase is over. Prefetch issue order, k-tile t:
+//   phase 1: A1(t+1)   phase 2: W0(t+2)   phase 3: A0(t+2)   phase 4: W1(t+2), then vmcnt(6): all of k-tile t+1 landed.
+// Hazards (guide, "read a staged buffer one phase AFTER the wait that retires it"):
+//   RAW  both groups' counted waits sit before the first barrier of phase 4; the first read of k-tile t+1 (group 0,
+//        phase 1) comes after the second barrier of phase 4, which group 1 reaches only past its own wait.
+//   WAR  W0 is re-staged one phase after its reads, which `lgkmcnt(8)` retires before phase 1's first barrier (the W
+//        reads are issued first); A0, W1, A1 are re-staged two phases after their reads (retired by the lgkmcnt(0)
+//        in front of that phase's MFMAs).
+constexpr int HALF_BYTES = 128 * BK * 2;    // 16 KB
+constexpr int KT4_BYTES = 4 * HALF_BYTES;   // one k-tile: A0 | A1 | W0 | W1
+
+template <int EPI, bool SWAPPED>
+__device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc)[2][4][2], float* lw, int mb, int nb, int bz, int lane) {
+  // 16x16 accumulator tiles of one 64-row half of the wave's sub-tile: acc[nj][it][jt][e] =
+  //   normal  C[m = mb + it*16 + fq*4 + e][n = nb + nj*32 + jt*16 + fr]
+  //   swapped C[m = mb + it*16 + fr][n = nb + nj*32 + jt*16 + fq*4 + e]            fr = lane & 15, fq = lane >> 4
+  const int fr = lane & 15, fq = lane >> 4;
+  const int d = p.d_model;
+  if constexpr (EPI == EPI_CROSS_KV && SWAPPED) {  // blocked K [l][slot][head][m/64][dd/8][m%64][8]: 8 contiguous bytes per lane
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int m = mb + it * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          const int n = nb + nj * 32 + jt * 16 + fq * 4;
+          const int l = n / d, c = n - l * d;
+          const int head = c >> 6, dd = c & 63;
+          h16x4 pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pk[e] = (h16)(acc[nj][it][jt][e] + (p.bias ? p.bias[n + e] : 0.f));
+          const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + head;
+          h16* dst = reinterpret_cast<h16*>(p.C) + slot * p.t_pad * 64 + (long)(m >> 6) * 4096 + (dd >> 3) * 512 + (m & 63) * 8 + (dd & 7);
+          *reinterpret_cast<h16x4*>(dst) = pk;
+        }
+    }
+  } else {
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int reg_ax = (SWAPPED ? nj * 32 + jt * 16 : it * 16) + fq * 4 + e;
+            const int lane_ax = (SWAPPED ? it * 16 : nj * 32 + jt * 16) + fr;
+            lw[reg_ax * 64 + lane_ax] = acc[nj][it][jt][e];
+          }
+    epilogue_rows<EPI, SWAPPED>(p, lw, mb, nb, bz, lane);
+  }
+}
+
+template <int EPI, bool SWAPPED>
+__global__ __launch_bounds__(512) void gemm256ph_bf16_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 k-tiles][A0 | A1 | W0 | W1]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  int n0, m0, bz;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+    const int nt = p.n_tiles, mt = (p.M + BM3 - 1) / BM3;
+    constexpr int G = 8;  // wide launches walk the columns in groups of 8 tiles (see gemm256sq_bf16_kernel)
+    int nl, rest;
+    if (nt <= G) {
+      nl = wg % nt;
+      rest = wg / nt;
+    } else {
+      const int panels = mt * p.batch, full = nt / G, in_full = full * G * panels;
+      if (wg < in_full) {
+        const int g = wg / (G * panels), within = wg % (G * panels);
+        rest = within / G;
+        nl = g * G + within % G;
+      } else {
+        const int gl = nt - full * G, w2 = wg - in_full;
+        rest = w2 / gl;
+        nl = full * G + w2 % gl;
+      }
+    }
+    n0 = p.n_begin + nl * BN3;
+    m0 = (rest % mt) * BM3;
+    bz = rest / mt;
+  }
+  const h16* A = p.A + (long)bz * p.a_batch_stride;
+  const h16* W = p.W;
+
+  // LDS-DMA sources: piece q of a half-tile = its rows q*64 + 8*wave + lane/8 (1 KiB per wave instruction, linear in
+  // LDS), chunk position lane%8 holding global chunk position ^ ((row>>1)&7) (swz(): the involution the reads apply)
+  const h16* a_src[2][2];
+  const h16* w_src[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int lr = q * 64 + 8 * wave + (lane >> 3);
+    const int gc = ((lane & 7) ^ ((lr >> 1) & 7)) * 8;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int arow = (lr >> 6) * 128 + hh * 64 + (lr & 63);
+      const int wrow = (lr >> 5) * 64 + hh * 32 + (lr & 31);
+      a_src[hh][q] = A + (long)min(m0 + arow, p.M - 1) * p.lda + gc;
+      w_src[hh][q] = W + (long)(n0 + wrow) * p.K + gc;
+    }
+  }
+  // which: 0 A0, 1 A1, 2 W0, 3 W1
+  auto stage = [&](auto WHICH, auto BUF, int kt) {
+    constexpr int which = decltype(WHICH)::value, buf = decltype(BUF)::value;
+    char* base = smem + buf * KT4_BYTES + which * HALF_BYTES + 8 * wave * (BK * 2);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const h16* src = (which < 2 ? a_src[which & 1][q] : w_src[which & 1][q]) + kt * BK;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(base + q * 64 * (BK * 2)), 16, 0, 0);
+    }
+  };
+  using I0_ = std::integral_constant<int, 0>;
+  using I1_ = std::integral_constant<int, 1>;
+  using I2_ = std::integral_constant<int, 2>;
+  using I3_ = std::integral_constant<int, 3>;
+
+  // fragment addresses: row-tile it (jt) adds 16 rows = 2048 B, k-step s flips chunk bit 2 (64 B); both fold into
+  // the ds_read's immediate offset or one XOR
+  const int swz_c = (fq ^ (fr >> 1)) * 16;
+  const int a_off = (wr * 64 + fr) * (BK * 2) + swz_c;
+  const int w_off = (wc * 32 + fr) * (BK * 2) + swz_c;
+
+  f32x4 acc[2][2][4][2];  // [mi][nj][it][jt]
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) acc[mi][nj][it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  h16x8 af[4][2], wf0[2][2], wf1[2][2];
+  auto read_a = [&](const char* half) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) af[it][s] = *reinterpret_cast<const h16x8*>(half + ((a_off + it * 2048) ^ (s * 64)));
+  };
+  auto read_w = [&](const char* half, h16x8 (&wf)[2][2]) {
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) wf[jt][s] = *reinterpret_cast<const h16x8*>(half + ((w_off + jt * 2048) ^ (s * 64)));
+  };
+  auto quadrant = [&](f32x4 (&c)[4][2], const h16x8 (&wf)[2][2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+          c[it][jt] = SWAPPED ? AXW_MFMA_16x16x32(wf[jt][s], af[it][s], c[it][jt]) : AXW_MFMA_16x16x32(af[it][s], wf[jt][s], c[it][jt]);
+  };
+#define AXW_PHASE_MFMA_BEGIN()                             \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  __builtin_amdgcn_s_barrier();                            \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  __builtin_amdgcn_s_setprio(1)
+#define AXW_PHASE_MFMA_END()                               \
+  __builtin_amdgcn_s_setprio(0);                           \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  __builtin_amdgcn_s_barrier();                            \
+  __builtin_amdgcn_sched_barrier(0)
+
+  // one k-tile out of LDS buffer BUF; NEXT1 / NEXT2: k-tiles kt+1 / kt+2 exist (their prefetches are issued here)
+  auto ktile = [&](auto BUF, auto NEXT1, auto NEXT2, int kt) {
+    constexpr int buf = decltype(BUF)::value;
+    constexpr bool next1 = decltype(NEXT1)::value != 0, next2 = decltype(NEXT2)::value != 0;
+    using OTHER = std::integral_constant<int, buf ^ 1>;
+    const char* base = smem + buf * KT4_BYTES;
+    // phase 1
+    read_w(base + 2 * HALF_BYTES, wf0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(base);
+    if constexpr (next1) stage(I1_{}, OTHER{}, kt + 1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    AXW_PHASE_MFMA_BEGIN();
+    quadrant(acc[0][0], wf0);
+    AXW_PHASE_MFMA_END();
+    // phase 2
+    read_w(base + 3 * HALF_BYTES, wf1);
+    if constexpr (next2) stage(I2_{}, BUF, kt + 2);
+    AXW_PHASE_MFMA_BEGIN();
+    quadrant(acc[0][1], wf1);
+    AXW_PHASE_MFMA_END();
+    // phase 3
+    read_a(base + HALF_BYTES);
+    if constexpr (next2) stage(I0_{}, BUF, kt + 2);
+    AXW_PHASE_MFMA_BEGIN();
+    quadrant(acc[1][1], wf1);
+    AXW_PHASE_MFMA_END();
+    // phase 4
+    if constexpr (next2) {
+      stage(I3_{}, BUF, kt + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if constexpr (next1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    AXW_PHASE_MFMA_BEGIN();
+    quadrant(acc[1][0], wf0);
+    AXW_PHASE_MFMA_END();
+  };
+
+  const int nk = p.K / BK;  // even, >= 4 (launch_one)
+  stage(I2_{}, I0_{}, 0);
+  stage(I0_{}, I0_{}, 0);
+  stage(I3_{}, I0_{}, 0);
+  stage(I1_{}, I0_{}, 0);
+  stage(I2_{}, I1_{}, 1);
+  stage(I0_{}, I1_{}, 1);
+  stage(I3_{}, I1_{}, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind the first from here on
+  __builtin_amdgcn_sched_barrier(0);
+  int kt = 0;
+  for (; kt + 2 < nk; kt += 2) {
+    ktile(I0_{}, I1_{}, I1_{}, kt);
+    ktile(I1_{}, I1_{}, I1_{}, kt + 1);
+  }
+  ktile(I0_{}, I1_{}, I0_{}, kt);
+  ktile(I1_{}, I0_{}, I0_{}, kt + 1);
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // back in step: every wave is done with the staging buffers
+  __builtin_amdgcn_sched_barrier(0);
+#undef AXW_PHASE_MFMA_BEGIN
+#undef AXW_PHASE_MFMA_END
+#ifdef AXW_GEMM_NO_EPILOGUE
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) asm volatile("" ::"v"(acc[mi][nj][it][jt]));
+  return;
+#endif
+  float* lw = reinterpret_cast<float*>(smem) + wave * 4096;  // the buffers now hold the parked sub-tiles, one 64-row half at a time
+  gemm_epilogue16<EPI, SWAPPED>(p, acc[0], lw, m0 + wr * 128, n0 + wc * 64, bz, lane);
+  gemm_epilogue16<EPI, SWAPPED>(p, acc[1], lw, m0 + wr * 128 + 64, n0 + wc * 64, bz, lane);
+}
+
+int gemm_force_tile = 0;  // 0: by tile count; 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 phased (microbenchmarks)
 
 template <int EPI, bool SW>
 static void launch_one(GemmParams p, int n_begin, int n_end, hipStream_t s) {
@@ -502,6 +781,12 @@ static void launch_one(GemmParams p, int n_begin, int n_end, hipStream_t s) {
     // one workgroup per CU: a launch runs in ceil(tiles / 256) rounds; the square tile is ~1.15x faster per flop
     auto fill = [](int tiles) { return (double)tiles / (double)((tiles + 255) / 256 * 256); };
     const bool sq_pays = tiles_sq >= 256 && 1.15 * fill(tiles_sq) >= fill(2 * tiles_sq);
+    const int nk = p.K / BK;
+    if ((gemm_force_tile == 4 || (gemm_force_tile == 0 && sq_pays)) && nk >= 4 && nk % 2 == 0) {
+      p.n_tiles = (n_end - n_begin) / BN3;
+      hipLaunchKernelGGL((gemm256ph_bf16_kernel<EPI, SW>), dim3(tiles_sq), dim3(512), 2 * KT4_BYTES, s, p);
+      return;
+    }
     if (gemm_force_tile == 3 || (gemm_force_tile == 0 && sq_pays)) {
       p.n_tiles = (n_end - n_begin) / BN3;
       hipLaunchKernelGGL((gemm256sq_bf16_kernel<EPI, SW>), dim3(tiles_sq), dim3(512), 2 * STAGE3_BYTES, s, p);
