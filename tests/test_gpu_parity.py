@@ -93,6 +93,42 @@ def test_encoder_vs_transformers_golden(engine):
     assert abs(np.abs(k).astype(np.float64).sum() / float(g["cross_k_abs"]) - 1) < 5e-3
 
 
+def test_encoder_attention_rescale_threshold(built_lib, micro_case, monkeypatch):
+    """encoder_attn.hip raises the running softmax maximum only when a tile's row maximum exceeds it by more than a
+    threshold (2^8 by default). The branch is data dependent, so: threshold 0 (rescale on every increase, the classic
+    online softmax), 0.5 (branch taken on some tiles, skipped on others) and the default must agree to rounding, on
+    inputs whose late frames are much louder than the early ones (the maximum keeps rising along the keys) and on the
+    reverse; every variant is also held against the bf16-policy oracle."""
+    from make_model_goldens_inputs import synth_mel
+
+    base = synth_mel(9, 80, 3000)
+    ramp = np.linspace(-1.5, 1.5, 3000, dtype=np.float32)[None, :]
+    mels = [base, np.clip(base * 0.2 + ramp, -1.5, 2.0).astype(np.float32), np.clip(base * 0.2 - ramp, -1.5, 2.0).astype(np.float32)]
+    outs = {}
+    for thr in ("0", "0.5", None):
+        if thr is None:
+            monkeypatch.delenv("AX_WHISPER_ENC_RESCALE_THR", raising=False)
+        else:
+            monkeypatch.setenv("AX_WHISPER_ENC_RESCALE_THR", thr)
+        e = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=3)
+        try:
+            e.encode_mel(np.stack(mels))
+            outs[thr] = [e.get_cross_kv(i) for i in range(3)]
+        finally:
+            e.close()
+    for i, mel in enumerate(mels):
+        kb, vb = micro_case.oracle_bf16.encoder(mel)
+        for thr, o in outs.items():
+            k, v = o[i]
+            err = max(np.abs(k - kb).max(), np.abs(v - vb).max())
+            print(f"mel {i} threshold {thr}: vs bf16-policy oracle {err:.3e}")
+            assert err < 3e-2
+        for thr in ("0.5", None):
+            dk = max(np.abs(outs[thr][i][0] - outs["0"][i][0]).max(), np.abs(outs[thr][i][1] - outs["0"][i][1]).max())
+            print(f"mel {i} threshold {thr} vs 0: {dk:.3e}")
+            assert dk < 2e-2  # h16 roundings of P at a different scale, a few ulps of the outputs
+
+
 # ------------------------------------------------------------------ decoder
 def test_decoder_teacher_forced_logits(engine, micro_case):
     mels = _mels()

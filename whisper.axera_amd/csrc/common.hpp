@@ -166,9 +166,11 @@ void launch_gemm(const GemmParams& p, hipStream_t s);
 void launch_layernorm_bf16(float* x, const float* g, const float* b, h16* y, long rows, int d, hipStream_t s,
                            const float* part = nullptr, int n_part = 0, long part_stride = 0, const float* part_bias = nullptr);
 
-// encoder self-attention (non-causal, T keys), Q/K h16 [B][T][d], V^T h16 [B][H][64][Tp] -> O h16 [B][T][d]
+// encoder self-attention (non-causal, T keys), Q/K h16 [B][T][d], V^T h16 [B][H][64][Tp] (frames of every 16-group in
+// the order [0-3, 8-11, 4-7, 12-15], as EPI_QKV writes them) -> O h16 [B][T][d]. rescale_thr: how far (log2 units) a
+// tile's row maximum may exceed the running one before the accumulators are rescaled; 0 = on every increase.
 void launch_encoder_attention(const h16* q, const h16* k, const h16* vt, h16* o, int batch, int T, int t_pad,
-                              int d_model, int n_head, hipStream_t s);
+                              int d_model, int n_head, hipStream_t s, float rescale_thr = 8.f);
 
 // ------------------------------------------------------------------ front-end
 struct FrontendParams {

@@ -12,8 +12,11 @@
 //     row max / row sum are per-lane reductions plus one lane^32 exchange;
 //   the exponentiated accumulator registers, narrowed pairwise to h16, ARE the B operand of
 //   O^T = V^T P^T with no lane movement (cdna guide §3, accumulator-as-operand); the A operand
-//   is read from the V^T tile with the matching permuted key order (two 8-byte reads).
-//   V^T comes for free from the QKV GEMM's swapped-operand epilogue (gemm.hip).
+//   wants the keys of a 16-group in the matching order {0-3, 8-11 | 4-7, 12-15}, which is the order the QKV GEMM's
+//   swapped-operand epilogue stores the frames of V^T in (gemm.hip): one 16-byte read per fragment.
+//   The running maximum is only raised when some row's tile maximum exceeds it by more than `rescale_thr` (log2 units):
+//   until then exp2 of a score may reach 2^thr instead of 1, which fp32 sums and h16 probabilities absorb, and the 32
+//   accumulator multiplies per tile drop out of every tile but the first few (cdna guide T13).
 // LDS: K tile [64 keys][64 d] + V^T tile [64 d][64 keys], h16, XOR-swizzled 16-byte chunks.
 // Work per (clip, layer): 4*T^2*64*H flops = 6.9 GFLOP (small); HBM: Q,K,V read once per
 // 128-row block (K,V stay in ONE L2 across the 12 blocks of a head: XCD-aware block order), O written once.
@@ -27,7 +30,7 @@ __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + 1
 
 __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const h16* __restrict__ Q, const h16* __restrict__ K,
                                                                 const h16* __restrict__ VT, h16* __restrict__ O, int T,
-                                                                int t_pad, int d_model, int n_head) {
+                                                                int t_pad, int d_model, int n_head, float rescale_thr) {
   __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
   __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
 
@@ -122,10 +125,18 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const h16* __
         mt = fmaxf(mt, sacc[kb][e]);
       }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);  // raw-score units; every tile has at least one unmasked key
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
-    m_run = m_new;
-    const float m_sc = m_new * sc;
+    // raise the running maximum (raw-score units; every tile has at least one unmasked key) only if some row needs it
+    if (__builtin_amdgcn_ballot_w64((mt - m_run) * sc > rescale_thr) != 0) {
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+    }
+    const float m_sc = m_run * sc;
     float ls = 0.f;
     h16x8 pf[2][2];
 #pragma unroll
@@ -136,28 +147,19 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const h16* __
         ls += pv;
         pf[kb][e >> 3][e & 7] = (h16)pv;
       }
-    l_run = l_run * alpha + ls;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+    l_run += ls;
 
-    // ---- O^T += V^T P^T : A element j of lane half h = V^T[d][key = kb*32 + 16*s2 + 8*(j>>2) + 4h + (j&3)]
+    // ---- O^T += V^T P^T : A element j of lane half h = V^T[d][key = kb*32 + 16*s2 + 8*(j>>2) + 4h + (j&3)] = the
+    // 8 h16 at positions 8h .. 8h+7 of that 16-group in the stored frame order
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const int row = db * 32 + r, c0 = 4 * kb + 2 * s2;
-          h16x4 lo = *reinterpret_cast<const h16x4*>(Vs + swz128(row, c0) + 8 * h);
-          h16x4 hi = *reinterpret_cast<const h16x4*>(Vs + swz128(row, c0 + 1) + 8 * h);
-          h16x8 vf;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+          const h16x8 vf = *reinterpret_cast<const h16x8*>(Vs + swz128(db * 32 + r, 4 * kb + 2 * s2 + h));
           oacc[db] = AXW_MFMA_32x32x16(vf, pf[kb][s2], oacc[db]);
         }
-
   };
   // Peeled so the staging registers are assigned unconditionally inside the loop (a conditional prefetch makes
   // hipcc keep them in scratch memory and serialise every load).
@@ -187,9 +189,9 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const h16* __
 }
 
 void launch_encoder_attention(const h16* q, const h16* k, const h16* vt, h16* o, int batch, int T, int t_pad, int d_model,
-                              int n_head, hipStream_t s) {
+                              int n_head, hipStream_t s, float rescale_thr) {
   dim3 grid(((T + 127) / 128) * n_head * batch);
-  hipLaunchKernelGGL(encoder_attention_kernel, grid, dim3(256), 0, s, q, k, vt, o, T, t_pad, d_model, n_head);
+  hipLaunchKernelGGL(encoder_attention_kernel, grid, dim3(256), 0, s, q, k, vt, o, T, t_pad, d_model, n_head, rescale_thr);
 }
 
 }  // inline namespace AXW_NS

@@ -117,6 +117,8 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
   {
     const char* e = getenv("AX_WHISPER_ENC_SPLITK");
     enc_split_k_ = !(e && e[0] == '0');
+    // encoder attention: rescale threshold of the running softmax maximum (tests run 0 = rescale on every increase)
+    if (const char* t = getenv("AX_WHISPER_ENC_RESCALE_THR")) enc_rescale_thr_ = std::max(0.f, std::min(16.f, (float)atof(t)));
   }
   cfg_.ints["t2s"] = t2s_ ? 1 : 0;
   cfg_.ints["fp16"] = AXW_F16;  // 16-bit storage / MFMA operand type of this engine: 0 bfloat16, 1 IEEE half
@@ -645,7 +647,7 @@ void Engine::run_encoder(int batch) {
     } else {
       launch_gemm(q, s);
     }
-    launch_encoder_attention(d_q_, d_k_, d_vt_, d_attn_, batch, T, t_pad_, d, H, s);
+    launch_encoder_attention(d_q_, d_k_, d_vt_, d_attn_, batch, T, t_pad_, d, H, s, enc_rescale_thr_);
     resid(d_attn_, d, e.w_o, e.b_o);
     layernorm(e.ln2_w, e.ln2_b);
     linear(d_ln_, d, e.w_fc1, e.b_fc1, d_ffn_, 4 * d, EPI_BIAS_GELU_BF16);

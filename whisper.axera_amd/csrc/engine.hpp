@@ -117,6 +117,7 @@ class Engine final : public IEngine {
   static constexpr int kEncPartClips = 2;  // split-K of the encoder's residual GEMMs pays for at most this many clips
   float* d_enc_part_ = nullptr;
   bool enc_split_k_ = true;
+  float enc_rescale_thr_ = 8.f;  // launch_encoder_attention
   h16 *d_cross_k_ = nullptr, *d_cross_v_ = nullptr, *d_self_k_ = nullptr, *d_self_v_ = nullptr;
   float *d_xdec_ = nullptr, *d_qdec_ = nullptr, *d_hid_ = nullptr, *d_part_self_ = nullptr, *d_part_cross_ = nullptr;
   h16 *d_act_[2] = {nullptr, nullptr}, *d_att_[2] = {nullptr, nullptr}, *d_hidp_[2] = {nullptr, nullptr};

@@ -111,7 +111,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
         h16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (h16)(v[e] + bias);
-        *reinterpret_cast<h16x4*>(reinterpret_cast<h16*>(p.C3) + (long)bz * p.c3_batch_stride + (long)(n - 2 * d) * p.t_pad + m) = o;
+        // frames of a 16-group are stored in the order [0-3, 8-11, 4-7, 12-15]: a lane of the attention kernel then
+        // finds the 8 keys of its P^T operand fragment in ONE 16-byte chunk (encoder_attn.hip)
+        const int mp = (m & ~15) | ((m & 4) << 1) | ((m & 8) >> 1);
+        *reinterpret_cast<h16x4*>(reinterpret_cast<h16*>(p.C3) + (long)bz * p.c3_batch_stride + (long)(n - 2 * d) * p.t_pad + mp) = o;
       }
     }
   }
