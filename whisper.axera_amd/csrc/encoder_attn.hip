@@ -17,7 +17,7 @@
 //   The running maximum is only raised when some row's tile maximum exceeds it by more than `rescale_thr` (log2 units):
 //   until then exp2 of a score may reach 2^thr instead of 1, which fp32 sums and h16 probabilities absorb, and the 32
 //   accumulator multiplies per tile drop out of every tile but the first few (cdna guide T13).
-// LDS: K tile [64 keys][64 d] + V^T tile [64 d][64 keys], h16, XOR-swizzled 16-byte chunks.
+// LDS: two buffers of K tile [64 keys][64 d] + V^T tile [64 d][64 keys], h16, XOR-swizzled 16-byte chunks; one barrier per tile.
 // Work per (clip, layer): 4*T^2*64*H flops = 6.9 GFLOP (small); HBM: Q,K,V read once per
 // 128-row block (K,V stay in ONE L2 across the 12 blocks of a head: XCD-aware block order), O written once.
 #include "common.hpp"
@@ -31,8 +31,7 @@ __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + 1
 __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const h16* __restrict__ Q, const h16* __restrict__ K,
                                                                 const h16* __restrict__ VT, h16* __restrict__ O, int T,
                                                                 int t_pad, int d_model, int n_head, float rescale_thr) {
-  __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
-  __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
+  __shared__ __attribute__((aligned(16))) char KVs[2][2][64 * 128];  // [buffer][K | V^T]: tile t+1 is stored while tile t is read
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -80,16 +79,16 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const h16* __
       rv[i] = *reinterpret_cast<const u32x4*>(Vb + (long)(ld_row + 32 * i) * t_pad + kt * 64 + ld_c * 8);
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<u32x4*>(Ks + swz128(ld_row + 32 * i, ld_c)) = rk[i];
-      *reinterpret_cast<u32x4*>(Vs + swz128(ld_row + 32 * i, ld_c)) = rv[i];
+      *reinterpret_cast<u32x4*>(KVs[buf][0] + swz128(ld_row + 32 * i, ld_c)) = rk[i];
+      *reinterpret_cast<u32x4*>(KVs[buf][1] + swz128(ld_row + 32 * i, ld_c)) = rv[i];
     }
   };
 
   load_tile(0);
-  store_tile();
+  store_tile(0);
   __syncthreads();
 
   const float sc = 0.125f * 1.44269504088896340736f;  // (64^-0.25)^2 * log2(e)
@@ -100,6 +99,8 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const h16* __
   // kept in raw-score units (sc > 0).
   auto process_tile = [&](int kt, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
+    const char* Ks = KVs[kt & 1][0];
+    const char* Vs = KVs[kt & 1][1];
     // ---- S^T = K Q^T : sacc[kb][e] = score(key = kt*64 + kb*32 + (e&3) + 8*(e>>2) + 4h, query = lane r)
     f32x16 sacc[2];
 #pragma unroll
@@ -166,8 +167,7 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const h16* __
   for (int kt = 0; kt + 1 < nkt; ++kt) {
     load_tile(kt + 1);
     process_tile(kt, std::false_type{});
-    __syncthreads();
-    store_tile();
+    store_tile((kt + 1) & 1);  // the buffer tile kt-1 was read from: every wave is past the barrier that ended iteration kt-1
     __syncthreads();
   }
   process_tile(nkt - 1, std::true_type{});  // t_pad - T < 64: only the last tile holds padded keys
