@@ -3,4 +3,4 @@
 set -e
 cd profiles/microbench
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../whisper.axera_amd/csrc gemm_shapes.cpp -o /tmp/gemm_shapes
-for r in 1 2; do for t in 3 4; do timeout -k 10 120 /tmp/gemm_shapes 20 $t; done; done
+for r in 1 2; do for t in ${TILES:-3 4}; do timeout -k 10 120 /tmp/gemm_shapes 20 $t; done; done

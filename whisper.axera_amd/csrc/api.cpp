@@ -270,6 +270,16 @@ AX_WHISPER_API int AX_WHISPER_GetConfigInt(AX_WHISPER_HANDLE handle, const char*
   Handle* h = H(handle);
   if (!h || !key || h->group.size() == 0) return INT_MIN;
   if (!strcmp(key, "n_devices")) return h->group.size();
+  if (!strcmp(key, "persistent_giveups")) {  // a count: summed over the handle's engines
+    long sum = 0;
+    for (int i = 0; i < h->group.size(); ++i) {
+      Engine& e = h->group.at(i);
+      std::lock_guard<std::mutex> lock(e.mutex());
+      auto it = e.config().ints.find(key);
+      if (it != e.config().ints.end()) sum += it->second;
+    }
+    return (int)sum;
+  }
   Engine& e = h->group.primary();
   std::lock_guard<std::mutex> lock(e.mutex());  // a few values change while the engine runs (persistent_decode, ...)
   auto& m = e.config().ints;

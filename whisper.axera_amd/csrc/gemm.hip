@@ -20,6 +20,7 @@
 // swapped so lanes run along M. Row-major outputs leave through LDS (gemm_epilogue): 16-byte row accesses.
 #include "common.hpp"
 
+#include <atomic>
 #include <type_traits>
 
 namespace axw {
@@ -34,7 +35,8 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 
 // Second half of the LDS epilogue: the wave's parked 64x64 fp32 sub-tile (lw[row * 64 + column], row = the output's
 // strided axis) leaves as whole rows. Shared by the 32x32 and the 16x16 accumulator layouts (they differ in the parking).
-template <int EPI, bool SWAPPED>
+// NT = row steps of 4 rows: 16 for a 64-row sub-tile, 4 for the 16-row slabs of the persistent kernel.
+template <int EPI, bool SWAPPED, int NT = 16>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* lw, int mb, int nb, int bz, int lane) {
   const int d = p.d_model;
   // read back rows: lane -> row 4t + (lane>>4), columns 4*(lane&15) .. +3
@@ -46,75 +48,102 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
     if constexpr (EPI == EPI_PARTIAL_F32) {
       float* slab = p.part + (long)blockIdx.y * p.part_stride + (long)bz * p.M * p.N;
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int row = 4 * t + rr, m = mb + row;
         if (m < p.M) *reinterpret_cast<f32x4*>(slab + (long)m * p.N + n) = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc);
       }
     } else if constexpr (EPI == EPI_RESID_F32) {
-      f32x4 cur[16];
+      f32x4 cur[NT];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int m = min(mb + 4 * t + rr, p.M - 1);
         cur[t] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n);
       }
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int row = 4 * t + rr, m = mb + row;
         const f32x4 v = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc) + bias4 + cur[t];
         if (m < p.M) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n) = v;
       }
-    } else {
+    } else if constexpr (EPI == EPI_GELU_POS_F32) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int row = 4 * t + rr, m = mb + row;
         if (m >= p.M) continue;
         f32x4 v = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc) + bias4;
-        if constexpr (EPI == EPI_GELU_POS_F32) {
-          const f32x4 pos = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.N + n);
+        const f32x4 pos = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.N + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]) + pos[e];
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n) = v;
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]) + pos[e];
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n) = v;
+      }
+    } else {
+      // h16 outputs: lane -> row 8t + (lane>>3), 8 consecutive columns = one 16-byte store (a wave instruction writes
+      // 8 whole 128-byte row segments; with 8-byte stores the epilogue's tail is bound by store issue, guide T21)
+      const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+      const int n8 = nb + c8;
+      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+        b0 = *reinterpret_cast<const f32x4*>(p.bias + n8);
+        b1 = *reinterpret_cast<const f32x4*>(p.bias + n8 + 4);
+      }
+#pragma unroll
+      for (int t = 0; t < NT / 2; ++t) {
+        const int row = 8 * t + r8, m = mb + row;
+        if (m >= p.M) continue;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(lw + row * 64 + c8) + b0;
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(lw + row * 64 + c8 + 4) + b1;
+        h16x8 o;
+        if constexpr (EPI == EPI_BIAS_GELU_BF16) {
+          const f32x2_t g0 = gelu_erf_fast2(f32x2_t{v0[0], v0[1]}), g1 = gelu_erf_fast2(f32x2_t{v0[2], v0[3]});
+          const f32x2_t g2 = gelu_erf_fast2(f32x2_t{v1[0], v1[1]}), g3 = gelu_erf_fast2(f32x2_t{v1[2], v1[3]});
+          o[0] = (h16)g0[0]; o[1] = (h16)g0[1]; o[2] = (h16)g1[0]; o[3] = (h16)g1[1];
+          o[4] = (h16)g2[0]; o[5] = (h16)g2[1]; o[6] = (h16)g3[0]; o[7] = (h16)g3[1];
         } else {
-          h16x4 o;
-          if constexpr (EPI == EPI_BIAS_GELU_BF16) {
-            const f32x2_t g0 = gelu_erf_fast2(f32x2_t{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2_t{v[2], v[3]});
-            o[0] = (h16)g0[0]; o[1] = (h16)g0[1]; o[2] = (h16)g1[0]; o[3] = (h16)g1[1];
-          } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (h16)v[e];
-          }
-          h16* dst;
-          if constexpr (EPI == EPI_QKV) {  // Q (n < d) or K (d <= n < 2d), both h16 [m][d]
-            dst = n < d ? reinterpret_cast<h16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * d + n
-                        : reinterpret_cast<h16*>(p.C2) + (long)bz * p.c2_batch_stride + (long)m * d + (n - d);
-          } else if constexpr (EPI == EPI_CROSS_KV) {  // V rows [n_layer*d, 2*n_layer*d): [l][slot][head][t_pad][64]
-            const int nv = n - p.n_layer * d;
-            const int l = nv / d, c = nv - l * d;
-            const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + (c >> 6);
-            dst = reinterpret_cast<h16*>(p.C2) + (slot * p.t_pad + m) * 64 + (c & 63);
-          } else {
-            dst = reinterpret_cast<h16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n;
-          }
-          *reinterpret_cast<h16x4*>(dst) = o;
+          for (int e = 0; e < 4; ++e) { o[e] = (h16)v0[e]; o[4 + e] = (h16)v1[e]; }
         }
+        h16* dst;
+        if constexpr (EPI == EPI_QKV) {  // Q (n < d) or K (d <= n < 2d), both h16 [m][d]
+          dst = n8 < d ? reinterpret_cast<h16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * d + n8
+                       : reinterpret_cast<h16*>(p.C2) + (long)bz * p.c2_batch_stride + (long)m * d + (n8 - d);
+        } else if constexpr (EPI == EPI_CROSS_KV) {  // V rows [n_layer*d, 2*n_layer*d): [l][slot][head][t_pad][64]
+          const int nv = n8 - p.n_layer * d;
+          const int l = nv / d, c = nv - l * d;
+          const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + (c >> 6);
+          dst = reinterpret_cast<h16*>(p.C2) + (slot * p.t_pad + m) * 64 + (c & 63);
+        } else {
+          dst = reinterpret_cast<h16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n8;
+        }
+        *reinterpret_cast<h16x8*>(dst) = o;
       }
     }
-  } else {  // EPI_QKV swapped: rows = n (V^T [head][64][t_pad]: row c = n - 2d), columns = m (4 consecutive frames per lane)
+  } else {  // EPI_QKV swapped: rows = n (V^T [head][64][t_pad]: row c = n - 2d), columns = m
     static_assert(EPI == EPI_QKV, "swapped row epilogue: V^T only");
-    const int m = mb + cc;
-    if (m < p.M) {  // M % 4 == 0 (checked by launch_gemm)
+    // The frames of a 16-group are stored in the order [0-3, 8-11, 4-7, 12-15]: a lane of the attention kernel then finds
+    // the 8 keys of its P^T operand fragment in ONE 16-byte chunk (encoder_attn.hip). A lane here takes such a chunk:
+    // frames mA..mA+3 and mA+8..mA+11 of its 16-group -> positions 8*hs .. 8*hs+7 (M % 4 == 0, checked by launch_gemm;
+    // mb % 16 == 0); a group of frames at or beyond M is not written (the padding stays zero).
+    const int r8 = lane >> 3, g16 = ((lane & 7) >> 1) * 16, hs = lane & 1;
+    const int cA = g16 + hs * 4, mA = mb + cA;
+    if (mA < p.M) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int row = 4 * t + rr, n = nb + row;
+      for (int t = 0; t < NT / 2; ++t) {
+        const int row = 8 * t + r8, n = nb + row;
         const float bias = p.bias ? p.bias[n] : 0.f;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(lw + row * 64 + cc);
-        h16x4 o;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(lw + row * 64 + cA);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(lw + row * 64 + cA + 8);
+        h16x8 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (h16)(v[e] + bias);
-        // frames of a 16-group are stored in the order [0-3, 8-11, 4-7, 12-15]: a lane of the attention kernel then
-        // finds the 8 keys of its P^T operand fragment in ONE 16-byte chunk (encoder_attn.hip)
-        const int mp = (m & ~15) | ((m & 4) << 1) | ((m & 8) >> 1);
-        *reinterpret_cast<h16x4*>(reinterpret_cast<h16*>(p.C3) + (long)bz * p.c3_batch_stride + (long)(n - 2 * d) * p.t_pad + mp) = o;
+        for (int e = 0; e < 4; ++e) { o[e] = (h16)(v0[e] + bias); o[4 + e] = (h16)(v1[e] + bias); }
+        h16* dst = reinterpret_cast<h16*>(p.C3) + (long)bz * p.c3_batch_stride + (long)(n - 2 * d) * p.t_pad + mb + g16 + hs * 8;
+        if (mA + 8 < p.M) {
+          *reinterpret_cast<h16x8*>(dst) = o;
+        } else {
+          h16x4 lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lo[e] = o[e];
+          *reinterpret_cast<h16x4*>(dst) = lo;
+        }
       }
     }
   }
@@ -772,7 +801,295 @@ __global__ __launch_bounds__(512) void gemm256ph_bf16_kernel(GemmParams p) {
   gemm_epilogue16<EPI, SWAPPED>(p, acc[1], lw, m0 + wr * 128 + 64, n0 + wc * 64, bz, lane);
 }
 
-int gemm_force_tile = 0;  // 0: by tile count; 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 phased (microbenchmarks)
+// ---------------------------------------------------------------------------- 256 x 256 tiles, one k-tile STREAM per CU
+// gemm256ph_bf16_kernel's k-loop, but a workgroup per CU that walks its share of the tiles, so that the LDS-DMA
+// pipeline never drains at a tile boundary: the last two k-tiles of a tile prefetch the first two of the NEXT tile
+// exactly where the steady state would prefetch k-tiles t+1 / t+2, and the epilogue runs with three half-tiles in
+// flight instead of being followed by a cold prologue (first loads of a 256-row A panel from HBM: 2-3 us of a ~30 us
+// tile at K = 768). For that the epilogue may not touch the two staging buffers: every wave parks 16-row slabs
+// (4 KB) in its own piece of the 32 KB that 160 KB of LDS leave beside them, 8 slabs per wave instead of 2 halves.
+// The two wave groups fall back in step before the epilogue (otherwise each group's epilogue would wait for the
+// other's at the phase barriers) and part again behind it.
+// Tile order: XCD x (workgroups with blockIdx % 8 == x) owns a contiguous chunk of the tile space and its 32
+// workgroups take 32 consecutive tiles of it per round: the same L2 sharing as the one-tile-per-workgroup order.
+constexpr int SLAB_FLOATS = 16 * 64;
+
+template <int EPI, bool SWAPPED>
+__global__ __launch_bounds__(512) void gemm256ps_bf16_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 k-tiles][A0 | A1 | W0 | W1] | 8 slabs x 4 KB
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nt = p.n_tiles, mt = (p.M + BM3 - 1) / BM3;
+  const int tiles = nt * mt * p.batch;
+  // this workgroup's tiles: first, first + step, ... < last
+  int t_cur, t_last, t_step;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, j = orig >> 3;
+    const int q = tiles >> 3, r = tiles & 7;
+    const int start = xcd * q + min(xcd, r);
+    t_last = start + q + (xcd < r ? 1 : 0);
+    t_step = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);
+    t_cur = start + j;
+  }
+  if (t_cur >= t_last) return;  // (whole workgroup)
+
+  auto decode = [&](int wg, int& n0, int& m0, int& bz) {
+    constexpr int G = 8;  // wide launches walk the columns in groups of 8 tiles (see gemm256sq_bf16_kernel)
+    int nl, rest;
+    if (nt <= G) {
+      nl = wg % nt;
+      rest = wg / nt;
+    } else {
+      const int panels = mt * p.batch, full = nt / G, in_full = full * G * panels;
+      if (wg < in_full) {
+        const int g = wg / (G * panels), within = wg % (G * panels);
+        rest = within / G;
+        nl = g * G + within % G;
+      } else {
+        const int gl = nt - full * G, w2 = wg - in_full;
+        rest = w2 / gl;
+        nl = full * G + w2 % gl;
+      }
+    }
+    n0 = p.n_begin + nl * BN3;
+    m0 = (rest % mt) * BM3;
+    bz = rest / mt;
+  };
+  // LDS-DMA sources as byte offsets from A / W (launch_one keeps both operands under 4 GB for this kernel): piece q of
+  // a half-tile = its rows q*64 + 8*wave + lane/8, chunk position lane%8 holding global chunk position ^ ((row>>1)&7)
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Wb = reinterpret_cast<const char*>(p.W);
+  // (W rows are never clamped: their offsets are a per-lane constant plus the tile's n0 * K, kept as a scalar; A rows
+  // are clamped to M - 1, so their offsets are recomputed per tile)
+  auto offsets = [&](int m0, int bz, unsigned (&ao)[2][2]) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // recomputed per tile: hoisted out of the tile loop these terms cost registers in the k-loop
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int lr = q * 64 + 8 * wave + (ln >> 3);
+      const int gc = ((ln & 7) ^ ((lr >> 1) & 7)) * 8;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int arow = (lr >> 6) * 128 + hh * 64 + (lr & 63);
+        ao[hh][q] = (unsigned)(((long)bz * p.a_batch_stride + (long)min(m0 + arow, p.M - 1) * p.lda + gc) * 2);
+      }
+    }
+  };
+  unsigned wo[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int lr = q * 64 + 8 * wave + (lane >> 3);
+    const int gc = ((lane & 7) ^ ((lr >> 1) & 7)) * 8;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) wo[hh][q] = (unsigned)((((lr >> 5) * 64 + hh * 32 + (lr & 31)) * p.K + gc) * 2);
+  }
+  unsigned ao_cur[2][2], ao_nxt[2][2];
+  int n0, m0, bz;
+  decode(t_cur, n0, m0, bz);
+  offsets(m0, bz, ao_cur);
+  unsigned wn_cur = (unsigned)n0 * (unsigned)p.K * 2u, wn_nxt = 0;  // byte offset of W row n0
+
+  // which: 0 A0, 1 A1, 2 W0, 3 W1
+  auto stage = [&](auto WHICH, auto BUF, const unsigned (&ao)[2][2], unsigned wn, int kt) {
+    constexpr int which = decltype(WHICH)::value, buf = decltype(BUF)::value;
+    char* base = smem + buf * KT4_BYTES + which * HALF_BYTES + 8 * wave * (BK * 2);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      // uniform 64-bit base (scalar registers) + 32-bit per-lane offset: the saddr form of the load, no 64-bit VALU adds
+      const char* ub = which < 2 ? Ab + (long)kt * (BK * 2) : Wb + ((long)wn + (long)kt * (BK * 2));
+      unsigned off = which < 2 ? ao[which & 1][q] : wo[which & 1][q];
+      asm volatile("" : "+v"(off));  // keeps the resident per-lane values 32 bits wide (hipcc would hold base + offset as 64-bit pairs)
+      const char* src = ub + off;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(base + q * 64 * (BK * 2)), 16, 0, 0);
+    }
+  };
+  using I0_ = std::integral_constant<int, 0>;
+  using I1_ = std::integral_constant<int, 1>;
+  using I2_ = std::integral_constant<int, 2>;
+  using I3_ = std::integral_constant<int, 3>;
+
+  const int swz_c = ((lane >> 4) ^ ((lane & 15) >> 1)) * 16;
+  const int a_off = (wr * 64 + (lane & 15)) * (BK * 2) + swz_c;
+  const int w_off = (wc * 32 + (lane & 15)) * (BK * 2) + swz_c;
+
+  f32x4 acc[2][2][4][2];  // [mi][nj][it][jt]
+  h16x8 af[4][2], wf0[2][2], wf1[2][2];
+  auto read_a = [&](const char* half) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) af[it][s] = *reinterpret_cast<const h16x8*>(half + ((a_off + it * 2048) ^ (s * 64)));
+  };
+  auto read_w = [&](const char* half, h16x8 (&wf)[2][2]) {
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) wf[jt][s] = *reinterpret_cast<const h16x8*>(half + ((w_off + jt * 2048) ^ (s * 64)));
+  };
+  auto quadrant = [&](f32x4 (&c)[4][2], const h16x8 (&wf)[2][2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+          c[it][jt] = SWAPPED ? AXW_MFMA_16x16x32(wf[jt][s], af[it][s], c[it][jt]) : AXW_MFMA_16x16x32(af[it][s], wf[jt][s], c[it][jt]);
+  };
+#define AXW_PHASE_MFMA_BEGIN()                             \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  __builtin_amdgcn_s_barrier();                            \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  __builtin_amdgcn_s_setprio(1)
+#define AXW_PHASE_MFMA_END()                               \
+  __builtin_amdgcn_s_setprio(0);                           \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  __builtin_amdgcn_s_barrier();                            \
+  __builtin_amdgcn_sched_barrier(0)
+
+  // One k-tile out of LDS buffer BUF (phases and hazards: gemm256ph_bf16_kernel). ISSUE1: phase 1 prefetches A1 of the
+  // stream's next k-tile = (ao1, kt1); ISSUE2: phases 2-4 prefetch W0, A0, W1 of the one after = (ao2 / wo2, kt2).
+  auto ktile = [&](auto BUF, auto ISSUE1, auto ISSUE2, const unsigned (&ao1)[2][2], unsigned wo1, int kt1,
+                   const unsigned (&ao2)[2][2], unsigned wo2, int kt2) {
+    constexpr int buf = decltype(BUF)::value;
+    constexpr bool issue1 = decltype(ISSUE1)::value != 0, issue2 = decltype(ISSUE2)::value != 0;
+    using OTHER = std::integral_constant<int, buf ^ 1>;
+    const char* base = smem + buf * KT4_BYTES;
+    // phase 1
+    read_w(base + 2 * HALF_BYTES, wf0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(base);
+    if constexpr (issue1) stage(I1_{}, OTHER{}, ao1, wo1, kt1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    AXW_PHASE_MFMA_BEGIN();
+    quadrant(acc[0][0], wf0);
+    AXW_PHASE_MFMA_END();
+    // phase 2
+    read_w(base + 3 * HALF_BYTES, wf1);
+    if constexpr (issue2) stage(I2_{}, BUF, ao2, wo2, kt2);
+    AXW_PHASE_MFMA_BEGIN();
+    quadrant(acc[0][1], wf1);
+    AXW_PHASE_MFMA_END();
+    // phase 3
+    read_a(base + HALF_BYTES);
+    if constexpr (issue2) stage(I0_{}, BUF, ao2, wo2, kt2);
+    AXW_PHASE_MFMA_BEGIN();
+    quadrant(acc[1][1], wf1);
+    AXW_PHASE_MFMA_END();
+    // phase 4
+    if constexpr (issue2) {
+      stage(I3_{}, BUF, ao2, wo2, kt2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if constexpr (issue1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    AXW_PHASE_MFMA_BEGIN();
+    quadrant(acc[1][0], wf0);
+    AXW_PHASE_MFMA_END();
+  };
+
+  const int nk = p.K / BK;  // even, >= 4 (launch_one)
+  float* lw = reinterpret_cast<float*>(smem + 2 * KT4_BYTES) + wave * SLAB_FLOATS;
+
+  // the stream's first k-tile and three half-tiles of its second
+  stage(I2_{}, I0_{}, ao_cur, wn_cur, 0);
+  stage(I0_{}, I0_{}, ao_cur, wn_cur, 0);
+  stage(I3_{}, I0_{}, ao_cur, wn_cur, 0);
+  stage(I1_{}, I0_{}, ao_cur, wn_cur, 0);
+  stage(I2_{}, I1_{}, ao_cur, wn_cur, 1);
+  stage(I0_{}, I1_{}, ao_cur, wn_cur, 1);
+  stage(I3_{}, I1_{}, ao_cur, wn_cur, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (;;) {
+    const int t_nxt = t_cur + t_step;
+    const bool has_next = t_nxt < t_last;  // workgroup-uniform
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) acc[mi][nj][it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind the first inside a tile
+    __builtin_amdgcn_sched_barrier(0);
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {
+      ktile(I0_{}, I1_{}, I1_{}, ao_cur, wn_cur, kt + 1, ao_cur, wn_cur, kt + 2);
+      ktile(I1_{}, I1_{}, I1_{}, ao_cur, wn_cur, kt + 2, ao_cur, wn_cur, kt + 3);
+    }
+    // the last two k-tiles prefetch the next tile's first two; the last tile "prefetches" its own again (one code
+    // path; 112 KB of L2 reads per workgroup, drained at the end)
+    int n0n, m0n, bzn;
+    decode(has_next ? t_nxt : t_cur, n0n, m0n, bzn);
+    offsets(m0n, bzn, ao_nxt);
+    wn_nxt = (unsigned)n0n * (unsigned)p.K * 2u;
+    __builtin_amdgcn_sched_barrier(0);
+    ktile(I0_{}, I1_{}, I1_{}, ao_cur, wn_cur, kt + 1, ao_nxt, wn_nxt, 0);
+    ktile(I1_{}, I1_{}, I1_{}, ao_nxt, wn_nxt, 0, ao_nxt, wn_nxt, 1);
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // back in step for the epilogue
+    __builtin_amdgcn_sched_barrier(0);
+
+    // epilogue: 16-row slabs through this wave's 4 KB (the staging buffers belong to the next tile already)
+    const int mbw = m0 + wr * 128, nbw = n0 + wc * 64;
+    int le = lane;
+    asm volatile("" : "+v"(le));  // as in offsets(): the epilogue's per-lane terms are not worth registers in the k-loop
+    const int fr = le & 15, fq = le >> 4;
+    if constexpr (EPI == EPI_CROSS_KV && SWAPPED) {
+      gemm_epilogue16<EPI, SWAPPED>(p, acc[0], lw, mbw, nbw, bz, le);  // register path, no LDS
+      gemm_epilogue16<EPI, SWAPPED>(p, acc[1], lw, mbw + 64, nbw, bz, le);
+    } else if constexpr (!SWAPPED) {  // slab = 16 rows (m) x 64 columns (n): acc[mi][.][it][.]
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+#pragma unroll
+          for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) lw[(fq * 4 + e) * 64 + nj * 32 + jt * 16 + fr] = acc[mi][nj][it][jt][e];
+          epilogue_rows<EPI, SWAPPED, 4>(p, lw, mbw + mi * 64 + it * 16, nbw, bz, le);
+          __builtin_amdgcn_sched_barrier(0);  // slab by slab: interleaving all eight costs more registers than there are
+        }
+    } else {  // swapped: slab = 16 rows (n) x 64 columns (m): acc[mi][nj][.][jt]
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) lw[(fq * 4 + e) * 64 + it * 16 + fr] = acc[mi][nj][it][jt][e];
+            epilogue_rows<EPI, SWAPPED, 4>(p, lw, mbw + mi * 64, nbw + nj * 32 + jt * 16, bz, le);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+    }
+    if (!has_next) break;
+    t_cur = t_nxt;
+    n0 = n0n; m0 = m0n; bz = bzn;
+    wn_cur = wn_nxt;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) ao_cur[hh][q] = ao_nxt[hh][q];
+  }
+#undef AXW_PHASE_MFMA_BEGIN
+#undef AXW_PHASE_MFMA_END
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+int gemm_force_tile = 0;  // 0: by tile count; 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 phased, 5: 256x256 persistent stream (microbenchmarks)
 
 template <int EPI, bool SW>
 static void launch_one(GemmParams p, int n_begin, int n_end, hipStream_t s) {
@@ -785,6 +1102,26 @@ static void launch_one(GemmParams p, int n_begin, int n_end, hipStream_t s) {
     auto fill = [](int tiles) { return (double)tiles / (double)((tiles + 255) / 256 * 256); };
     const bool sq_pays = tiles_sq >= 256 && 1.15 * fill(tiles_sq) >= fill(2 * tiles_sq);
     const int nk = p.K / BK;
+    const bool small_ops = ((long)p.batch * p.a_batch_stride + (long)p.M * p.lda) * 2 < (1L << 32) && (long)p.N * p.K * 2 < (1L << 32);
+    if ((gemm_force_tile == 5 || (gemm_force_tile == 0 && sq_pays)) && nk >= 4 && nk % 2 == 0 && small_ops) {
+      constexpr int lds = 2 * KT4_BYTES + 8 * SLAB_FLOATS * 4;  // all 160 KB of a CU: opt-in per kernel and device
+      static std::atomic<unsigned long long> attr_done{0};     // (per instantiation) bit = device ordinal
+      static std::atomic<int> n_cus{0};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256ps_bf16_kernel<EPI, SW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        int cu = 0;
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess || cu < 1) { fprintf(stderr, "[ax_whisper] launch_gemm: %s\n", hipGetErrorString(e)); abort(); }
+        n_cus.store(cu, std::memory_order_relaxed);  // the devices of one node are alike
+        attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
+      }
+      const int cus = n_cus.load(std::memory_order_relaxed);
+      p.n_tiles = (n_end - n_begin) / BN3;
+      hipLaunchKernelGGL((gemm256ps_bf16_kernel<EPI, SW>), dim3(tiles_sq < cus ? tiles_sq : cus), dim3(512), lds, s, p);
+      return;
+    }
     if ((gemm_force_tile == 4 || (gemm_force_tile == 0 && sq_pays)) && nk >= 4 && nk % 2 == 0) {
       p.n_tiles = (n_end - n_begin) / BN3;
       hipLaunchKernelGGL((gemm256ph_bf16_kernel<EPI, SW>), dim3(tiles_sq), dim3(512), 2 * KT4_BYTES, s, p);
