@@ -78,14 +78,39 @@ __device__ __forceinline__ void h16split2(float x0, float x1, unsigned& hi, unsi
   hi = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
   lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
 }
+// sum / maximum over the wave in every lane (all 64 lanes active): DPP butterflies inside a 16-lane row, then
+// v_permlane{16,32}_swap across rows — ~8 short vector instructions; the __shfl_xor form compiles to six dependent
+// ds_bpermute round trips (~700 cycles of latency per call, which bounded the K/V block loop of decode_attention_kernel)
+#define AXW_DPP_F(CTRL, X) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), CTRL, 0xf, 0xf, true))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += AXW_DPP_F(0xB1, v);   // quad_perm [1,0,3,2]
+  v += AXW_DPP_F(0x4E, v);   // quad_perm [2,3,0,1]
+  v += AXW_DPP_F(0x141, v);  // row_half_mirror
+  v += AXW_DPP_F(0x140, v);  // row_mirror
+  {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, AXW_DPP_F(0xB1, v));   // quad_perm [1,0,3,2]
+  v = fmaxf(v, AXW_DPP_F(0x4E, v));   // quad_perm [2,3,0,1]
+  v = fmaxf(v, AXW_DPP_F(0x141, v));  // row_half_mirror
+  v = fmaxf(v, AXW_DPP_F(0x140, v));  // row_mirror
+#undef AXW_DPP_F
+  {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
   return v;
 }
 // exact-erf GELU (nn.GELU default; export_onnx.py:158-159 F.gelu)

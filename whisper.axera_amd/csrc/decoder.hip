@@ -64,7 +64,8 @@ __device__ __forceinline__ uint4 ld_kv(const uint4* p) {
 template <bool FUSE_Q>
 __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, int cap_blocks) {
   __shared__ float s_part[4][kPartStride];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the block loop below is wave-uniform control flow
   const int split = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
   // A clip that has reached its eot keeps its slot in the batch but streams no K/V any more (the reference stops each
   // utterance at its own eot, Whisper.cpp:219-222). Its stale attention output feeds linear layers whose results
@@ -82,20 +83,27 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
   uint4 kn[8], vn[8];
   int blk = blk_begin + wave;
   // keys at or beyond `limit` are not fetched (they are masked anyway): the 36 rows that pad 1500 keys to 24 blocks of
-  // 64 (2.3 % of the cross-attention bytes) and, on average, half a block of the self-attention cache per wave
-  auto load_block = [&](int bk, int limit) {
-    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+  // 64 (2.3 % of the cross-attention bytes) and, on average, half a block of the self-attention cache per wave.
+  // Lanes whose key is at or beyond `limit` read the block's last valid key instead (the same cache lines as their
+  // neighbours: no extra bytes, and no per-lane predicate around the loads, which hipcc turns into one branch per load).
+  // A block that is loaded at all has at least one key below the limit.
+  auto load_k = [&](int bk, int limit) {
+    const int lk = max(0, min(lane, limit - 1 - bk * 64));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kn[i] = ld_kv(reinterpret_cast<const uint4*>(kb + (long)bk * 4096 + i * 512 + lk * 8));
+  };
+  auto load_v = [&](int bk, int limit) {
+    const int last = max(bk * 64, limit - 1);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      kn[i] = bk * 64 + lane < limit ? ld_kv(reinterpret_cast<const uint4*>(kb + (long)bk * 4096 + i * 512 + lane * 8)) : zero;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      vn[i] = bk * 64 + 8 * i + (lane >> 3) < limit
-                  ? ld_kv(reinterpret_cast<const uint4*>(vb + ((long)bk * 64 + 8 * i + (lane >> 3)) * 64 + (lane & 7) * 8)) : zero;
+      vn[i] = ld_kv(reinterpret_cast<const uint4*>(vb + (long)min(bk * 64 + 8 * i + (lane >> 3), last) * 64 + (lane & 7) * 8));
   };
   // cross-attention knows its key count; self-attention does not yet (the step counter is a load): its first block is
   // fetched whole (every block below cap_blocks is allocated and zero-initialised)
-  if (blk < blk_cap_end) load_block(blk, p.n_keys >= 0 ? p.n_keys : 0x7fffffff);
+  if (blk < blk_cap_end) {
+    load_k(blk, p.n_keys >= 0 ? p.n_keys : 0x7fffffff);
+    load_v(blk, p.n_keys >= 0 ? p.n_keys : 0x7fffffff);
+  }
   float qv[64];
   if constexpr (FUSE_Q) {
     __shared__ __attribute__((aligned(16))) float s_act[1024];
@@ -177,24 +185,27 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = 0.f;
 
-  while (blk < blk_end) {
-    uint4 kr[8], vr[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { kr[i] = kn[i]; vr[i] = vn[i]; }
-    const int cur = blk;
-    blk += 4;
-    if (blk < blk_end) load_block(blk, n_keys);  // next block in flight during this block's arithmetic
+  // One register set per operand (K 32 + V 32 VGPRs instead of current + next of both): the next block's K is requested
+  // as soon as the scores of this one are formed and lands under the softmax and the P.V arithmetic, the next V right
+  // after P.V. The requests sit behind a wave-uniform `if (more)`, and hipcc joins the loaded registers with the old
+  // ones at the end of the iteration (`s_waitcnt vmcnt(0)` + copies), so V's latency is exposed once per block. The
+  // peeled form (unconditional requests, counted waits, loads crossing the iteration: 366 instead of 524 instructions
+  // per block) measured the same per attention launch (14.7 us) but a SLOWER decoder step at 64 clips (1.157 against
+  // 1.140 ms, twice in one call): the launch-latency-bound GEMM chain of the other graph branch shares the memory
+  // queues with these loads, and the deeper this kernel keeps them, the longer each dependent GEMM launch takes.
+  auto one_block = [&](int cur, bool prefetch) {
     // lane = key cur*64 + lane: dot(q, k) over 64 dims
     float sc = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const unsigned u[4] = {kr[i].x, kr[i].y, kr[i].z, kr[i].w};
+      const unsigned u[4] = {kn[i].x, kn[i].y, kn[i].z, kn[i].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         sc = fmaf(qv[i * 8 + 2 * e], h16lo(u[e]), sc);
         sc = fmaf(qv[i * 8 + 2 * e + 1], h16hi(u[e]), sc);
       }
     }
+    if (prefetch) load_k(cur + 4, n_keys);
     sc *= 0.125f;  // (64^-0.25)^2, export_onnx.py:116,124-126
     if (cur * 64 + lane >= n_keys) sc = -INFINITY;
     const float m_new = fmaxf(m_w, wave_max(sc));
@@ -207,14 +218,16 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float w = __shfl(pk, 8 * i + (lane >> 3), 64);
-      const unsigned u[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
+      const unsigned u[4] = {vn[i].x, vn[i].y, vn[i].z, vn[i].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         o[2 * e] = fmaf(w, h16lo(u[e]), o[2 * e]);
         o[2 * e + 1] = fmaf(w, h16hi(u[e]), o[2 * e + 1]);
       }
     }
-  }
+    if (prefetch) load_v(cur + 4, n_keys);
+  };
+  for (; blk < blk_end; blk += 4) one_block(blk, blk + 4 < blk_end);
   // wave partial: sum o over the 8 key sub-rows (lanes with equal lane&7), sum l over the wave
   const float l_w = wave_sum(l_lane);
 #pragma unroll
