@@ -15,7 +15,7 @@ struct FakeEngine {
   std::mutex mu;
   std::vector<std::pair<int, const float*>> calls;  // (batch, first clip pointer)
   int fail_on_value = -1;
-  static std::atomic<int> concurrent, max_concurrent;
+  static std::atomic<int> concurrent, max_concurrent, wait_ms;
   explicit FakeEngine(int d) : device(d) {}
   std::mutex& mutex() { return mu; }
   void run_tokens(const float* const* pcm, const float* d_pcm, int, const int* n_samples, int batch, int max_new, int32_t* ids, int* n_ids) {
@@ -23,7 +23,9 @@ struct FakeEngine {
     const int c = ++concurrent;
     int m = max_concurrent.load();
     while (c > m && !max_concurrent.compare_exchange_weak(m, c)) {}
-    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    // stay inside the call until a second worker has been seen inside too (or 2 s: a single worker / a serial bug), so the
+    // side-by-side check below does not depend on how fast a loaded machine starts threads
+    for (int i = 0; i < wait_ms.load() && max_concurrent.load() < 2; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(1));
     calls.push_back({batch, pcm[0]});
     for (int b = 0; b < batch; ++b) {
       if ((int)pcm[b][0] == fail_on_value) { --concurrent; throw std::runtime_error("clip " + std::to_string((int)pcm[b][0]) + " is poisoned"); }
@@ -36,7 +38,7 @@ struct FakeEngine {
     --concurrent;
   }
 };
-std::atomic<int> FakeEngine::concurrent{0}, FakeEngine::max_concurrent{0};
+std::atomic<int> FakeEngine::concurrent{0}, FakeEngine::max_concurrent{0}, FakeEngine::wait_ms{0};
 
 static void check_shards() {
   for (int n : {0, 1, 5, 7, 64, 512, 513})
@@ -66,7 +68,9 @@ static void run_case(int G, int B, int max_new) {
   std::vector<int32_t> ids((size_t)B * 448, -1), want((size_t)B * 448, -1);
   std::vector<int> n(B, -1), wn(B, -1);
   FakeEngine::max_concurrent = 0;
+  FakeEngine::wait_ms = (G < B ? G : B) > 1 ? 2000 : 0;
   g.run_tokens(ptrs.data(), lens.data(), B, max_new, 448, ids.data(), n.data());
+  FakeEngine::wait_ms = 0;
   FakeEngine single(99);
   single.run_tokens(ptrs.data(), nullptr, 0, lens.data(), B, max_new, want.data(), wn.data());
   assert(n == wn && ids == want);  // joined result == one engine over the whole batch, in order
