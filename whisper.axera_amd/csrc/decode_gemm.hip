@@ -475,7 +475,7 @@ __global__ __launch_bounds__(512) void decode_logits_kernel(DecGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);  // [2][8 waves][NB][16 clips][16 rows]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: k-step selection is wave-uniform
   const int r = lane & 15, q = lane >> 4;
   const int KS = p.K / 32, n_rb = (p.N + 15) / 16, G = gridDim.x;
 
@@ -494,7 +494,11 @@ __global__ __launch_bounds__(512) void decode_logits_kernel(DecGemmParams p) {
     for (int c = 0; c < CH; ++c)
       w[c] = *reinterpret_cast<const h16x8*>(p.W + ((long)min(rb, n_rb - 1) * KS + min(wave + 8 * c, KS - 1)) * 512 + lane * 8);
   };
-  h16x8 w0[CH], w1[CH];
+  // three register sets: the blocks of the next TWO iterations are in flight while one is multiplied (with one block
+  // ahead an iteration was one memory round trip: 25 us for 80 MB at 64 clips). loadw clamps the block index, so the
+  // requests are unconditional (a conditional request joins old and new registers at the loop's end, which hipcc
+  // resolves with a full drain); the tail re-reads the last block (L2 hits).
+  h16x8 w0[CH], w1[CH], w2[CH];
   loadw(w0, blockIdx.x);
   if (p.state->step < p.skip_before_step) return;  // SOT steps: logits are discarded (Whisper.cpp:214-217)
 
@@ -540,12 +544,16 @@ __global__ __launch_bounds__(512) void decode_logits_kernel(DecGemmParams p) {
     }
   };
   int it = 0;
-  for (int rb = blockIdx.x; rb < n_rb; rb += 2 * G) {
-    if (rb + G < n_rb) loadw(w1, rb + G);
+  loadw(w1, blockIdx.x + G);
+  for (int rb = blockIdx.x; rb < n_rb; rb += 3 * G) {
+    loadw(w2, rb + 2 * G);
     body(w0, rb, it++);
     if (rb + G >= n_rb) break;
-    if (rb + 2 * G < n_rb) loadw(w0, rb + 2 * G);
+    loadw(w0, rb + 3 * G);
     body(w1, rb + G, it++);
+    if (rb + 2 * G >= n_rb) break;
+    loadw(w1, rb + 4 * G);
+    body(w2, rb + 2 * G, it++);
   }
   // the 16 lanes that share a clip hold its candidates of different row lanes: lowest index wins ties
 #pragma unroll
