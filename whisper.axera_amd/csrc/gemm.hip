@@ -1,15 +1,20 @@
 // gemm.hip — h16 MFMA GEMM with fused epilogues for the encoder (K3, K4, K6, K8 of SURVEY §8a).
 //
 // C[M,N] = A[M,K] * W[N,K]^T, A and W h16 with K contiguous (nn.Linear weights are [out][in],
-// so no transposition is ever needed), fp32 accumulation in v_mfma_f32_32x32x16_bf16.
+// so no transposition is ever needed), fp32 accumulation on the matrix cores.
 //
 // Replaces, inside the reference's opaque encoder blob (cpp/src/ax_model_runner/
 // ax_model_runner.cpp:95-108 running export_onnx.py:153-213): conv1/conv2 (as GEMMs over
 // overlapping time-major rows: A row t = 3 consecutive input frames, lda = stride*C_in),
 // every nn.Linear of the encoder blocks and the per-decoder-layer cross K/V projections.
 //
-// Three tile shapes share one design and are chosen per launch by how many tiles it has (launch_one): 128x128
-// (4 waves, this comment), 256x128 (8 waves, 3-stage ring) and 256x256 (8 waves, 128x64 per wave) further down.
+// Kernels, chosen per launch by how many tiles it has (launch_one):
+//   gemm_bf16_kernel       128x128, 4 waves, two LDS buffers (this comment)        few tiles: one to four clips
+//   gemm256_bf16_kernel    256x128, 8 waves, 3-stage LDS-DMA ring                  mid-size launches
+//   gemm256ps_bf16_kernel  256x256, phased 16x16x32 k-loop, one k-tile STREAM per CU the batched encoder (>= 256 tiles)
+//   gemm256ph_bf16_kernel  the same k-loop, one tile per workgroup                 operands beyond 4 GB / A-B runs
+//   gemm256sq_bf16_kernel  256x256, two-stage 32x32x16 loop (round 1)              odd k-tile counts
+// All share the swizzled LDS image, the tile order and the epilogues (epilogue_rows).
 // Tiling of the smallest (wave64): 128x128 output tile, BK = 64, 256 threads = 4 waves in 2x2, each wave a
 // 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs). A and W tiles are staged by LDS-DMA
 // (global_load_lds, no VGPR round trip) with an XOR swizzle of the 16-byte chunks (chunk ^ ((row>>1)&7)),
