@@ -29,6 +29,7 @@ int main(int argc, char** argv) {
       {"mlp.2          (N=768  K=3072, resid f32)", 1500, 64, 768, 3072, EPI_RESID_F32},
       {"4096^3         (bias bf16)", 4096, 1, 4096, 4096, EPI_BIAS_BF16},
       {"one clip mlp.0 (N=3072 K=768,  gelu bf16)", 1500, 1, 3072, 768, EPI_BIAS_GELU_BF16},
+      {"q,k,v          (N=2304 K=768,  Q K V^T    )", 1500, 64, 2304, 768, EPI_QKV},
   };
   std::mt19937 rng(1);
   std::uniform_real_distribution<float> U(-1.f, 1.f);
@@ -41,7 +42,10 @@ int main(int argc, char** argv) {
     for (auto& v : hb) v = U(rng);
     h16 *dA, *dW; float* db; void* dC;
     const bool f32out = sh.epi == EPI_RESID_F32;
-    const size_t cbytes = (size_t)rows * sh.N * (f32out ? 4 : 2);
+    const bool qkv = sh.epi == EPI_QKV;  // Q [B][M][d] | K [B][M][d] | V^T [B][d][t_pad] in one buffer
+    const int d = 768, t_pad = (sh.M + 63) / 64 * 64;
+    const size_t q_elems = (size_t)rows * d, vt_elems = (size_t)sh.batch * d * t_pad;
+    const size_t cbytes = qkv ? (2 * q_elems + vt_elems) * 2 : (size_t)rows * sh.N * (f32out ? 4 : 2);
     CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dW, hW.size() * 2)); CK(hipMalloc(&db, sh.N * 4)); CK(hipMalloc(&dC, cbytes));
     CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
@@ -51,6 +55,13 @@ int main(int argc, char** argv) {
     p.A = dA; p.lda = sh.K; p.a_batch_stride = (long)sh.M * sh.K; p.W = dW; p.bias = db;
     p.C = dC; p.ldc = sh.N; p.c_batch_stride = (long)sh.M * sh.N;
     p.M = sh.M; p.N = sh.N; p.K = sh.K; p.batch = sh.batch; p.d_model = 768; p.epilogue = sh.epi;
+    if (qkv) {
+      h16* base = reinterpret_cast<h16*>(dC);
+      p.C = base; p.c_batch_stride = (long)sh.M * d;
+      p.C2 = base + q_elems; p.c2_batch_stride = (long)sh.M * d;
+      p.C3 = base + 2 * q_elems; p.c3_batch_stride = (long)d * t_pad;
+      p.t_pad = t_pad;
+    }
     hipStream_t s; CK(hipStreamCreate(&s));
     launch_gemm(p, s);  // first launch: checked below (resid: C was 0)
     CK(hipStreamSynchronize(s));
@@ -62,9 +73,19 @@ int main(int argc, char** argv) {
       double acc = hb[n];
       for (int k = 0; k < sh.K; ++k) acc += (double)bf16_to_f(hA[m * sh.K + k]) * bf16_to_f(hW[(size_t)n * sh.K + k]);
       if (sh.epi == EPI_BIAS_GELU_BF16) acc = 0.5 * acc * (1 + erf(acc * 0.7071067811865476));
-      const double got = f32out ? (double)reinterpret_cast<float*>(hC.data())[m * sh.N + n] : (double)bf16_to_f(reinterpret_cast<unsigned short*>(hC.data())[m * sh.N + n]);
+      double got;
+      if (qkv) {  // V^T: frames of a 16-group are stored in the order [0-3, 8-11, 4-7, 12-15] (gemm.hip, encoder_attn.hip)
+        const unsigned short* o = reinterpret_cast<unsigned short*>(hC.data());
+        const long b = m / sh.M, mm = m % sh.M;
+        const long mp = (mm & ~15L) | ((mm & 4) << 1) | ((mm & 8) >> 1) | (mm & 3);
+        got = n < d ? bf16_to_f(o[m * d + n]) : n < 2 * d ? bf16_to_f(o[q_elems + m * d + (n - d)])
+                                                          : bf16_to_f(o[2 * q_elems + (b * d + (n - 2 * d)) * t_pad + mp]);
+      } else {
+        got = f32out ? (double)reinterpret_cast<float*>(hC.data())[m * sh.N + n] : (double)bf16_to_f(reinterpret_cast<unsigned short*>(hC.data())[m * sh.N + n]);
+      }
       const double err = fabs(got - acc) / (f32out ? 1.0 : fmax(1.0, fabs(acc)) * 4.0);  // bf16 output: within half an ulp-ish
       if (err > max_err) max_err = err;
+      if (qkv && err > 4e-3 && getenv("GEMM_SHAPES_DEBUG")) fprintf(stderr, "  qkv mismatch m=%ld (clip %ld row %ld) n=%d got %.5f want %.5f\n", m, m / sh.M, m % sh.M, n, got, acc);
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 2; ++i) launch_gemm(p, s);
