@@ -1,6 +1,6 @@
-"""GPU: the batched decode path (5+ clips: bf16-pair activations on the matrix cores, one attention workgroup per
-(clip, head)) against the oracle and against the small-batch path, at batch sizes that exercise 1, 2 and 4
-clip blocks of 16 and a ragged last block."""
+"""GPU: the batched decode path (3+ clips: bf16-pair activations on the matrix cores, one attention workgroup per
+(clip, head), several at few clips) against the oracle and against the small-batch path, at batch sizes that exercise
+1, 2 and 4 clip blocks of 16 and a ragged last block."""
 import numpy as np
 import pytest
 import torch  # noqa: F401  (before libax_whisper.so: one HIP runtime per process)
@@ -26,7 +26,7 @@ def engine(built_lib, micro_case):
     e.close()
 
 
-@pytest.mark.parametrize("B", [5, 16, 21, 50])
+@pytest.mark.parametrize("B", [3, 4, 5, 16, 21, 50])  # 3-5 clips: cross-attention key blocks split over several workgroups
 def test_batched_teacher_forced_logits_vs_oracle(engine, micro_case, B):
     mels = _mels(B)
     engine.encode_mel(np.stack(mels))
@@ -153,3 +153,32 @@ def test_model_widths_batched_and_single_vs_oracle(built_lib, oracle_mod, tmp_pa
         assert err1 < 2e-2
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("B", [3, 4])
+def test_cross_attention_splits_and_decode_families_agree(built_lib, micro_case, monkeypatch, B):
+    """At few clips the key blocks of a (clip, head) are divided among several workgroups that meet through a ticket
+    (decoder.hip); the result must not depend on the split count (fold in split order), and the GEMV family (still the
+    path of one and two clips without the persistent launch) must agree with the clip-block GEMMs on the same clips."""
+    mels = np.stack(_mels(B))
+    forced = np.tile(np.array([[50258 + (i * 7) % 100 for i in range(8)]], dtype=np.int32), (B, 1))
+    out = {}
+    for name, env in (("default", {}), ("one workgroup", {"AX_WHISPER_CROSS_SPLIT": "1"}), ("three", {"AX_WHISPER_CROSS_SPLIT": "3"}),
+                      ("gemv family", {"AX_WHISPER_GEMV_MAX": "4"})):
+        for k in ("AX_WHISPER_CROSS_SPLIT", "AX_WHISPER_GEMV_MAX"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=B)
+        try:
+            e.encode_mel(mels)
+            out[name] = e.decode_forced(B, forced)[0]
+        finally:
+            e.close()
+    for name in ("one workgroup", "three"):
+        d = float(np.abs(out[name] - out["default"]).max())
+        print(f"B={B} cross-attention splits, {name} vs default: {d:.3e}")
+        assert d < 2e-4  # fp32 partial sums in a different association
+    d = float(np.abs(out["gemv family"] - out["default"]).max())
+    print(f"B={B} GEMV family vs clip-block GEMMs: {d:.3e}")
+    assert d < 5e-3

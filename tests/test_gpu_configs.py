@@ -100,8 +100,9 @@ def test_ragged_batch_leaves_the_loop_clip_by_clip(built_lib, small_case):
         for b in range(B):
             assert len(uniform[b]) == 140 and ragged[b] == uniform[b][: budget[b]], b
         print(f"decode of 64 clips: uniform 140 ids {t_uniform:.1f} ms, ragged 20/60/140 ids {t_ragged:.1f} ms")
-        # K/V bytes of the ragged run = (22*24 + 21*64 + 21*144) / (64*144) = 0.53 of the uniform run's; linear layers unchanged
-        assert t_ragged < 0.85 * t_uniform
+        # K/V bytes of the ragged run = (22*24 + 21*64 + 21*144) / (64*144) = 0.53 of the uniform run's; linear layers and
+        # launch count unchanged (measured 0.84-0.85 of the uniform run since the attention launches got faster; 0.79 before)
+        assert t_ragged < 0.92 * t_uniform
         # a clip whose budget is spent at once, beside clips that run on; and budgets above max_new are capped by it
         again = e.decode_greedy(B, max_new=30, max_new_clip=[1 if b == 7 else 400 for b in range(B)])
         assert again[7] == uniform[7][:1] and all(again[b] == uniform[b][:30] for b in range(B) if b != 7)

@@ -286,14 +286,16 @@ struct DecAttnParams {
   int cap_blocks;             // allocated 64-key blocks per (slot, head): 24 cross, 7 self
   const DecState* state;
   const int* done;            // optional device [B]: clips whose flag is set are skipped (greedy loop past their eot)
-  h16* out_hi; h16* out_lo; int nbs; // n_split == 1 only: normalised output as a fragment-major h16 pair instead of partials
+  h16* out_hi; h16* out_lo; int nbs; // normalised output as a fragment-major h16 pair instead of partials; with n_split > 1
+                                     // the splits of a (clip, head) meet through mpart / mcnt and the last one to arrive writes it
+  float* mpart; unsigned* mcnt;      // [B][H][n_split][66] / [B][H] (zero between launches), same clip origin as q / out
   // fused query projection (batched cross-attention): q = Wq[head rows] . LayerNorm(x[b]) + bq computed by the
   // (clip, head) workgroup itself while its first K/V block is in flight; wq == nullptr: q is read from `q`
   const float* x; const float* ln_w; const float* ln_b; const h16* wq; const float* bq;
 };
 void launch_decode_attention(const DecAttnParams& p, hipStream_t s);
 
-// ---- batched decode (5..64 clips per launch): activations as h16 (hi, lo) pairs, MFMA GEMM (decode_gemm.hip)
+// ---- batched decode (3..64 clips per launch): activations as h16 (hi, lo) pairs, MFMA GEMM (decode_gemm.hip)
 struct DecGemmParams {
   const h16* W;                           // fragment-major packed weights
   const float* bias; int N, K, batch;

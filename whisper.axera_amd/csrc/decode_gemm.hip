@@ -1,4 +1,4 @@
-// decode_gemm.hip — the decoder step's nn.Linear layers for 5..64 clips per launch on the matrix cores.
+// decode_gemm.hip — the decoder step's nn.Linear layers for 3..64 clips per launch on the matrix cores.
 //
 // y[b][n] = sum_k W[n][k] a[b][k] (+ bias[n]): W h16 [N][K] streamed from HBM exactly once per step for the
 // whole batch (277.8 MB/step for small), activations fp32-equivalent: every activation is carried

@@ -253,7 +253,46 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
         ov += f * s_part[w][2 + tid];
       }
     }
-    if (p.out_hi) {  // single split: this IS the attention output (batched decode path)
+    if (p.out_hi && p.n_split > 1) {
+      // Splits of one (clip, head) in the batched path at FEW clips (3 clips x 12 heads are 36 workgroups for 256 CUs,
+      // each streaming its 24 key blocks one after the other). Every split publishes (m, l, o[64]) with write-through
+      // stores, drains them, and draws a ticket; whoever draws the last one folds all of them IN SPLIT ORDER (the
+      // result does not depend on who arrives last) and writes the output.
+      float* base = p.mpart + ((long)b * p.n_head + head) * p.n_split * kPartStride;
+      float* mine = base + split * kPartStride;
+      __hip_atomic_store(mine + 2 + tid, ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) {
+        __hip_atomic_store(mine, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned ticket = 0;
+      if (tid == 0) ticket = __hip_atomic_fetch_add(p.mcnt + b * p.n_head + head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ticket = __builtin_amdgcn_readfirstlane(ticket);
+      if (ticket != (unsigned)p.n_split - 1u) return;  // (the whole wave; the other waves are past their last use of LDS)
+      float M = -INFINITY, Ls = 0.f, O = 0.f;
+      for (int s2 = 0; s2 < p.n_split; ++s2) {
+        float m2 = m, l2 = l, o2 = ov;
+        if (s2 != split) {
+          const float* other = base + s2 * kPartStride;
+          m2 = __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          l2 = __hip_atomic_load(other + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          o2 = __hip_atomic_load(other + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const float mn = fmaxf(M, m2);
+        const float f1 = M > -INFINITY ? __expf(M - mn) : 0.f, f2 = m2 > -INFINITY ? __expf(m2 - mn) : 0.f;
+        Ls = f1 * Ls + f2 * l2;
+        O = f1 * O + f2 * o2;
+        M = mn;
+      }
+      if (tid == 0) __hip_atomic_store(p.mcnt + b * p.n_head + head, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+      const float y = O / Ls;
+      const h16 yh = (h16)y;
+      const int k = head * 64 + tid;
+      const long i = ((((long)(k >> 5) * p.nbs + (b >> 4)) * 64) + ((k >> 3) & 3) * 16 + (b & 15)) * 8 + (k & 7);
+      p.out_hi[i] = yh;
+      p.out_lo[i] = (h16)(y - (float)yh);
+    } else if (p.out_hi) {  // single split: this IS the attention output (batched decode path)
       const float y = ov / l;
       const h16 yh = (h16)y;
       const int k = head * 64 + tid;  // fragment-major pair (layout: decode_gemm.hip)
@@ -270,7 +309,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
 
 void launch_decode_attention(const DecAttnParams& p, hipStream_t s) {
   if (p.wq) {
-    if (p.d_model > 1024 || p.d_model % 32 != 0 || p.n_split != 1) { fprintf(stderr, "[ax_whisper] fused query projection: d_model %d, n_split %d unsupported\n", p.d_model, p.n_split); abort(); }
+    if (p.d_model > 1024 || p.d_model % 32 != 0 || (p.n_split != 1 && !(p.out_hi && p.mpart && p.mcnt))) { fprintf(stderr, "[ax_whisper] fused query projection: d_model %d, n_split %d unsupported\n", p.d_model, p.n_split); abort(); }
     hipLaunchKernelGGL(decode_attention_kernel<true>, dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);
   } else {
     hipLaunchKernelGGL(decode_attention_kernel<false>, dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);

@@ -117,6 +117,9 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
   {
     const char* e = getenv("AX_WHISPER_ENC_SPLITK");
     enc_split_k_ = !(e && e[0] == '0');
+    // A/B and test switches of the batched decode sequence (read per engine)
+    if (const char* t = getenv("AX_WHISPER_GEMV_MAX")) gemv_max_ = std::max(1, std::min(4, atoi(t)));
+    if (const char* t = getenv("AX_WHISPER_CROSS_SPLIT")) cross_split_env_ = atoi(t);
     // encoder attention: rescale threshold of the running softmax maximum (tests run 0 = rescale on every increase)
     if (const char* t = getenv("AX_WHISPER_ENC_RESCALE_THR")) enc_rescale_thr_ = std::max(0.f, std::min(16.f, (float)atof(t)));
   }
@@ -530,6 +533,8 @@ void Engine::ensure_capacity(int batch) {
   d_amax_idx_ = (int*)A((size_t)n_amax_part_ * B * 4, true);
   d_tok_ = (int*)A((size_t)B * 4, true);
   d_done_ = (int*)A((size_t)B * 4, true);
+  d_attn_mpart_ = (float*)A((size_t)B * cfg_.n_text_head * kCrossSplitMax * 66 * 4, true);
+  d_attn_mcnt_ = (unsigned*)A((size_t)B * cfg_.n_text_head * 4, true);  // zero: every launch leaves its tickets at zero
   d_nout_ = (int*)A((size_t)B * 4, true);
   d_max_new_clip_ = (int*)A((size_t)B * 4, true);
   d_out_ids_ = (int*)A((size_t)B * Tc * 4, true);
@@ -689,12 +694,14 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
                                  long logits_stride, int* d_argmax) {
   const int d = cfg_.n_text_state, H = cfg_.n_text_head, L = cfg_.n_text_layer, Tc = cfg_.n_text_ctx;
   hipStream_t s = stream();
-  if (batch > 4) {
+  // 3+ clips: the clip-block sequence (a 4-clip step: 0.78 ms through the GEMV family, 0.59 through clip-block GEMMs);
+  // one clip that cannot use the persistent launch and two clips that cannot either stay on the GEMV family
+  if (batch > gemv_max_) {
     enqueue_decode_step_batched(batch, max_new, d_forced, n_forced, d_logits, logits_stride, d_argmax);
     return;
   }
 
-  // the VALU GEMV handles <= 4 clips per launch; tile the batch
+  // the VALU GEMV handles <= 4 clips per launch; tile the batch (gemv_max_ <= 4: one tile)
   auto gemv = [&](GemvParams p, auto&& offset) {
     for (int b0 = 0; b0 < batch; b0 += 4) {
       GemvParams q = p;
@@ -794,6 +801,17 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
     return c;
   };
   static const bool fuse_cq = [] { const char* e = getenv("AX_WHISPER_FUSE_CQ"); return !(e && e[0] == '0'); }();
+  // Workgroups per (clip, head) of the cross-attention launch (its key blocks divided among them, at least four blocks
+  // = one per wave each): at few clips one workgroup per (clip, head) leaves most CUs idle behind 24 sequential blocks
+  // (3 clips: attention 0.245 -> 0.209 ms per step with 6 splits); from ~24 clips on there are enough (clip, head)
+  // pairs and splitting only repeats the query projection (64 clips: 525 -> 588 ms with 2 splits).
+  int cross_split = 1;
+  {
+    const int blocks = t_pad_ / 64;
+    for (int c : {6, 4, 3, 2})
+      if (c <= kCrossSplitMax && blocks % c == 0 && nb * H * c <= 320) { cross_split = c; break; }
+    if (cross_split_env_ > 0 && cross_split_env_ <= kCrossSplitMax && blocks % cross_split_env_ == 0) cross_split = cross_split_env_;
+  }
   auto cgo = [&](const DecCGemmParams& c) { if (step_mask_ & 1) launch_decode_cgemm(c, s); };
   auto attn = [&](const h16* kc, const h16* vc, long stride, int n_keys, int cap_blocks) {
     DecAttnParams a{};
@@ -825,6 +843,9 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
     if (fuse_cq && d <= 1024) {  // the cross-attention workgroups project their own queries (decode_attention_kernel<true>)
       DecAttnParams a = attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64);
       a.q = nullptr;
+      a.n_split = cross_split;
+      a.mpart = d_attn_mpart_ + (long)b0 * H * kCrossSplitMax * 66;
+      a.mcnt = d_attn_mcnt_ + (long)b0 * H;
       a.x = x; a.ln_w = w.cross_ln_w; a.ln_b = w.cross_ln_b; a.wq = w.w_cq; a.bq = w.b_cq;
       if (step_mask_ & 2) launch_decode_attention(a, s);
     } else {
@@ -855,7 +876,7 @@ int Engine::decode_branches(int batch) const {
   return std::max(n, 1);
 }
 
-// Batched variant (5+ clips): LayerNorm -> h16 pairs (act_prep), MFMA GEMMs that read the weights once for the
+// Batched variant (3+ clips): LayerNorm -> h16 pairs (act_prep), MFMA GEMMs that read the weights once for the
 // whole batch, one attention workgroup per (clip, head) writing its output directly (no split partials).
 void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits,
                                          long logits_stride, int* d_argmax) {

@@ -114,15 +114,20 @@ class Engine final : public IEngine {
   h16 *d_mel_tm_ = nullptr, *d_h1_ = nullptr, *d_ln_ = nullptr, *d_q_ = nullptr, *d_k_ = nullptr, *d_vt_ = nullptr,
        *d_attn_ = nullptr, *d_ffn_ = nullptr;
   float* d_x_ = nullptr;
+  static constexpr int kCrossSplitMax = 6;  // workgroups per (clip, head) of the batched cross-attention launch at few clips
   static constexpr int kEncPartClips = 2;  // split-K of the encoder's residual GEMMs pays for at most this many clips
   float* d_enc_part_ = nullptr;
   bool enc_split_k_ = true;
   float enc_rescale_thr_ = 8.f;  // launch_encoder_attention
+  int gemv_max_ = 2;             // clips per call up to which the decoder step uses the GEMV family (AX_WHISPER_GEMV_MAX, <= 4)
+  int cross_split_env_ = 0;      // AX_WHISPER_CROSS_SPLIT: workgroups per (clip, head) of the batched cross-attention, 0 = by clip count
   h16 *d_cross_k_ = nullptr, *d_cross_v_ = nullptr, *d_self_k_ = nullptr, *d_self_v_ = nullptr;
   float *d_xdec_ = nullptr, *d_qdec_ = nullptr, *d_hid_ = nullptr, *d_part_self_ = nullptr, *d_part_cross_ = nullptr;
   h16 *d_act_[2] = {nullptr, nullptr}, *d_att_[2] = {nullptr, nullptr}, *d_hidp_[2] = {nullptr, nullptr};
   float* d_part_ = nullptr;
   float* d_amax_val_ = nullptr; int* d_amax_idx_ = nullptr; int n_amax_part_ = 0;
+  float* d_attn_mpart_ = nullptr;     // batched cross-attention in splits: partials and tickets (DecAttnParams::mpart / mcnt)
+  unsigned* d_attn_mcnt_ = nullptr;
   int *d_tok_ = nullptr, *d_done_ = nullptr, *d_nout_ = nullptr, *d_out_ids_ = nullptr, *d_max_new_clip_ = nullptr;
   DecState* d_state_ = nullptr;
   int* h_poll_ = nullptr;  // pinned
