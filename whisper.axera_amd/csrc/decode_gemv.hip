@@ -484,58 +484,42 @@ void launch_gemv(const GemvParams& p, hipStream_t s) {
 // One wave per clip merges the per-workgroup argmax partials (first max wins); 16 clips per workgroup. The step
 // counter is advanced by whichever workgroup finishes last (ticket in state->pad0), i.e. after every
 // workgroup has read it.
+// (value, index) maximum over the wave in every lane, lower index on equal values; DPP butterflies inside a 16-lane row,
+// v_permlane{16,32}_swap across rows (the __shfl_xor form: twelve dependent ds_bpermute round trips)
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+  auto take = [&](float ov, int oi) { if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; } };
+#define AXW_DPP_I(CTRL, X) __builtin_amdgcn_update_dpp(0, X, CTRL, 0xf, 0xf, true)
+#define AXW_ARGMAX_STEP(CTRL) { const float ov = __int_as_float(AXW_DPP_I(CTRL, __float_as_int(v))); const int oi = AXW_DPP_I(CTRL, idx); take(ov, oi); }
+  AXW_ARGMAX_STEP(0xB1)   // quad_perm [1,0,3,2]
+  AXW_ARGMAX_STEP(0x4E)   // quad_perm [2,3,0,1]
+  AXW_ARGMAX_STEP(0x141)  // row_half_mirror
+  AXW_ARGMAX_STEP(0x140)  // row_mirror
+#undef AXW_ARGMAX_STEP
+#undef AXW_DPP_I
+  {
+    auto rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    auto ri = __builtin_amdgcn_permlane16_swap((unsigned)idx, (unsigned)idx, false, false);
+    v = __uint_as_float(rv[0]); idx = (int)ri[0];
+    take(__uint_as_float(rv[1]), (int)ri[1]);
+  }
+  {
+    auto rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    auto ri = __builtin_amdgcn_permlane32_swap((unsigned)idx, (unsigned)idx, false, false);
+    v = __uint_as_float(rv[0]); idx = (int)ri[0];
+    take(__uint_as_float(rv[1]), (int)ri[1]);
+  }
+}
+
+// One wave per clip. The kernel is one dependent chain per decoder step (step counter -> argmax partials -> loop state ->
+// embedding row of the chosen token), so everything that does not depend on the previous link is requested early: the
+// loop state and the next position's embedding beside the partials, the step ticket right behind the step counter, and
+// the embedding row in 8-byte pieces that are all in flight before the first store (as `for (c = lane; c < d; c += 64)`
+// the row was 12 load -> add -> store round trips, 12.7 us per step at turbo dims).
 __global__ __launch_bounds__(1024) void advance_kernel(AdvanceParams p) {
   const int s = p.state->step;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x * 16 + wave;
-  if (b < p.batch) {
-    int tok = 0;
-    if (s < 3) {
-      tok = p.sot[s + 1];
-      if (lane == 0) p.tok[b] = tok;
-    } else {
-      float v = -INFINITY;
-      int idx = 0x7fffffff;
-#pragma unroll 4
-      for (int i = lane; i < p.n_part; i += 64) {
-        const float ov = p.amax_val[(long)b * p.amax_stride + i];
-        const int oi = p.amax_idx[(long)b * p.amax_stride + i];
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(v, o, 64);
-        const int oi = __shfl_xor(idx, o, 64);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-      }
-      // no logit compared greater than -inf (all NaN / -inf: non-finite audio): std::max_element returns index 0
-      // (Whisper.cpp:42-45); never let the "no candidate" index reach the embedding lookup below
-      if ((unsigned)idx >= (unsigned)p.n_vocab) idx = 0;
-      tok = p.tok[b];
-      const int gi = s - 3;
-      if (p.forced) {
-        if (gi < p.n_forced) tok = p.forced[(long)b * p.n_forced + gi];
-      } else if (!p.done[b]) {
-        const int n_out = p.n_out[b];
-        const int max_new = p.max_new_clip ? min(p.max_new_clip[b], p.max_new) : p.max_new;
-        if (idx == p.eot || s + 1 >= p.n_ctx || n_out >= max_new) {
-          if (lane == 0) { p.done[b] = 1; atomicAdd(&p.state->n_done, 1); }
-        } else {
-          if (lane == 0) { p.out_ids[(long)b * p.n_ctx + n_out] = idx; p.n_out[b] = n_out + 1; }
-          tok = idx;
-        }
-      }
-      if (lane == 0) {
-        if (p.argmax_dump && gi <= p.n_forced) p.argmax_dump[(long)b * (p.n_forced + 1) + gi] = idx;
-        p.tok[b] = tok;
-      }
-    }
-    // fused embedding of the NEXT step: x = tok_emb[token] + pos[step + 1]   (export_onnx.py:334-336)
-    if (s + 1 < p.n_ctx) {
-      for (int c = lane; c < p.d_model; c += 64)
-        p.x[(long)b * p.d_model + c] = (float)p.tok_emb[(long)tok * p.d_model + c] + p.pos[(long)(s + 1) * p.d_model + c];
-    }
-  }
+  // every thread holds the step counter before this workgroup's ticket can let the last workgroup advance it
   __syncthreads();
   if (threadIdx.x == 0) {
     const int ticket = atomicAdd(&p.state->pad0, 1);
@@ -544,9 +528,72 @@ __global__ __launch_bounds__(1024) void advance_kernel(AdvanceParams p) {
       p.state->step = s + 1;
     }
   }
+  if (b >= p.batch) return;
+  constexpr int MAXJ = 8;  // d_model <= 2048: lane l owns elements 4l + 256j
+  const int d = p.d_model;
+  const bool embed = s + 1 < p.n_ctx;
+  float4 pv[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+    if (embed && 4 * lane + 256 * j < d) pv[j] = *reinterpret_cast<const float4*>(p.pos + (long)(s + 1) * d + 4 * lane + 256 * j);
+  int tok = 0;
+  if (s < 3) {
+    tok = p.sot[s + 1];
+    if (lane == 0) p.tok[b] = tok;
+  } else {
+    // loop state of this clip: requested beside the partials, used after the reduction
+    const int tok_old = p.tok[b];
+    const bool greedy = !p.forced;
+    const int done_b = greedy ? p.done[b] : 0;
+    const int n_out = greedy ? p.n_out[b] : 0;
+    const int max_new = greedy ? (p.max_new_clip ? min(p.max_new_clip[b], p.max_new) : p.max_new) : 0;
+    float v = -INFINITY;
+    int idx = 0x7fffffff;
+#pragma unroll 4
+    for (int i = lane; i < p.n_part; i += 64) {
+      const float ov = p.amax_val[(long)b * p.amax_stride + i];
+      const int oi = p.amax_idx[(long)b * p.amax_stride + i];
+      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    wave_argmax(v, idx);
+    // no logit compared greater than -inf (all NaN / -inf: non-finite audio): std::max_element returns index 0
+    // (Whisper.cpp:42-45); never let the "no candidate" index reach the embedding lookup below
+    if ((unsigned)idx >= (unsigned)p.n_vocab) idx = 0;
+    tok = tok_old;
+    const int gi = s - 3;
+    if (p.forced) {
+      if (gi < p.n_forced) tok = p.forced[(long)b * p.n_forced + gi];
+    } else if (!done_b) {
+      if (idx == p.eot || s + 1 >= p.n_ctx || n_out >= max_new) {
+        if (lane == 0) { p.done[b] = 1; atomicAdd(&p.state->n_done, 1); }
+      } else {
+        if (lane == 0) { p.out_ids[(long)b * p.n_ctx + n_out] = idx; p.n_out[b] = n_out + 1; }
+        tok = idx;
+      }
+    }
+    if (lane == 0) {
+      if (p.argmax_dump && gi <= p.n_forced) p.argmax_dump[(long)b * (p.n_forced + 1) + gi] = idx;
+      p.tok[b] = tok;
+    }
+  }
+  // fused embedding of the NEXT step: x = tok_emb[token] + pos[step + 1]   (export_onnx.py:334-336)
+  if (embed) {
+    h16x4 ev[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+      if (4 * lane + 256 * j < d) ev[j] = *reinterpret_cast<const h16x4*>(p.tok_emb + (long)tok * d + 4 * lane + 256 * j);
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+      if (4 * lane + 256 * j < d) {
+        float4 o;
+        o.x = (float)ev[j][0] + pv[j].x; o.y = (float)ev[j][1] + pv[j].y; o.z = (float)ev[j][2] + pv[j].z; o.w = (float)ev[j][3] + pv[j].w;
+        *reinterpret_cast<float4*>(p.x + (long)b * d + 4 * lane + 256 * j) = o;
+      }
+  }
 }
 
 void launch_advance(const AdvanceParams& p, hipStream_t s) {
+  if (p.d_model > 2048 || p.d_model % 4 != 0) { fprintf(stderr, "[ax_whisper] launch_advance: d_model %d unsupported\n", p.d_model); abort(); }
   hipLaunchKernelGGL(advance_kernel, dim3((p.batch + 15) / 16), dim3(1024), 0, s, p);
 }
 
