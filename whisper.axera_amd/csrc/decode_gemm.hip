@@ -270,6 +270,15 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
   }
 }
 
+// v[l] + v[l^16] + v[l^32] + v[l^48] in every lane (the same pairing and order as two __shfl_xor steps, bit-identical,
+// without their two dependent ds_bpermute round trips)
+__device__ __forceinline__ float sum_lanes_16_32(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // ---------------------------------------------------------------------------- clip-block GEMM (DecCGemmParams)
 // grid = (weight-row blocks of 16*RT, clip blocks of 16); 8 waves split K (k-steps w, w+8, ...), reduce through LDS;
 // at most one output per thread (RT <= 2), so the bias and the residual value are requested before anything else.
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
   __shared__ __attribute__((aligned(16))) float red[8 * RT * 256];  // [wave][t][clip][row]
   __shared__ float stat[2][8][16];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: k-step selection is wave-uniform control flow
   const int r = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * (16 * RT), cb = blockIdx.y;
   const int KS = p.K / 32;
@@ -333,8 +342,7 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) s1 += (v[c][u][0] + v[c][u][1]) + (v[c][u][2] + v[c][u][3]);
       }
-    s1 += __shfl_xor(s1, 16, 64);
-    s1 += __shfl_xor(s1, 32, 64);
+    s1 = sum_lanes_16_32(s1);
     if (q == 0) stat[0][wave][r] = s1;
     __syncthreads();
     float mean = 0.f;
@@ -350,8 +358,7 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) { const float t2 = v[c][u][e] - mean; s2 += t2 * t2; }
       }
-    s2 += __shfl_xor(s2, 16, 64);
-    s2 += __shfl_xor(s2, 32, 64);
+    s2 = sum_lanes_16_32(s2);
     if (q == 0) stat[1][wave][r] = s2;
     __syncthreads();
     float var = 0.f;

@@ -231,10 +231,16 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
   // wave partial: sum o over the 8 key sub-rows (lanes with equal lane&7), sum l over the wave
   const float l_w = wave_sum(l_lane);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    o[e] += __shfl_xor(o[e], 8, 64);
-    o[e] += __shfl_xor(o[e], 16, 64);
-    o[e] += __shfl_xor(o[e], 32, 64);
+  for (int e = 0; e < 8; ++e) {  // lanes l, l^8, l^16, l^32 ...: a DPP rotation inside the 16-lane row, then the row swaps
+    o[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o[e]), 0x128, 0xf, 0xf, true));  // row_ror:8
+    {
+      auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[e]), __float_as_uint(o[e]), false, false);
+      o[e] = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    }
+    {
+      auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[e]), __float_as_uint(o[e]), false, false);
+      o[e] = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    }
   }
   if (lane == 0) { s_part[wave][0] = m_w; s_part[wave][1] = l_w; }
   if (lane < 8) {
