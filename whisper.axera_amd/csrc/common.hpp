@@ -113,6 +113,32 @@ __device__ __forceinline__ float wave_max(float v) {
   }
   return v;
 }
+// (value, index) maximum over the wave in every lane, lower index on equal values; DPP butterflies inside a 16-lane row,
+// v_permlane{16,32}_swap across rows (the __shfl_xor form: twelve dependent ds_bpermute round trips)
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+  auto take = [&](float ov, int oi) { if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; } };
+#define AXW_DPP_I(CTRL, X) __builtin_amdgcn_update_dpp(0, X, CTRL, 0xf, 0xf, true)
+#define AXW_ARGMAX_STEP(CTRL) { const float ov = __int_as_float(AXW_DPP_I(CTRL, __float_as_int(v))); const int oi = AXW_DPP_I(CTRL, idx); take(ov, oi); }
+  AXW_ARGMAX_STEP(0xB1)   // quad_perm [1,0,3,2]
+  AXW_ARGMAX_STEP(0x4E)   // quad_perm [2,3,0,1]
+  AXW_ARGMAX_STEP(0x141)  // row_half_mirror
+  AXW_ARGMAX_STEP(0x140)  // row_mirror
+#undef AXW_ARGMAX_STEP
+#undef AXW_DPP_I
+  {
+    auto rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    auto ri = __builtin_amdgcn_permlane16_swap((unsigned)idx, (unsigned)idx, false, false);
+    v = __uint_as_float(rv[0]); idx = (int)ri[0];
+    take(__uint_as_float(rv[1]), (int)ri[1]);
+  }
+  {
+    auto rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    auto ri = __builtin_amdgcn_permlane32_swap((unsigned)idx, (unsigned)idx, false, false);
+    v = __uint_as_float(rv[0]); idx = (int)ri[0];
+    take(__uint_as_float(rv[1]), (int)ri[1]);
+  }
+}
+
 // exact-erf GELU (nn.GELU default; export_onnx.py:158-159 F.gelu)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 // The same GELU with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. far below one h16 ulp of the

@@ -484,32 +484,6 @@ void launch_gemv(const GemvParams& p, hipStream_t s) {
 // One wave per clip merges the per-workgroup argmax partials (first max wins); 16 clips per workgroup. The step
 // counter is advanced by whichever workgroup finishes last (ticket in state->pad0), i.e. after every
 // workgroup has read it.
-// (value, index) maximum over the wave in every lane, lower index on equal values; DPP butterflies inside a 16-lane row,
-// v_permlane{16,32}_swap across rows (the __shfl_xor form: twelve dependent ds_bpermute round trips)
-__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
-  auto take = [&](float ov, int oi) { if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; } };
-#define AXW_DPP_I(CTRL, X) __builtin_amdgcn_update_dpp(0, X, CTRL, 0xf, 0xf, true)
-#define AXW_ARGMAX_STEP(CTRL) { const float ov = __int_as_float(AXW_DPP_I(CTRL, __float_as_int(v))); const int oi = AXW_DPP_I(CTRL, idx); take(ov, oi); }
-  AXW_ARGMAX_STEP(0xB1)   // quad_perm [1,0,3,2]
-  AXW_ARGMAX_STEP(0x4E)   // quad_perm [2,3,0,1]
-  AXW_ARGMAX_STEP(0x141)  // row_half_mirror
-  AXW_ARGMAX_STEP(0x140)  // row_mirror
-#undef AXW_ARGMAX_STEP
-#undef AXW_DPP_I
-  {
-    auto rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    auto ri = __builtin_amdgcn_permlane16_swap((unsigned)idx, (unsigned)idx, false, false);
-    v = __uint_as_float(rv[0]); idx = (int)ri[0];
-    take(__uint_as_float(rv[1]), (int)ri[1]);
-  }
-  {
-    auto rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    auto ri = __builtin_amdgcn_permlane32_swap((unsigned)idx, (unsigned)idx, false, false);
-    v = __uint_as_float(rv[0]); idx = (int)ri[0];
-    take(__uint_as_float(rv[1]), (int)ri[1]);
-  }
-}
-
 // One wave per clip. The kernel is one dependent chain per decoder step (step counter -> argmax partials -> loop state ->
 // embedding row of the chosen token), so everything that does not depend on the previous link is requested early: the
 // loop state and the next position's embedding beside the partials, the step ticket right behind the step counter, and

@@ -730,12 +730,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         // first max wins (Whisper.cpp:42-45)
         float cv = tid < P ? __uint_as_float(v[0]) : -INFINITY;
         int ci = tid < P ? (int)v[1] : 0x7fffffff;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const float ov = __shfl_xor(cv, o, 64);
-          const int oi = __shfl_xor(ci, o, 64);
-          if (ov > cv || (ov == cv && oi < ci)) { cv = ov; ci = oi; }
-        }
+        wave_argmax(cv, ci);  // DPP + row swaps: the __shfl_xor form is twelve dependent ds_bpermute round trips on the token's path
         if ((tid & 63) == 0) { am_v[tid >> 6] = cv; am_i[tid >> 6] = ci; }
         if (fail2) ctl[0] = 1;
         AXW_STAMP(15)
@@ -1046,12 +1041,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid, pk_qkv);
         // workgroup argmax: lanes with j == 0 hold candidates; the lower index wins ties
         if (j != 0) { bv = -INFINITY; bi = 0x7fffffff; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const float ov = __shfl_xor(bv, o, 64);
-          const int oi = __shfl_xor(bi, o, 64);
-          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
+        wave_argmax(bv, bi);
         if (lane == 0) { am_v[8 + cw] = bv; am_i[8 + cw] = bi; }
         // compute waves only: named exchange through LDS, then wave 0 publishes. The pollers sit at B3 meanwhile.
         wg_barrier();  // B3 (all waves)
