@@ -182,3 +182,22 @@ def test_cross_attention_splits_and_decode_families_agree(built_lib, micro_case,
     d = float(np.abs(out["gemv family"] - out["default"]).max())
     print(f"B={B} GEMV family vs clip-block GEMMs: {d:.3e}")
     assert d < 5e-3
+
+
+@pytest.mark.parametrize("B", [3, 6])
+def test_ragged_small_batch_with_split_cross_attention(built_lib, micro_case, B):
+    """Clips that leave early (per-clip id budgets) beside clips that run on, at clip counts where the cross-attention of a
+    (clip, head) is split over several workgroups: a finished clip's workgroups return before they touch the tickets of
+    their (clip, head), the others' ids stay those of the uniform run."""
+    e = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=B)
+    try:
+        e.encode_mel(np.stack(_mels(B)))
+        uniform = e.decode_greedy(B, max_new=24)
+        budget = [2 + 7 * (b % 3) for b in range(B)]
+        ragged = e.decode_greedy(B, max_new=24, max_new_clip=budget)
+        for b in range(B):
+            assert ragged[b] == uniform[b][: budget[b]], b
+        again = e.decode_greedy(B, max_new=24)  # tickets were left at zero: the next call is unaffected
+        assert again == uniform
+    finally:
+        e.close()
