@@ -898,18 +898,19 @@ __global__ __launch_bounds__(512) void gemm256ps_bf16_kernel(GemmParams p) {
   offsets(m0, bz, ao_cur);
   unsigned wn_cur = (unsigned)n0 * (unsigned)p.K * 2u, wn_nxt = 0;  // byte offset of W row n0
 
-  // which: 0 A0, 1 A1, 2 W0, 3 W1
+  // which: 0 A0, 1 A1, 2 W0, 3 W1. Buffer form of the LDS-DMA load: scalar resource of the operand + this lane's 32-bit
+  // offset + a scalar offset (k-tile, and the tile's first weight row) — no 64-bit address arithmetic in the k-loop
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0xffffffff, 0x27000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0xffffffff, 0x27000);
   auto stage = [&](auto WHICH, auto BUF, const unsigned (&ao)[2][2], unsigned wn, int kt) {
     constexpr int which = decltype(WHICH)::value, buf = decltype(BUF)::value;
     char* base = smem + buf * KT4_BYTES + which * HALF_BYTES + 8 * wave * (BK * 2);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      // uniform 64-bit base (scalar registers) + 32-bit per-lane offset: the saddr form of the load, no 64-bit VALU adds
-      const char* ub = which < 2 ? Ab + (long)kt * (BK * 2) : Wb + ((long)wn + (long)kt * (BK * 2));
-      unsigned off = which < 2 ? ao[which & 1][q] : wo[which & 1][q];
-      asm volatile("" : "+v"(off));  // keeps the resident per-lane values 32 bits wide (hipcc would hold base + offset as 64-bit pairs)
-      const char* src = ub + off;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(base + q * 64 * (BK * 2)), 16, 0, 0);
+      if constexpr (which < 2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(base + q * 64 * (BK * 2)), 16, (int)ao[which & 1][q], kt * (BK * 2), 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(base + q * 64 * (BK * 2)), 16, (int)wo[which & 1][q], (int)wn + kt * (BK * 2), 0, 0);
     }
   };
   using I0_ = std::integral_constant<int, 0>;
