@@ -71,12 +71,22 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const h16* __
   const int ld_row = tid >> 3, ld_c = tid & 7;
   const int nkt = t_pad / 64;
   u32x4 rk[2], rv[2];
+  // K / V^T tiles through buffer loads: scalar resource of this (clip, head), one constant 32-bit offset per lane and
+  // row, the tile as one add (K) or a scalar offset (V^T) — next to no vector address arithmetic in a kernel bound by vector issue.
+  // K's resource ends behind row T - 1, so the rows of the last tile at or beyond T read as zeros (they are masked).
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (unsigned)(((long)T * d_model - head * 64) * 2), 0x27000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (unsigned)(64 * t_pad * 2), 0x27000);
+  int offk[2], offv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    offk[i] = ((ld_row + 32 * i) * d_model + ld_c * 8) * 2;
+    offv[i] = ((ld_row + 32 * i) * t_pad + ld_c * 8) * 2;
+  }
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int key = min(kt * 64 + ld_row + 32 * i, T - 1);
-      rk[i] = *reinterpret_cast<const u32x4*>(Kb + (long)key * d_model + ld_c * 8);
-      rv[i] = *reinterpret_cast<const u32x4*>(Vb + (long)(ld_row + 32 * i) * t_pad + kt * 64 + ld_c * 8);
+      rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, offk[i] + kt * 64 * d_model * 2, 0, 0);  // in the lane offset: the range check ignores the scalar one
+      rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, offv[i], kt * 64 * 2, 0);
     }
   };
   auto store_tile = [&](int buf) {
