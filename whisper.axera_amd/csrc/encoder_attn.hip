@@ -107,10 +107,8 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const h16* __
   // last tile has any, and as a run-time test the compiler evaluated the 32 compare/select pairs on every tile.
   // The raw MFMA scores stay unscaled: exp2(s*sc - m*sc) is one FMA per element into v_exp, the running maximum is
   // kept in raw-score units (sc > 0).
-  auto process_tile = [&](int kt, auto tail_tag) {
+  auto process_tile = [&](int kt, auto tail_tag, const char* Ks, const char* Vs) {
     constexpr bool TAIL = decltype(tail_tag)::value;
-    const char* Ks = KVs[kt & 1][0];
-    const char* Vs = KVs[kt & 1][1];
     // ---- S^T = K Q^T : sacc[kb][e] = score(key = kt*64 + kb*32 + (e&3) + 8*(e>>2) + 4h, query = lane r)
     f32x16 sacc[2];
 #pragma unroll
@@ -135,7 +133,10 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const h16* __
         }
         mt = fmaxf(mt, sacc[kb][e]);
       }
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    {
+      auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+      mt = fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+    }
     // raise the running maximum (raw-score units; every tile has at least one unmasked key) only if some row needs it
     if (__builtin_amdgcn_ballot_w64((mt - m_run) * sc > rescale_thr) != 0) {
       const float m_new = fmaxf(m_run, mt);
@@ -174,13 +175,26 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const h16* __
   };
   // Peeled so the staging registers are assigned unconditionally inside the loop (a conditional prefetch makes
   // hipcc keep them in scratch memory and serialise every load).
-  for (int kt = 0; kt + 1 < nkt; ++kt) {
+  // (two tiles per iteration: the buffer of a tile is a compile-time constant, its LDS addresses immediates)
+  int kt = 0;
+  for (; kt + 2 < nkt; kt += 2) {
     load_tile(kt + 1);
-    process_tile(kt, std::false_type{});
-    store_tile((kt + 1) & 1);  // the buffer tile kt-1 was read from: every wave is past the barrier that ended iteration kt-1
+    process_tile(kt, std::false_type{}, KVs[0][0], KVs[0][1]);
+    store_tile(1);  // the buffer tile kt-1 was read from: every wave is past the barrier that ended iteration kt-1
+    __syncthreads();
+    load_tile(kt + 2);
+    process_tile(kt + 1, std::false_type{}, KVs[1][0], KVs[1][1]);
+    store_tile(0);
     __syncthreads();
   }
-  process_tile(nkt - 1, std::true_type{});  // t_pad - T < 64: only the last tile holds padded keys
+  if (kt + 1 < nkt) {  // an even tile count: one more full tile in buffer 0 before the last one
+    load_tile(kt + 1);
+    process_tile(kt, std::false_type{}, KVs[0][0], KVs[0][1]);
+    store_tile(1);
+    __syncthreads();
+    ++kt;
+  }
+  process_tile(nkt - 1, std::true_type{}, KVs[kt & 1][0], KVs[kt & 1][1]);  // t_pad - T < 64: only the last tile holds padded keys
 
   const float l = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l;
