@@ -565,11 +565,15 @@ __global__ __launch_bounds__(512) void decode_logits_kernel(DecGemmParams p) {
   // the 16 lanes that share a clip hold its candidates of different row lanes: lowest index wins ties
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv[u], o, 64);
-      const int oi = __shfl_xor(bi[u], o, 64);
-      if (ov > bv[u] || (ov == bv[u] && oi < bi[u])) { bv[u] = ov; bi[u] = oi; }
+    {  // DPP butterflies inside the 16-lane row (the __shfl_xor form: eight dependent ds_bpermute round trips at the launch's end)
+      auto take = [&](float ov, int oi) { if (ov > bv[u] || (ov == bv[u] && oi < bi[u])) { bv[u] = ov; bi[u] = oi; } };
+#define AXW_ROW_STEP(CTRL) { const float ov = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bv[u]), CTRL, 0xf, 0xf, true)); \
+                             const int oi = __builtin_amdgcn_update_dpp(0, bi[u], CTRL, 0xf, 0xf, true); take(ov, oi); }
+      AXW_ROW_STEP(0xB1)   // quad_perm [1,0,3,2]
+      AXW_ROW_STEP(0x4E)   // quad_perm [2,3,0,1]
+      AXW_ROW_STEP(0x141)  // row_half_mirror
+      AXW_ROW_STEP(0x140)  // row_mirror
+#undef AXW_ROW_STEP
     }
     const int o = tid + 512 * u, b = o >> 4;
     if (o < NB * 256 && (o & 15) == 0 && b < p.batch) {
