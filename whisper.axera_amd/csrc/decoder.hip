@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
       }
     }
     float acc = a0 + a1;
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
+    acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+    acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
     if (qj == 0) s_q[qrow] = acc + bq;
     __syncthreads();
 #pragma unroll
