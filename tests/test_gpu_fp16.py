@@ -60,10 +60,14 @@ def test_fp16_encoder_cross_kv_vs_oracle(built_lib, micro16):
         e.close()
 
 
-@pytest.mark.parametrize("batch,mode", [(1, "persistent"), (1, "graph"), (3, "gemv"), (7, "mfma"), (20, "mfma")])
+# 3 clips: clip-block GEMMs with the cross-attention split over several workgroups; "gemv": the fp32-FMA family (the path
+# of one or two clips outside the persistent launch), forced for 2 and 3 clips
+@pytest.mark.parametrize("batch,mode", [(1, "persistent"), (1, "graph"), (2, "graph"), (3, "gemv"), (3, "mfma"), (7, "mfma"), (20, "mfma")])
 def test_fp16_decode_paths_vs_oracle(built_lib, micro16, monkeypatch, batch, mode):
     if mode == "graph":
         monkeypatch.setenv("AX_WHISPER_DECODE", "graph")
+    if mode == "gemv":
+        monkeypatch.setenv("AX_WHISPER_GEMV_MAX", "4")
     e = built_lib.Whisper("micro", micro16.root, "zh", device=0, max_batch=batch)
     try:
         mels = _mels(min(batch, 4))
