@@ -923,6 +923,15 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
     a.done = d_forced ? nullptr : d_done_;
     a.out_hi = d_att_[0]; a.out_lo = d_att_[1]; a.nbs = nbs_;
+    if (n_keys >= 0) {  // cross-attention: few (clip, head) pairs leave CUs with one workgroup beside CUs with two (turbo, 16 clips: 320)
+      int c = 1;
+      for (int k : {6, 4, 3, 2})
+        if (k <= kCrossSplitMax && cap_blocks % k == 0 && batch * H * k <= 640) { c = k; break; }
+      if (cross_split_env_ > 0 && cross_split_env_ <= kCrossSplitMax && cap_blocks % cross_split_env_ == 0) c = cross_split_env_;
+      a.n_split = c;
+      a.mpart = d_attn_mpart_;
+      a.mcnt = d_attn_mcnt_;
+    }
     if (step_mask_ & 2) launch_decode_attention(a, s);
   };
   auto base = [&](const h16* W, const float* bias, int N, int K, const h16* ahi, const h16* alo, int epi) {
