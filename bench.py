@@ -48,6 +48,11 @@ def parse_args(argv=None):
                     help="16-bit storage / MFMA operand type; default: bf16, fp16 for --model turbo (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch64", action="store_true", help="N=1, batch 1 only: skip the batch-64 leg")
+    ap.add_argument("--no-turbo", action="store_true", help="N=1, batch 1 only: skip the turbo fp16 batch-16 leg (configs[3])")
+    ap.add_argument("--no-config0", action="store_true", help="N=1, batch 1 only: skip the tiny / demo.wav CPU-vs-GPU leg (configs[0])")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed region and its roofline: no host-PCM / forced-length / demo.wav / batch-64 / turbo / "
+                         "config0 / CPU legs (profiling runs: every launch in the trace belongs to the headline workload)")
     ap.add_argument("--model-dir", default=os.environ.get("AXW_BENCH_MODEL_DIR", "/tmp/axw_bench_models"))
     return ap.parse_args(argv)
 
@@ -63,14 +68,30 @@ def spawn_ranks(args) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
-    for l in r.stdout.splitlines():
+    # A rank that dies mid-step leaves the others inside a collective: torch.distributed.run notices the dead worker and
+    # tears the rest down (non-zero exit). Should that ever not happen, this process does not wait forever either: after
+    # AXW_BENCH_TIMEOUT_S (default 50 min) it kills the process group it started — that exact group, nothing by pattern.
+    timeout_s = float(os.environ.get("AXW_BENCH_TIMEOUT_S", "3000"))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    try:
+        stdout, _ = p.communicate(timeout=timeout_s)
+        code = p.returncode
+    except subprocess.TimeoutExpired:
+        import signal
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        stdout, _ = p.communicate()
+        print(f"bench.py: the {args.gpus} ranks did not finish within {timeout_s:.0f} s; killed", file=sys.stderr)
+        code = 124
+    lines = [l for l in stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in stdout.splitlines():
         if l not in lines:
             print(l, file=sys.stderr)
-    if lines:
+    if lines and code == 0:
         print(lines[-1], flush=True)
-    return r.returncode if r.returncode != 0 or lines else 1
+    return code if code != 0 or lines else 1
 
 
 # ------------------------------------------------------------------------------------------- algorithmic work
@@ -192,6 +213,116 @@ def stage_rooflines(eng, dims, model, B):
         stages["encoder"] = {"ms": round(ms_enc, 3), "TFLOPs": round(tf, 1), "bound": "mfma", "peak": MFMA_BF16_PEAK_TF,
                              "frac": round(tf / MFMA_BF16_PEAK_TF, 4)}
     return stages
+
+
+def ensure_model_dir(modelgen, model_dir, model, dims, dtype):
+    """Seeded synthetic-weight model directory (no weights exist in the reference or this image); the weights file's
+    dtype (BF16 / F16) selects the engine build. Returns (model_root, model directory)."""
+    model_root = model_dir + ("_f16" if dtype == "fp16" else "")
+    mdir = os.path.join(model_root, model)
+    if not os.path.exists(os.path.join(mdir, f"{model}.safetensors")):
+        modelgen.write_model_dir(model_root, model, dims, seed=0, dtype="F16" if dtype == "fp16" else "BF16",
+                                 tiktoken_path=os.path.join(ROOT, "tests", "golden", "multilingual.tiktoken"))
+    return model_root, mdir
+
+
+def batch_leg(torch, dev, dev_index, sync, model, dtype, B, steps, max_new, model_dir, rooflines=True):
+    """One more BASELINE config timed in the same run on the same GPU: B synthetic 30 s clips resident in HBM through
+    the whole hot path, `steps` timed passes after one warm-up pass."""
+    import numpy as np
+
+    import modelgen
+    import whisper_axera_amd as wa
+
+    dims = modelgen.DIMS[model]
+    model_root, _ = ensure_model_dir(modelgen, model_dir, model, dims, dtype)
+    clips = np.stack([modelgen.synth_clip(i, N_SAMP) for i in range(B)])
+    d_pcm = torch.from_numpy(clips).to(dev)
+    eng = wa.Whisper(model, model_root, "zh", device=dev_index, max_batch=B)
+    assert eng.L.AX_WHISPER_GetConfigInt(eng.h, b"fp16") == (1 if dtype == "fp16" else 0)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    st = {"frontend_ms": 0.0, "encoder_ms": 0.0, "decode_ms": 0.0, "steps": 0}
+
+    def step():
+        r = eng.run_device_tokens(d_pcm.data_ptr(), N_SAMP, [N_SAMP] * B, max_new=max_new)
+        tm = eng.timings()
+        for k in st:
+            st[k] += tm[k]
+        return r
+
+    step()
+    for k in st:
+        st[k] = 0
+    dt, ids = timed_steps(step, steps, 0, sync, lambda: None)
+    leg = {
+        "value": round(B * steps / dt, 3), "unit": "clips/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2),
+        "rtf": round(dt / steps / (B * 30.0), 7), "dtype": dtype,
+        "config": {"workload": f"whisper-{model} {dtype}, batch {B}, 30 s synthetic clips resident in HBM, greedy decode "
+                               f"{float(np.mean([len(r) for r in ids])):.0f} ids/clip ({st['steps'] / steps:.0f} decoder steps)"},
+        "stage_ms": {k: round(v / steps, 3) for k, v in st.items() if k != "steps"}}
+    if rooflines:
+        leg["roofline"] = roofline_for(eng, dims, model, B, st["steps"] / steps, st["decode_ms"] / steps)
+        leg["stage_rooflines"] = stage_rooflines(eng, dims, model, B)
+    eng.close()
+    del d_pcm
+    return leg, ids
+
+
+def config0_leg(torch, dev, dev_index, sync, model_dir, n_ids=32):
+    """BASELINE configs[0]: Whisper-tiny on demo.wav, greedy, batch 1 — the loop of the reference's CPU/ONNX path
+    (model_convert/generate_data.py:179-250) stood in for by the fp32 CPU oracle, timed on this box's host cores
+    (1 thread and all cores) beside the GPU engine at tiny dims on the same file and the same seeded weights. RTF over
+    the clip's TRUE duration (4.2039 s), as whisper_cli.cpp:93-103 and the README compute it. Synthetic weights never
+    emit eot, so both sides decode a fixed number of ids."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import wave
+
+    import numpy as np
+
+    import modelgen
+    import oracle
+    import whisper_axera_amd as wa
+
+    dims = modelgen.DIMS["tiny"]
+    model_root, mdir = ensure_model_dir(modelgen, model_dir, "tiny", dims, "bf16")
+    w = wave.open(os.path.join(ROOT, "tests", "golden", "demo.wav"))
+    demo = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32) / np.float32(32768.0)
+    audio_s = len(demo) / 16000.0
+    eng = wa.Whisper("tiny", model_root, "zh", device=dev_index, max_batch=1)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    gpu_ids = eng.run_tokens_batch([demo], max_new=n_ids)[0]
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        eng.run_tokens_batch([demo], max_new=n_ids)
+    tg = (time.perf_counter() - t0) / 5
+    eng.close()
+    weights = modelgen.read_safetensors(os.path.join(mdir, "tiny.safetensors"))
+    cfg = modelgen.make_config("tiny", dims)
+    ncpu = os.cpu_count() or 1
+    threads = min(ncpu, 32)
+    res = {}
+    for name, th in (("all_cores", threads), ("single_thread", 1)):
+        orc = oracle.Oracle(cfg, weights, bf16_policy=False, threads=th)
+        t1 = time.perf_counter()
+        cpu_ids = orc.transcribe(demo, "zh", max_new=n_ids)
+        tc = time.perf_counter() - t1
+        res[name] = {"seconds": round(tc, 4), "rtf_true_duration": round(tc / audio_s, 5), "cores": th}
+    orc.L.orc_set_threads(min(ncpu, 16))
+    agree = 0
+    for a, b in zip(cpu_ids, gpu_ids):
+        if a != b:
+            break
+        agree += 1
+    return {"workload": f"whisper-tiny (seeded synthetic weights), tests/golden/demo.wav ({audio_s:.4f} s, zh), greedy, batch 1, "
+                        f"{n_ids} ids (synthetic weights never emit eot)",
+            "cpu": dict(res, kind="port", what="fp32 CPU oracle (the restatement of export_onnx.py's graph + Whisper.cpp's loop; "
+                                               "the reference's own fp32 path needs onnxruntime + openai-whisper, absent here)",
+                        cpu_model=cpu_model_string(), host_cores=ncpu),
+            "gpu": {"ms": round(tg * 1e3, 3), "rtf_true_duration": round(tg / audio_s, 6), "dtype": "bf16",
+                    "what": "AX_WHISPER_RunPCMBatchTokens (host PCM, H2D + D2H inside)"},
+            "ids_agree_prefix": f"{agree}/{len(cpu_ids)}",
+            "speedup_vs_all_cores": round(res["all_cores"]["seconds"] / tg, 1)}
 
 
 def cpu_model_string():
@@ -347,7 +478,13 @@ def run_rank(args) -> int:
     if rehearsal:
         eng = RehearsalEngine()
 
+        fail_rank = int(os.environ.get("AXW_BENCH_FAIL_RANK", "-1"))  # test hook: this rank dies inside its second step
+        calls = [0]
+
         def one_step():
+            calls[0] += 1
+            if rank == fail_rank and calls[0] == 2:
+                raise RuntimeError(f"rank {rank}: injected failure (AXW_BENCH_FAIL_RANK)")
             ids = eng.run(clips, args.max_new)
             return dp.gather_ids(ids, B, device=None) if use_dist else ids
 
@@ -360,9 +497,8 @@ def run_rank(args) -> int:
         #      dtype (BF16 / F16) selects the engine build
         model_root = args.model_dir + ("_f16" if dtype == "fp16" else "")
         mdir = os.path.join(model_root, args.model)
-        if local_rank == 0 and not os.path.exists(os.path.join(mdir, f"{args.model}.safetensors")):
-            modelgen.write_model_dir(model_root, args.model, dims, seed=0, dtype="F16" if dtype == "fp16" else "BF16",
-                                     tiktoken_path=os.path.join(ROOT, "tests", "golden", "multilingual.tiktoken"))
+        if local_rank == 0:
+            ensure_model_dir(modelgen, args.model_dir, args.model, dims, dtype)
         barrier()
         eng = wa.Whisper(args.model, model_root, "zh", device=dev_index, max_batch=B)
         assert eng.L.AX_WHISPER_GetConfigInt(eng.h, b"fp16") == (1 if dtype == "fp16" else 0)
@@ -413,13 +549,36 @@ def run_rank(args) -> int:
     }
     if os.environ.get("AXW_BENCH_ONE_DEVICE") == "1" and world > 1:
         out["data"] = "synthetic; REHEARSAL on ONE device (AXW_BENCH_ONE_DEVICE=1): all ranks share GPU 0 — not a multi-GPU measurement"
+    def single_gpu_reference(step_fn):
+        """N > 1: the same per-GPU workload on ONE GPU in the same run — rank 0 alone times a few more steps (no collective
+        inside) while the other ranks wait at the second barrier — the reference point of the weak-scaling ratio
+        value / (N * this): N=1 runs of this script default to batch 1, so the ratio of two driver lines says nothing."""
+        if not (use_dist and world > 1):
+            return
+        barrier()
+        if rank == 0:
+            n1 = max(1, min(args.steps, 5))
+            t0 = time.perf_counter()
+            for _ in range(n1):
+                step_fn()
+            sync()
+            t1 = (time.perf_counter() - t0) / n1
+            out["single_gpu_same_batch"] = {"value": round(B / t1, 3), "unit": "clips/s", "ms_per_step": round(t1 * 1e3, 3), "steps": n1,
+                                            "what": f"rank 0 alone, {B} clips, the other {world - 1} ranks idle at a barrier"}
+            out["weak_scaling_efficiency"] = round(clips_per_s / (world * B / t1), 4)
+        barrier()
+
     if rehearsal:
         out["data"] = "REHEARSAL (AXW_BENCH_REHEARSAL=1): no GPU and no engine ran — plumbing test of the N>1 path only"
+        single_gpu_reference(lambda: eng.run(clips, args.max_new))
         out["value"] = None
         out["gathered_rows"] = len(ids)
     else:
         out["stage_ms"] = {k: round(v / args.steps, 3) for k, v in stage.items() if k != "steps"}
-        if rank == 0:
+        single_gpu_reference(lambda: eng.run_device_tokens(d_pcm.data_ptr(), N_SAMP, [N_SAMP] * B, max_new=args.max_new))
+        if rank == 0 and args.no_extras:
+            out["roofline"] = None  # --no-extras: a profiling run; the roofline legs would put other launches into the trace
+        elif rank == 0:
             out["roofline"] = roofline_for(eng, dims, args.model, B, dec_steps, stage["decode_ms"] / args.steps)
             out["stage_rooflines"] = stage_rooflines(eng, dims, args.model, B)
             # SURVEY §8(d) defines RTF on the host-pointer call (H2D of the PCM and D2H of the ids included): same
@@ -462,38 +621,20 @@ def run_rank(args) -> int:
                                            "RTF over the clip's true 4.2 s as whisper_cli computes it"}
         eng.close()
         sync()
-        # ---- the other half of the headline metric ("clips/s at batch"), in the same run: configs[2], batch 64
-        if rank == 0 and world == 1 and B == 1 and not args.no_batch64 and args.model == "small":
-            import whisper_axera_amd as wa
-            B2 = 64
-            clips2 = np.stack([modelgen.synth_clip(i, N_SAMP) for i in range(B2)])
-            d_pcm2 = torch.from_numpy(clips2).to(dev)
-            eng2 = wa.Whisper(args.model, model_root, "zh", device=dev_index, max_batch=B2)
-            eng2.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-            st2 = {"frontend_ms": 0.0, "encoder_ms": 0.0, "decode_ms": 0.0, "steps": 0}
-
-            def step2():
-                r = eng2.run_device_tokens(d_pcm2.data_ptr(), N_SAMP, [N_SAMP] * B2, max_new=args.max_new)
-                tm = eng2.timings()
-                for k in st2:
-                    st2[k] += tm[k]
-                return r
-
-            step2()
-            for k in st2:
-                st2[k] = 0
+        # ---- the other configs of BASELINE.json in the same run, so that the driver's line carries every headline number:
+        #      configs[2] (small, batch 64: "clips/s at batch"), configs[3] (turbo fp16, batch 16), configs[0] (tiny, demo.wav,
+        #      the CPU path timed beside the GPU)
+        if rank == 0 and world == 1 and B == 1 and args.model == "small":
             n2 = max(1, min(args.steps, 5))
-            dt2, ids2 = timed_steps(step2, n2, 0, sync, lambda: None)
-            out["batch64"] = {
-                "value": round(B2 * n2 / dt2, 3), "unit": "clips/s", "steps": n2, "ms_per_step": round(dt2 / n2 * 1e3, 2),
-                "rtf": round(dt2 / n2 / (B2 * 30.0), 7),
-                "config": {"workload": f"whisper-{args.model} {dtype}, batch {B2}, 30 s synthetic clips resident in HBM, greedy decode "
-                                       f"{float(np.mean([len(r) for r in ids2])):.0f} ids/clip ({st2['steps'] / n2:.0f} decoder steps)"},
-                "stage_ms": {k: round(v / n2, 3) for k, v in st2.items() if k != "steps"},
-                "roofline": roofline_for(eng2, dims, args.model, B2, st2["steps"] / n2, st2["decode_ms"] / n2),
-                "stage_rooflines": stage_rooflines(eng2, dims, args.model, B2),
-                "clip0_ids_equal_batch1": ids2[0] == ids[0]}
-            eng2.close()
+            if not args.no_batch64:
+                leg, ids2 = batch_leg(torch, dev, dev_index, sync, "small", dtype, 64, n2, args.max_new, args.model_dir)
+                leg["clip0_ids_equal_batch1"] = ids2[0] == ids[0]
+                out["batch64"] = leg
+            if not args.no_turbo and args.max_new == 0 and dtype == "bf16":
+                leg, _ = batch_leg(torch, dev, dev_index, sync, "turbo", "fp16", 16, min(n2, 3), 0, args.model_dir)
+                out["turbo_fp16_b16"] = leg
+            if not args.no_config0 and args.max_new == 0 and dtype == "bf16":
+                out["config0"] = config0_leg(torch, dev, dev_index, sync, args.model_dir)
         # ---- CPU baseline: the oracle ("port") on this box's host cores, one clip of the same workload
         if rank == 0 and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, dims, mdir, clips[0], ids[0], dec_steps, dtype)
@@ -512,6 +653,8 @@ def run_rank(args) -> int:
 
 def main():
     args = parse_args()
+    if args.no_extras:
+        args.no_batch64 = args.no_turbo = args.no_config0 = args.no_cpu_baseline = True
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         return 2

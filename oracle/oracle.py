@@ -20,7 +20,7 @@ fp = C.POINTER(C.c_float)
 
 
 class OrcPolicy(C.Structure):
-    _fields_ = [("bf16_policy", C.c_int)]
+    _fields_ = [("bf16_policy", C.c_int), ("literal_mask", C.c_int)]
 
 
 class OrcBlock(C.Structure):
@@ -126,12 +126,14 @@ def mel_filterbank(n_mels: int, use_ref: bool = False) -> np.ndarray:
 class Oracle:
     """CPU restatement bound to one set of weights (openai-whisper state_dict names, fp32)."""
 
-    def __init__(self, config: dict, weights: dict, bf16_policy=False, threads: int = 0):
+    def __init__(self, config: dict, weights: dict, bf16_policy=False, threads: int = 0, literal_mask: bool = False):
         """bf16_policy: False/0 = pure fp32, True/1 = the engine's bfloat16 storage points, 2 or "fp16" = the same
         storage points in IEEE half (the engine's fp16 build)."""
         self.cfg = config
         self.w = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in weights.items()}
-        self.policy = OrcPolicy(2 if bf16_policy in (2, "fp16") else (1 if bf16_policy else 0))
+        # literal_mask: decoder self-attention as the exported graph states it (448-row cache, -60000 fill, separate
+        # current-token column, 449-wide softmax: export_onnx.py:124-137) instead of the equivalent causal form
+        self.policy = OrcPolicy(2 if bf16_policy in (2, "fp16") else (1 if bf16_policy else 0), 1 if literal_mask else 0)
         self.L = lib()
         if threads:
             self.L.orc_set_threads(threads)

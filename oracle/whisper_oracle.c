@@ -543,6 +543,43 @@ static void attend_one(int n_keys, int d, int H, const float *q, const float *K,
   }
 }
 
+/* modified_self_qkv_attention as written (export_onnx.py:103-147), one head at a time: qk over the whole n_ctx-row
+ * cache (k_cache * scale, q * scale), masked_fill_(mask, -60000) with mask[j] = (j >= offset) (causal_mask_1d,
+ * export_onnx.py:59-68 / Whisper.cpp:253-258), qk1 against the current token's k1, softmax over the n_ctx + 1
+ * concatenated values in fp32, out = w @ v_cache + w1 @ v1. The cache rows >= offset are whatever the host left
+ * there (zeros after the reset of Whisper.cpp:204-205); they are multiplied by weights that underflow to 0. */
+static void attend_self_literal(int n_ctx, int offset, int d, int H, const float *q, const float *Kc, const float *Vc,
+                                const float *k1, const float *v1, float *out) {
+  int hd = d / H;
+  float scale = powf((float)hd, -0.25f);
+#pragma omp parallel for schedule(static)
+  for (int h = 0; h < H; ++h) {
+    float *s = (float *)malloc(sizeof(float) * (size_t)(n_ctx + 1));
+    float qs[256];
+    for (int c = 0; c < hd; ++c) qs[c] = q[h * hd + c] * scale;
+    for (int j = 0; j <= n_ctx; ++j) {
+      const float *kj = j < n_ctx ? Kc + (size_t)j * d + h * hd : k1 + h * hd;
+      float acc = 0.f;
+      for (int c = 0; c < hd; ++c) acc += qs[c] * (kj[c] * scale);
+      s[j] = (j < n_ctx && j >= offset) ? -60000.f : acc; /* masked_fill_ (:130) */
+    }
+    float mx = -3.402823466e38f;
+    for (int j = 0; j <= n_ctx; ++j) if (s[j] > mx) mx = s[j];
+    double sum = 0.0;
+    for (int j = 0; j <= n_ctx; ++j) { s[j] = expf(s[j] - mx); sum += s[j]; }
+    float inv = (float)(1.0 / sum);
+    float o[256];
+    for (int c = 0; c < hd; ++c) o[c] = 0.f;
+    for (int j = 0; j <= n_ctx; ++j) { /* w @ v_cache, then + w1 @ v1 (:139-141) */
+      const float *vj = j < n_ctx ? Vc + (size_t)j * d + h * hd : v1 + h * hd;
+      float w = s[j] * inv;
+      for (int c = 0; c < hd; ++c) o[c] += w * vj[c];
+    }
+    for (int c = 0; c < hd; ++c) out[h * hd + c] = o[c];
+    free(s);
+  }
+}
+
 /* export_onnx.py:312-387 for one token + the cache append of Whisper.cpp:328-342. */
 void orc_decoder_step(const orc_model *m, const orc_policy *p, int token, int offset,
                       const float *cross_k, const float *cross_v, float *self_k, float *self_v,
@@ -559,11 +596,25 @@ void orc_decoder_step(const orc_model *m, const orc_policy *p, int token, int of
     /* self-attn (export_onnx.py:238-261, 103-147) */
     layer_norm(1, d, x, b->attn_ln_w, b->attn_ln_b, ln);
     linear(1, d, d, ln, b->q_w, b->q_b, q);
-    linear(1, d, d, ln, b->k_w, NULL, Kc + (size_t)offset * d);
-    linear(1, d, d, ln, b->v_w, b->v_b, Vc + (size_t)offset * d);
-    maybe_round(p, Kc + (size_t)offset * d, d); /* engine keeps the self-KV cache in bf16 */
-    maybe_round(p, Vc + (size_t)offset * d, d);
-    attend_one(offset + 1, d, H, q, Kc, Vc, a);
+    if (p && p->literal_mask) {
+      /* the graph as exported: k, v of this token stay outside the cache while it is attended over (export_onnx.py:
+       * 245-261), the host appends them afterwards (Whisper.cpp:328-342) */
+      float *k1 = (float *)malloc(sizeof(float) * 2 * d), *v1 = k1 + d;
+      linear(1, d, d, ln, b->k_w, NULL, k1);
+      linear(1, d, d, ln, b->v_w, b->v_b, v1);
+      maybe_round(p, k1, d);
+      maybe_round(p, v1, d);
+      attend_self_literal(Tc, offset, d, H, q, Kc, Vc, k1, v1, a);
+      memcpy(Kc + (size_t)offset * d, k1, sizeof(float) * d);
+      memcpy(Vc + (size_t)offset * d, v1, sizeof(float) * d);
+      free(k1);
+    } else {
+      linear(1, d, d, ln, b->k_w, NULL, Kc + (size_t)offset * d);
+      linear(1, d, d, ln, b->v_w, b->v_b, Vc + (size_t)offset * d);
+      maybe_round(p, Kc + (size_t)offset * d, d); /* engine keeps the self-KV cache in bf16 */
+      maybe_round(p, Vc + (size_t)offset * d, d);
+      attend_one(offset + 1, d, H, q, Kc, Vc, a);
+    }
     linear(1, d, d, a, b->o_w, b->o_b, t1);
     for (int c = 0; c < d; ++c) x[c] += t1[c];
     /* cross-attn (export_onnx.py:221-230, 292-295) */

@@ -41,6 +41,13 @@ extern "C" {
  * half (the engine's fp16 build: BASELINE configs[3] "Whisper-turbo fp16"). */
 typedef struct {
   int bf16_policy;
+  /* 1: decoder self-attention exactly as the exported graph states it (export_onnx.py:124-137): scores against ALL
+   * 448 cache rows, rows >= offset filled with -60000 (the int mask of Whisper.cpp:253-258), a separate score
+   * column for the current token's k1, one fp32 softmax over the 449 values, w @ v_cache + w1 @ v1, and the cache
+   * append done by the host afterwards (Whisper.cpp:328-342). 0: the equivalent causal form (keys 0..offset, the
+   * current token appended first) that the engine's kernels implement. tests/test_oracle_model.py holds the two
+   * against each other bit for bit. */
+  int literal_mask;
 } orc_policy;
 
 typedef struct {

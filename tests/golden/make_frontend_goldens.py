@@ -33,8 +33,10 @@ def main():
         fb = oracle.mel_filterbank(nm, use_ref=True)
         np.savez_compressed(os.path.join(HERE, f"melfilter_{nm}.npz"), fb=fb)
     # seeded clips: a 30 s clip (3001 frames -> truncated), a short ragged one, a 1-frame-over one
+    # ... and a 75 s clip whose loudest second is at 70 s: the maximum over ALL frames sets the clamp floor of the 3000
+    # kept ones (Whisper.cpp:158-172)
     cases = {"synth0_30s": modelgen.synth_clip(0), "synth3_7777": modelgen.synth_clip(3, 7777),
-             "synth5_1s": modelgen.synth_clip(5, 16000)}
+             "synth5_1s": modelgen.synth_clip(5, 16000), "long75s_loud70": modelgen.synth_long_clip(75, 70)}
     for name, x in cases.items():
         mel, nf, mmax = oracle.log_mel(x, 80, use_ref=True)
         keep = min(nf, 3000)

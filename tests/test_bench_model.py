@@ -65,3 +65,30 @@ def test_bench_default_batch_is_64_per_gpu_beyond_one_gpu():
 def test_bench_rejects_a_rank_count_that_differs_from_gpus():
     rc, lines, err = _run_bench(["--gpus", "4"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert rc != 0 and not lines and "--gpus 4" in err
+
+
+def test_bench_gpus_8_rehearsal_is_configs4():
+    """BASELINE configs[4] — 8 ranks x 64 clips = 512 — as far as it can be run without eight GPUs: the rank spawn, the
+    default of 64 clips per GPU, the gather of all 512 id rows, the single-GPU reference leg behind the barrier and the ONE
+    JSON line (gloo, stand-in engine)."""
+    rc, lines, err = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "1"], {"OMP_NUM_THREADS": "1"})
+    assert rc == 0, err
+    assert len(lines) == 1
+    j = lines[0]
+    assert j["n_gpus"] == 8 and j["config"]["batch_per_gpu"] == 64 and j["config"]["global_batch"] == 512
+    assert j["gathered_rows"] == 512 and j["config"]["parallelism"] == "dp8" and j["scaling"] == "weak"
+    assert j["single_gpu_same_batch"]["steps"] == 2 and "weak_scaling_efficiency" in j  # the same-run reference of the ratio
+    assert j["value"] is None and "REHEARSAL" in j["data"]
+
+
+def test_bench_exits_nonzero_when_a_rank_dies_mid_step():
+    """World 2, rank 1 raises inside its second step while rank 0 sits in the gather: the launcher must come back with a
+    non-zero code (no hang at the barrier) and must not print a result line."""
+    import time
+
+    t0 = time.time()
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "0", "--batch", "2"],
+                                {"AXW_BENCH_FAIL_RANK": "1", "AXW_BENCH_TIMEOUT_S": "120"})
+    assert rc != 0 and not lines, (rc, lines)
+    assert "injected failure" in err
+    assert time.time() - t0 < 200

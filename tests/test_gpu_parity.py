@@ -53,6 +53,30 @@ def test_frontend_seeded_clips_vs_oracle(engine, oracle_mod, clip, n):
     assert np.all(mel[:, min(nf, 3000):] == 0.0)
 
 
+def test_frontend_long_clip_vs_reference_golden(engine, oracle_mod):
+    """75 s input, loudest second at 70 s: beyond the 30 s window and beyond the engine's 60 s staging row. The clamp
+    floor of the 3000 kept frames comes from the maximum over ALL 7501 frames (Whisper.cpp:158-172); golden from the
+    reference's own librosa.h build (tests/golden/make_frontend_goldens.py)."""
+    import modelgen
+
+    g = np.load(os.path.join(GOLDEN, "frontend_long75s_loud70.npz"))
+    x = modelgen.synth_long_clip(75, 70)
+    mel = engine.compute_mel(x)
+    err = np.abs(mel[:, g["idx"]] - g["mel_sub"]).max()
+    ref, _, mmax = oracle_mod.log_mel(x, 80)
+    err_all = np.abs(mel - ref).max()
+    print("frontend 75 s: vs reference golden", err, "vs oracle (all frames)", err_all)
+    assert err < 2e-4 and err_all < 2e-4
+    # the same clip through the transcription entry point (staging rows + packed tails) next to a 10-minute clip in one
+    # batch: both get their own floor
+    y = np.concatenate([modelgen.synth_clip(9, 9 * 60 * 16000) * np.float32(0.02), modelgen.synth_clip(9, 16000)])
+    for clip in (x, y):
+        ref, _, _ = oracle_mod.log_mel(clip, 80)
+        assert np.abs(engine.compute_mel(clip) - ref).max() < 2e-4
+    ids_pair = engine.run_tokens_batch([x, y, x[:480000]], max_new=6)
+    assert ids_pair[0] == engine.run_tokens(x, max_new=6) and ids_pair[1] == engine.run_tokens(y, max_new=6)
+
+
 def test_frontend_silence_and_dc(engine, oracle_mod):
     for x in (np.zeros(16000, np.float32), np.full(32000, 0.25, np.float32)):
         ref, _, _ = oracle_mod.log_mel(x, 80)

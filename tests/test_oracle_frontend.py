@@ -52,6 +52,21 @@ def test_seeded_clips(oracle_mod, name, clip, n):
     assert np.all(mel[:, min(nf, 3000):] == 0.0)
 
 
+def test_long_clip_floor_comes_from_all_frames(oracle_mod):
+    """75 s, loudest second at 70 s (Whisper.cpp:158-172: the maximum is taken over ALL frames of the input, then 3000
+    are kept): golden from the reference's own front-end; cutting the input anywhere before 70 s changes the floor."""
+    import modelgen
+
+    g = np.load(os.path.join(GOLDEN, "frontend_long75s_loud70.npz"))
+    x = modelgen.synth_long_clip(75, 70)
+    mel, nf, mmax = oracle_mod.log_mel(x, 80)
+    assert nf == int(g["n_frames"]) == 7501 and len(x) == int(g["n_samples"])
+    assert abs(mmax - float(g["mmax"])) < 1e-5
+    assert np.abs(mel[:, g["idx"]] - g["mel_sub"]).max() < TOL
+    cut, _, mmax_cut = oracle_mod.log_mel(x[:960000], 80)
+    assert mmax_cut < mmax - 1.0 and np.abs(cut - mel).max() > 0.1  # the cap this round removed WAS a result difference
+
+
 def test_against_live_reference_build(oracle_mod):
     """Where oracle/_ref was built (the container with /root/reference) compare live, full frames."""
     if oracle_mod.ref_lib() is None:

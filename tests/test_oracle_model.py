@@ -54,6 +54,27 @@ def test_teacher_forcing_equals_free_running(oracle_mod, micro_case):
     assert ids2 == ids and np.array_equal(lg, lg2)
 
 
+@pytest.mark.parametrize("policy", [False, True, "fp16"])
+def test_literal_mask_graph_equals_the_causal_form(oracle_mod, micro_case, policy):
+    """export_onnx.py:124-137 executed as written — scores against all 448 cache rows, rows >= offset filled with -60000,
+    a separate column for the current token, one fp32 softmax over 449 values, w @ v_cache + w1 @ v1, host-side cache
+    append afterwards (Whisper.cpp:328-342) — against the causal form (keys 0..offset, current token appended first)
+    that the oracle's default path and the engine's kernels use (SURVEY A.2 argues the two equal; here they are run):
+    identical ids and bit-identical logits over a full 444-step context, in fp32 and under both 16-bit storage policies."""
+    a = oracle_mod.Oracle(micro_case.cfg, micro_case.weights, bf16_policy=policy)
+    b = oracle_mod.Oracle(micro_case.cfg, micro_case.weights, bf16_policy=policy, literal_mask=True)
+    ck, cv = a.encoder(_mel_for("micro_demo"))
+    ids, lg = a.greedy(ck, cv, "zh", max_new=444, want_logits=True)
+    forced = ids if len(ids) >= 440 else (ids + [(7 * i + 11) % 50257 for i in range(444 - len(ids))])
+    ids_a, lg_a = a.greedy(ck, cv, "zh", max_new=444, forced=forced, want_logits=True)
+    ids_b, lg_b = b.greedy(ck, cv, "zh", max_new=444, forced=forced, want_logits=True)
+    assert len(lg_a) == 445 and ids_a == ids_b
+    assert np.array_equal(lg_a, lg_b), float(np.abs(lg_a - lg_b).max())
+    # free-running too (its own eot / context stop)
+    assert b.greedy(ck, cv, "zh", max_new=444) == ids
+    del lg
+
+
 def test_bf16_policy_is_close_to_fp32(oracle_mod, micro_case):
     ck, cv = micro_case.oracle_fp32.encoder(_mel_for("micro_demo"))
     ckb, cvb = micro_case.oracle_bf16.encoder(_mel_for("micro_demo"))

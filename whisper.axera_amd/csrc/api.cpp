@@ -27,6 +27,13 @@
 
 using Engine = axw::IEngine;
 
+namespace axw {
+std::mutex& persistent_launch_mutex(int device) {
+  static std::mutex mu[64];  // one per device: engines of different GPUs never wait for each other
+  return mu[device & 63];
+}
+}  // namespace axw
+
 namespace {
 thread_local std::string g_init_error;
 struct Handle {
@@ -289,7 +296,15 @@ AX_WHISPER_API int AX_WHISPER_GetConfigInt(AX_WHISPER_HANDLE handle, const char*
 
 AX_WHISPER_API const char* AX_WHISPER_LastError(AX_WHISPER_HANDLE handle) {
   Handle* h = H(handle);
-  return h ? h->last_error.c_str() : g_init_error.c_str();
+  if (!h) return g_init_error.c_str();
+  // a copy taken under the lock: server threads and device workers may set_error() concurrently, and the pointer handed
+  // out must not dangle when they do (valid until this thread's next call)
+  thread_local std::string copy;
+  {
+    std::lock_guard<std::mutex> lk(h->err_mu);
+    copy = h->last_error;
+  }
+  return copy.c_str();
 }
 
 AX_WHISPER_API int AX_WHISPER_SetStream(AX_WHISPER_HANDLE handle, void* hip_stream) {

@@ -29,7 +29,7 @@ typedef _Float16 h16;
 constexpr const char* kDtypeName = "fp16";
 #else
 typedef __bf16 h16;
-constexpr const char* kDtypeName = "h16";
+constexpr const char* kDtypeName = "bf16";
 #endif
 typedef h16 h16x4 __attribute__((ext_vector_type(4)));
 typedef h16 h16x8 __attribute__((ext_vector_type(8)));
@@ -239,6 +239,8 @@ struct FrontendParams {
   h16* mel_tm;            // device [batch][mel_rows][n_mels] h16 time-major, row 0 = left pad, or nullptr
   int mel_rows;
   int max_frames;          // frames computed per clip (<= 3001)
+  const float* overflow;   // samples beyond `stride` of clips longer than the staging row (device, packed), or nullptr:
+  const long long* over_off;  //   sample j >= stride of clip b is overflow[over_off[b] + j - stride] (device [batch])
   int openai;              // 1: the fp32 ONNX lineage's front-end (SURVEY A.1 column 3, generate_data.py:162-176): clip
                            // zero-padded / trimmed to 30 s before the STFT, last frame dropped, no zero fill
 };
@@ -398,7 +400,7 @@ size_t decode_persistent_gran_bytes(int d_model, int grid);   // granule area; t
 hipError_t launch_decode_persistent(const PersistParams& p, int d_model, int grid, hipStream_t s);
 
 // weight preparation (device): raw file dtype -> h16 / fp32, with the layout changes the kernels want
-void launch_convert_to_h16(const void* src, int src_dtype /*0 f32,1 h16,2 f16*/, h16* dst, long n, hipStream_t s);
+void launch_convert_to_h16(const void* src, int src_dtype /*0 f32,1 bf16,2 f16*/, h16* dst, long n, hipStream_t s);
 void launch_convert_to_f32(const void* src, int src_dtype, float* dst, long n, hipStream_t s);
 // conv weight [Cout][Cin][3] -> [Cout][Kpad] with k-major taps: dst[n][k*Cin + c]
 void launch_conv_weight_pack(const void* src, int src_dtype, h16* dst, int cout, int cin, int kpad, hipStream_t s);

@@ -276,8 +276,10 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
         __hip_atomic_store(mine + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // acq_rel at agent scope: the ticket releases this split's partials and, for whoever draws the last one, acquires
+      // everybody else's — the ordering no longer leans on write-through behaviour or on where the compiler puts the loads
       unsigned ticket = 0;
-      if (tid == 0) ticket = __hip_atomic_fetch_add(p.mcnt + b * p.n_head + head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) ticket = __hip_atomic_fetch_add(p.mcnt + b * p.n_head + head, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       ticket = __builtin_amdgcn_readfirstlane(ticket);
       if (ticket != (unsigned)p.n_split - 1u) return;  // (the whole wave; the other waves are past their last use of LDS)
       float M = -INFINITY, Ls = 0.f, O = 0.f;

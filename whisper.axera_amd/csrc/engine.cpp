@@ -139,6 +139,7 @@ void Engine::destroy() {
   for (void* p : allocs_) (void)hipFree(p);
   allocs_.clear();
   if (load_stage_) { (void)hipFree(load_stage_); load_stage_ = nullptr; }
+  if (d_over_) { (void)hipFree(d_over_); d_over_ = nullptr; over_cap_ = 0; }
   if (h_poll_) { (void)hipHostFree(h_poll_); h_poll_ = nullptr; }
   for (auto& e : ev_) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   for (auto& e : ev_join_) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -491,10 +492,11 @@ void Engine::ensure_capacity(int batch) {
   const int B = batch, d = cfg_.n_text_state, nm = cfg_.n_mels, H = cfg_.n_text_head, L = cfg_.n_text_layer;
   const int T = cfg_.n_audio_ctx, Tc = cfg_.n_text_ctx;
   auto A = [&](size_t bytes, bool zero = false) { void* p = dalloc(bytes, zero); slot_allocs_.push_back(p); return p; };
-  pcm_stride_ = 2 * 480000;  // up to 60 s per clip is kept for the global-max scan; the window itself is 30 s
+  pcm_stride_ = 2 * 480000;  // staging row of a clip (60 s; the window itself is 30 s); longer clips put their tails into d_over_
   d_pcm_ = (float*)A((size_t)B * pcm_stride_ * 4, true);
   HIP_CHECK(hipHostMalloc((void**)&h_pcm_, (size_t)B * pcm_stride_ * 4, hipHostMallocDefault));
   d_nsamp_ = (int*)A((size_t)B * 4);
+  d_over_off_ = (long long*)A((size_t)B * 8, true);
   d_gmax_ = (unsigned*)A((size_t)B * 4);
   d_logmel_ = (float*)A((size_t)B * kFramesOut * nm * 4);
   d_mel_ref_ = (float*)A((size_t)B * nm * kFramesOut * 4);
@@ -545,6 +547,24 @@ void Engine::ensure_capacity(int batch) {
 
 // ------------------------------------------------------------------------------ front-end
 void Engine::upload_pcm(const float* const* pcm, const int* n_samples, int batch) {
+  // Clips longer than a staging row: the reference computes the log-mel of the WHOLE input and takes the maximum over
+  // all of its frames before it keeps 3000 of them (Whisper.cpp:158-172), so every sample counts for the clamp floor.
+  // The first pcm_stride_ samples go through the pinned staging rows as always; the tails are packed into d_over_.
+  std::vector<long long> off(batch, 0);
+  size_t over_total = 0;
+  for (int b = 0; b < batch; ++b) {
+    if (n_samples[b] > (1 << 30)) throw std::runtime_error("clip " + std::to_string(b) + ": more than 2^30 samples");
+    off[b] = (long long)over_total;
+    if (n_samples[b] > pcm_stride_) over_total += (size_t)n_samples[b] - (size_t)pcm_stride_;
+  }
+  over_used_ = over_total > 0;
+  if (over_total > over_cap_) {
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    if (d_over_) { (void)hipFree(d_over_); d_over_ = nullptr; over_cap_ = 0; }
+    HIP_CHECK(hipMalloc((void**)&d_over_, over_total * 4));
+    over_cap_ = over_total;
+  }
+  if (over_used_) HIP_CHECK(hipMemcpy(d_over_off_, off.data(), (size_t)batch * 8, hipMemcpyHostToDevice));
   for (int b = 0; b < batch; ++b) {
     const int n = (int)std::min<long>(n_samples[b], pcm_stride_);
     // pcm_data is copied, not retained (api.cpp:151-152). The ABI asks for samples in [-1, 1] (ax_whisper_api.h:89 of the
@@ -554,18 +574,24 @@ void Engine::upload_pcm(const float* const* pcm, const int* n_samples, int batch
     memcpy(dst, pcm[b], (size_t)n * 4);
     unsigned bad = 0;
     for (int i = 0; i < n; ++i) bad |= !std::isfinite(dst[i]);  // vectorises: ~0.1 ms per 30 s clip
+    const float* tail = pcm[b] + n;
+    const size_t n_tail = (size_t)n_samples[b] - (size_t)n;
+    for (size_t i = 0; i < n_tail; ++i) bad |= !std::isfinite(tail[i]);
     if (bad) throw std::runtime_error("clip " + std::to_string(b) + ": non-finite PCM sample (NaN or Inf)");
     HIP_CHECK(hipMemcpyAsync(d_pcm_ + (size_t)b * pcm_stride_, h_pcm_ + (size_t)b * pcm_stride_, (size_t)n * 4,
                              hipMemcpyHostToDevice, stream()));
+    if (n_tail) HIP_CHECK(hipMemcpy(d_over_ + off[b], tail, n_tail * 4, hipMemcpyHostToDevice));  // rare path: pageable, synchronous
   }
 }
 
-void Engine::run_frontend(const float* d_pcm, int stride, const int* n_samples, int batch, bool want_ref_layout) {
+// staged: the clips came through upload_pcm (tails of clips beyond a staging row sit in d_over_); otherwise d_pcm is the
+// caller's device buffer and a clip ends at its row's end
+void Engine::run_frontend(const float* d_pcm, int stride, const int* n_samples, int batch, bool want_ref_layout, bool staged) {
   std::vector<int> ns(batch);
   int max_frames = 1;
   for (int b = 0; b < batch; ++b) {
     if (n_samples[b] < 1) throw std::runtime_error("empty audio clip");
-    ns[b] = std::min(n_samples[b], stride);
+    ns[b] = staged ? n_samples[b] : std::min(n_samples[b], stride);
     max_frames = std::max(max_frames, 1 + ns[b] / kHop);
   }
   if (feature_openai_) max_frames = kFramesOut;
@@ -577,6 +603,7 @@ void Engine::run_frontend(const float* d_pcm, int stride, const int* n_samples, 
   p.logmel = d_logmel_; p.gmax = d_gmax_;
   p.mel_ref = want_ref_layout ? d_mel_ref_ : nullptr;
   p.mel_tm = d_mel_tm_; p.mel_rows = mel_rows_; p.max_frames = max_frames; p.openai = feature_openai_ ? 1 : 0;
+  if (staged && over_used_) { p.overflow = d_over_; p.over_off = d_over_off_; }
   launch_frontend(p, stream());
 }
 
@@ -1100,8 +1127,8 @@ int Engine::greedy_loop(int batch, int max_new, const int* max_new_clip) {
 int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float* d_logits, int* d_argmax, int slot) {
   // The launch needs every workgroup resident at once (one per CU): two of them in flight on one GPU could each hold
   // part of the CUs and starve the other until both give up. Handles of one process on one device take turns.
-  static std::mutex launch_mu[64];  // one per device: engines of different GPUs never wait for each other
-  std::lock_guard<std::mutex> launch_lock(launch_mu[device_ & 63]);
+  // (one mutex per device, shared by the bfloat16 and the half build of this file: iengine.hpp)
+  std::lock_guard<std::mutex> launch_lock(persistent_launch_mutex(device_));
   hipStream_t s = stream();
   const int Tc = cfg_.n_text_ctx, H = cfg_.n_text_head;
   PersistParams p{};
@@ -1172,7 +1199,7 @@ void Engine::run_tokens(const float* const* pcm, const float* d_pcm, int d_strid
   HIP_CHECK(hipEventRecord(ev_[0], s));
   if (pcm) {
     upload_pcm(pcm, n_samples, batch);
-    run_frontend(d_pcm_, (int)pcm_stride_, n_samples, batch, false);
+    run_frontend(d_pcm_, (int)pcm_stride_, n_samples, batch, false, true);
   } else {
     run_frontend(d_pcm, d_stride, n_samples, batch, false);
   }
@@ -1226,7 +1253,7 @@ void Engine::compute_mel(const float* pcm, int n_samples, float* mel_out) {
   ensure_capacity(1);
   const float* arr[1] = {pcm};
   upload_pcm(arr, &n_samples, 1);
-  run_frontend(d_pcm_, (int)pcm_stride_, &n_samples, 1, true);
+  run_frontend(d_pcm_, (int)pcm_stride_, &n_samples, 1, true, true);
   HIP_CHECK(hipMemcpyAsync(mel_out, d_mel_ref_, (size_t)cfg_.n_mels * kFramesOut * 4, hipMemcpyDeviceToHost, stream()));
   HIP_CHECK(hipStreamSynchronize(stream()));
 }
@@ -1269,12 +1296,17 @@ void Engine::decode_forced(int batch, const int32_t* forced, int n_forced, float
   if (n_forced < 0 || n_forced + 4 > cfg_.n_text_ctx) throw std::runtime_error("decode_forced: n_forced out of range");
   hipStream_t s = stream();
   const int nv = cfg_.n_vocab, rows = n_forced + 1;
-  int* d_forced = nullptr;
-  float* d_logits = nullptr;
-  int* d_arg = nullptr;
-  HIP_CHECK(hipMalloc((void**)&d_forced, std::max<size_t>((size_t)batch * n_forced * 4, 256)));
-  HIP_CHECK(hipMalloc((void**)&d_arg, (size_t)batch * rows * 4));
-  if (logits) HIP_CHECK(hipMalloc((void**)&d_logits, (size_t)batch * rows * nv * 4));
+  // device scratch of this call, freed on every path out (a HIP_CHECK below may throw)
+  struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+  } b_forced, b_arg, b_logits;
+  HIP_CHECK(hipMalloc(&b_forced.p, std::max<size_t>((size_t)batch * n_forced * 4, 256)));
+  HIP_CHECK(hipMalloc(&b_arg.p, (size_t)batch * rows * 4));
+  if (logits) HIP_CHECK(hipMalloc(&b_logits.p, (size_t)batch * rows * nv * 4));
+  int* d_forced = (int*)b_forced.p;
+  int* d_arg = (int*)b_arg.p;
+  float* d_logits = (float*)b_logits.p;
   if (n_forced) HIP_CHECK(hipMemcpy(d_forced, forced, (size_t)batch * n_forced * 4, hipMemcpyHostToDevice));
   bool done = false;
   if (batch == 1 && persistent_usable()) {
@@ -1290,9 +1322,6 @@ void Engine::decode_forced(int batch, const int32_t* forced, int n_forced, float
   HIP_CHECK(hipStreamSynchronize(s));
   if (logits) HIP_CHECK(hipMemcpy(logits, d_logits, (size_t)batch * rows * nv * 4, hipMemcpyDeviceToHost));
   if (argmax_ids) HIP_CHECK(hipMemcpy(argmax_ids, d_arg, (size_t)batch * rows * 4, hipMemcpyDeviceToHost));
-  (void)hipFree(d_forced);
-  (void)hipFree(d_arg);
-  if (d_logits) (void)hipFree(d_logits);
 }
 
 void Engine::decode_greedy(int batch, int max_new, const int* max_new_clip, int32_t* ids, int* n_ids) {

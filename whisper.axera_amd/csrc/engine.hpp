@@ -59,7 +59,7 @@ class Engine final : public IEngine {
   void ensure_capacity(int batch);
   void free_slot_buffers();
   void upload_pcm(const float* const* pcm, const int* n_samples, int batch);
-  void run_frontend(const float* d_pcm, int stride, const int* n_samples, int batch, bool want_ref_layout);
+  void run_frontend(const float* d_pcm, int stride, const int* n_samples, int batch, bool want_ref_layout, bool staged = false);
   void run_encoder(int batch);
   void reset_decode_state(int batch, const int* max_new_clip = nullptr);
   void enqueue_decode_step(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits, long logits_stride,
@@ -110,6 +110,9 @@ class Engine final : public IEngine {
   int cap_ = 0;
   int t_pad_ = 1536, mel_rows_ = 3004, h1_rows_ = 3002;
   float* d_pcm_ = nullptr; long pcm_stride_ = 0; float* h_pcm_ = nullptr;
+  // clips longer than a staging row (60 s): their tails, packed, so that the clamp floor comes from ALL frames of the
+  // input however long it is (Whisper.cpp:158-172); grown on demand, empty for ordinary requests
+  float* d_over_ = nullptr; size_t over_cap_ = 0; long long* d_over_off_ = nullptr; bool over_used_ = false;
   int* d_nsamp_ = nullptr; unsigned* d_gmax_ = nullptr; float* d_logmel_ = nullptr; float* d_mel_ref_ = nullptr;
   h16 *d_mel_tm_ = nullptr, *d_h1_ = nullptr, *d_ln_ = nullptr, *d_q_ = nullptr, *d_k_ = nullptr, *d_vt_ = nullptr,
        *d_attn_ = nullptr, *d_ffn_ = nullptr;

@@ -4,6 +4,8 @@
 // clamp/normalise/pad of Whisper::preprocess (cpp/src/Whisper.cpp:151-184):
 //   reflect pad 200 | periodic Hann | 400-pt DFT bins 0..200 | re^2+im^2 | Slaney mel GEMM |
 //   log10(max(.,1e-10)) | global max over ALL frames | max(., gmax-8) | (.+4)/4 | zero-fill to 3000
+// "ALL frames" means all frames of the input however long it is (Whisper.cpp:158-172 takes the maximum before it
+// truncates to 3000 frames): the grid covers every frame of the longest clip, frames past 3000 only feed the maximum.
 //
 // Kernel 1 (stft_mel_kernel): one workgroup = 32 consecutive frames of one clip. The windowed
 // frames are staged in LDS ([32][400] f32, 51 KB), the 400-point DFT is evaluated directly with
@@ -54,7 +56,9 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(FrontendParams p, const f
       if (j < 0) j = -j;                              // librosa.h:51  x[left - i]
       if (j >= n) j = 2 * n - 2 - j;                  // librosa.h:54  x[size - 2 - i + left]
       j = min(max(j, 0), n - 1);                      // clips shorter than the pad: stay in bounds
-      v = (j < n_real ? x[j] : 0.f) * p.window[k];    // librosa.h:92 (openai mode: zeros behind the clip's end)
+      float smp = 0.f;                                // librosa.h:92 (openai mode: zeros behind the clip's end)
+      if (j < n_real) smp = j < p.stride ? x[j] : p.overflow[p.over_off[b] + (j - p.stride)];  // clips beyond the staging row
+      v = smp * p.window[k];
     }
     xw[i] = v;
   }

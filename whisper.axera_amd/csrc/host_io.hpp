@@ -9,6 +9,7 @@
 //     int16 -> /32768; ax_whisper_api.cpp:105-113: stereo -> (L+R)/2; AIFF: AudioFile.h:643-776)
 #pragma once
 
+#include <array>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -226,13 +227,14 @@ class SafeTensors {
 
 // ------------------------------------------------------------------------------- tokens
 inline bool base64_decode(const std::string& in, std::string& out) {
-  static int8_t map[256]; static bool init = false;
-  if (!init) {
-    memset(map, -1, sizeof(map));
+  // a magic static: built once, thread-safe (the engines of AX_WHISPER_InitMulti load their token tables side by side)
+  static const std::array<int8_t, 256> map = [] {
+    std::array<int8_t, 256> m;
+    m.fill(-1);
     const char* a = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
-    for (int i = 0; i < 64; ++i) map[(unsigned char)a[i]] = (int8_t)i;
-    init = true;
-  }
+    for (int i = 0; i < 64; ++i) m[(unsigned char)a[i]] = (int8_t)i;
+    return m;
+  }();
   out.clear();
   uint32_t acc = 0; int bits = 0;
   for (unsigned char c : in) {

@@ -50,6 +50,11 @@ class IEngine {
   std::mutex mu_;
 };
 
+// One persistent decode launch at a time per GPU, whichever build (bfloat16 / half) the launching handle belongs to:
+// the launch needs every CU, and two of them co-resident would each hold part of the chip until both give up. Defined
+// once in api.cpp (engine.cpp is compiled twice).
+std::mutex& persistent_launch_mutex(int device);
+
 IEngine* make_engine_bf16(const std::string& model_type, const std::string& model_path, const std::string& language, int device, int max_batch);
 IEngine* make_engine_f16(const std::string& model_type, const std::string& model_path, const std::string& language, int device, int max_batch);
 

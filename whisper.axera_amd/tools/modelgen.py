@@ -269,6 +269,17 @@ def synth_clip(i: int, n_samples: int = 480000) -> np.ndarray:
     return np.clip(x, -1.0, 1.0).astype(np.float32)
 
 
+def synth_long_clip(seconds: int = 75, loud_at: int = 70) -> np.ndarray:
+    """A clip longer than the 30 s window AND longer than the engine's 60 s staging row whose loudest second lies
+    behind both: synthetic clip 8 at 1/20 of its level, with second `loud_at` at full level. The reference takes
+    the log-mel maximum over ALL frames of the input before it keeps the first 3000 (Whisper.cpp:158-172), so the
+    clamp floor of the kept frames is set by audio that is itself cut away."""
+    x = synth_clip(8, seconds * 16000).astype(np.float32)
+    g = np.full(len(x), np.float32(0.05))
+    g[loud_at * 16000:(loud_at + 1) * 16000] = np.float32(1.0)
+    return (x * g).astype(np.float32)
+
+
 if __name__ == "__main__":
     import argparse
 
