@@ -503,9 +503,15 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   int tok = AXW_COLD(sot)[0];
   int n_out = 0, n_done = 0, steps_run = 0;
 
-  auto ca_unit_of = [&](int l) -> int {  // cross-attention unit of this workgroup in layer l, or -1
+  // Cross-attention unit of this workgroup in the t-th layer of the LAUNCH (t = step * L + l), or -1. The units of
+  // consecutive layers take consecutive ranges of NU workgroups modulo NS, counted over the whole launch and not per
+  // step: 2 * NU <= NS then keeps the two units of any workgroup at least two layers apart across the step boundary
+  // as well. (Counted per step, the last layer's range wrapped onto the first layer's of the next step whenever
+  // L * NU > NS — large-v3-turbo: 4 x 60 units on 176 workgroups — and a workgroup staged the next step's K tiles over
+  // the ones its last-layer unit had not used yet: logits off by 4e-2 at every step of that model.)
+  auto ca_unit_of = [&](int t) -> int {
     if (wg >= NS) return -1;
-    int r = (wg - l * NU) % NS;
+    int r = (wg - (int)(((long)t * NU) % NS)) % NS;
     if (r < 0) r += NS;
     return r < NU ? r : -1;
   };
@@ -628,7 +634,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_TL(4)
         }
         // ---- cross-attention unit: collect the head's query
-        const int cu = ca_unit_of(l);
+        const int cu = ca_unit_of(step * L + l);
         if (cu >= 0) {
           const int ca_head = cu / kCrossSplit;
           unsigned v[2];
@@ -811,12 +817,12 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         const float *b_qkv = FL + DecArena::F_B_QKV * D, *b_o = FL + DecArena::F_B_O * D, *b_cq = FL + DecArena::F_B_CQ * D,
                     *b_co = FL + DecArena::F_B_CO * D, *b_fc1 = FL + DecArena::F_B_FC1 * D, *b_fc2 = FL + DecArena::F_B_FC2 * D;
         const unsigned tag = (unsigned)(step * L + l + 1);
-        const int cu = ca_unit_of(l);
+        const int cu = ca_unit_of(step * L + l);
         // Cross K/V tiles are constant during the utterance: the unit this workgroup runs in the NEXT layer is staged
         // into LDS now (LDS-DMA, 16 x 1 KiB per wave), a few instructions after each publish of this layer, so that no
-        // publish waits behind a burst of DMA requests. Units of one workgroup are at least two layers apart.
+        // publish waits behind a burst of DMA requests. Units of one workgroup are at least two layers apart (ca_unit_of).
         const int ln = l + 1 < L ? l + 1 : 0;
-        const int cun = ca_unit_of(ln);
+        const int cun = ca_unit_of(step * L + l + 1);
         auto kv_piece = [&](int i0, int i1) {
           if (cun < 0) return;
           const int kb = (cun % kCrossSplit) * NCW + cw;  // 64-key block of this wave (24 blocks = t_pad 1536)

@@ -276,10 +276,20 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
         __hip_atomic_store(mine + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      // acq_rel at agent scope: the ticket releases this split's partials and, for whoever draws the last one, acquires
-      // everybody else's — the ordering no longer leans on write-through behaviour or on where the compiler puts the loads
+      // The hand-off is the first row of MI355X_MICROARCH.md's table of hand-offs that need no acquire: every payload
+      // store is sc1 (write-through), the storing wave drains vmcnt, ONE lane adds to an agent-scope counter, and the
+      // workgroup whose add came last — told by the value its add returned — reads the others' records with sc1 loads
+      // after that add has returned (the loads sit behind a branch on the returned value; the signal fences pin the
+      // compiler's ordering on both sides). An acq_rel RMW instead (buffer_wbl2 + buffer_inv per workgroup, what the C++
+      // memory model would ask for) was measured at turbo dims, 16 clips, 2 splits: decode 151.5 -> 197.0 ms.
+      // AX_WHISPER_STRICT_TICKET=1 selects it.
       unsigned ticket = 0;
-      if (tid == 0) ticket = __hip_atomic_fetch_add(p.mcnt + b * p.n_head + head, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      if (tid == 0) {
+        if (p.strict_ticket) ticket = __hip_atomic_fetch_add(p.mcnt + b * p.n_head + head, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        else ticket = __hip_atomic_fetch_add(p.mcnt + b * p.n_head + head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
       ticket = __builtin_amdgcn_readfirstlane(ticket);
       if (ticket != (unsigned)p.n_split - 1u) return;  // (the whole wave; the other waves are past their last use of LDS)
       float M = -INFINITY, Ls = 0.f, O = 0.f;

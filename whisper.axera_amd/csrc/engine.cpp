@@ -32,6 +32,11 @@ static int logits_rt() {
   return v;
 }
 
+static int strict_ticket() {
+  static const int v = [] { const char* e = getenv("AX_WHISPER_STRICT_TICKET"); return e && e[0] == '1' ? 1 : 0; }();
+  return v;
+}
+
 static int dtype_code(const std::string& d) { return d == "F32" ? 0 : d == "BF16" ? 1 : 2; }
 
 // host: the bits of one stored h16 value -> float (bfloat16: the upper half of the fp32 pattern; half: IEEE binary16)
@@ -873,6 +878,7 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
       a.n_split = cross_split;
       a.mpart = d_attn_mpart_ + (long)b0 * H * kCrossSplitMax * 66;
       a.mcnt = d_attn_mcnt_ + (long)b0 * H;
+      a.strict_ticket = strict_ticket();
       a.x = x; a.ln_w = w.cross_ln_w; a.ln_b = w.cross_ln_b; a.wq = w.w_cq; a.bq = w.b_cq;
       if (step_mask_ & 2) launch_decode_attention(a, s);
     } else {
@@ -958,6 +964,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
       a.n_split = c;
       a.mpart = d_attn_mpart_;
       a.mcnt = d_attn_mcnt_;
+      a.strict_ticket = strict_ticket();
     }
     if (step_mask_ & 2) launch_decode_attention(a, s);
   };
