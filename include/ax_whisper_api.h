@@ -120,6 +120,33 @@ AX_WHISPER_API int AX_WHISPER_DecodeGreedy(AX_WHISPER_HANDLE handle, int batch, 
  *  (Whisper.cpp:219-222). A finished clip keeps its slot but no longer streams its K/V. */
 AX_WHISPER_API int AX_WHISPER_DecodeGreedyRagged(AX_WHISPER_HANDLE handle, int batch, int max_new,
                                                  const int* max_new_clip, int32_t* ids, int* n_ids);
+/** ids -> the text RunPCM* would have returned for them: detokenised bytes + the reference's zh post-pass (OpenCC t2s,
+ *  Whisper.cpp:224-236) when its data files were found. *result is malloc'd; the caller frees it. */
+AX_WHISPER_API int AX_WHISPER_Transcript(AX_WHISPER_HANDLE handle, const int32_t* ids, int n, char** result);
+
+/* ---- additions: utterance slots that are refilled while the others decode (continuous batching) ---------------
+ * The reference decodes ONE utterance per call and stops it at its own eot (Whisper.cpp:207-222); its server hands
+ * requests to the handle one by one (WhisperHTTPServer.hpp:37-100). Here every utterance slot has its own decode offset,
+ * so a slot whose clip has finished can take the next clip while the other slots decode on: no clip waits for the
+ * slowest one of a micro-batch. Primary engine of the handle (one handle per GPU, as whisper_srv --devices runs them).
+ *   StreamOpen(n_slots)  all slots idle; the batched entry points above are refused until StreamClose
+ *   StreamAdmit(slot..)  front-end + encoder of one clip on a second stream into an idle slot's cross-K/V; the slot joins
+ *                        the decode loop at the first StreamStep after its encoder has finished
+ *   StreamStep(n_steps)  n decoder steps over all slots (captured step graph); returns the slots that have finished
+ *   StreamCollect(slot)  ids of a finished slot; the slot is idle again */
+AX_WHISPER_API int AX_WHISPER_StreamOpen(AX_WHISPER_HANDLE handle, int n_slots);
+/** max_new <= 0: until eot or the end of the context. pcm is copied before the call returns. -1 if the slot is busy. */
+AX_WHISPER_API int AX_WHISPER_StreamAdmit(AX_WHISPER_HANDLE handle, int slot, const float* pcm, int num_samples, int max_new);
+/** `count` clips at once into `count` idle slots (any slots, any order): one front-end + encoder pass for all of them —
+ *  a batched pass costs a fraction of count one-clip passes. max_new may be NULL. -1 if any slot is busy (none admitted). */
+AX_WHISPER_API int AX_WHISPER_StreamAdmitBatch(AX_WHISPER_HANDLE handle, const int* slots, const float* const* pcm,
+                                               const int* num_samples, const int* max_new, int count);
+/** finished_slots: host [n_slots]; *n_finished: how many were written. Slots stay "finished" until collected. */
+AX_WHISPER_API int AX_WHISPER_StreamStep(AX_WHISPER_HANDLE handle, int n_steps, int* finished_slots, int* n_finished);
+/** ids: host [n_text_ctx]. */
+AX_WHISPER_API int AX_WHISPER_StreamCollect(AX_WHISPER_HANDLE handle, int slot, int32_t* ids, int* n_ids);
+AX_WHISPER_API int AX_WHISPER_StreamClose(AX_WHISPER_HANDLE handle);
+
 /** Stage timings of the last Run* / DecodeGreedy* call, ms (hipEvent): [0] front-end, [1] encoder,
  *  [2] decode loop, [3] whole call (wall), [4] decode steps executed. */
 AX_WHISPER_API int AX_WHISPER_GetTimings(AX_WHISPER_HANDLE handle, float* out5);

@@ -88,8 +88,11 @@ def test_turbo_shaped_model(built_lib, oracle_mod, tmp_path):
     e.close()
 
 
-def test_server_asr_round_trip(built_lib, micro_case):
-    """whisper_srv: POST /asr with raw f32 PCM (WhisperHTTPServer.hpp:37-100), JSON reply, 400s, concurrent clients."""
+@pytest.mark.parametrize("scheduler", ["slots", "batches"])
+def test_server_asr_round_trip(built_lib, micro_case, scheduler):
+    """whisper_srv: POST /asr with raw f32 PCM (WhisperHTTPServer.hpp:37-100), JSON reply, 400s, concurrent clients —
+    through both schedulers (refilled slots / micro-batches) — and the connection limits: body cap, receive timeout,
+    a body that ends early."""
     import json
     import socket
     import threading
@@ -103,7 +106,8 @@ def test_server_asr_round_trip(built_lib, micro_case):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    proc = subprocess.Popen([srv, "--port", str(port), "-t", "micro", "-p", micro_case.root, "-l", "zh", "--max_batch", "4"],
+    proc = subprocess.Popen([srv, "--port", str(port), "-t", "micro", "-p", micro_case.root, "-l", "zh", "--max_batch", "4",
+                             "--scheduler", scheduler, "--max_body_mb", "2", "--recv_timeout_s", "2"],
                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     try:
         base = f"http://127.0.0.1:{port}"
@@ -146,8 +150,38 @@ def test_server_asr_round_trip(built_lib, micro_case):
         [t.start() for t in th]
         [t.join() for t in th]
         assert out[2][0] == 400 and all(o[0] == 200 and o[1]["text"] == js["text"] for i, o in enumerate(out) if i != 2)
+        # nine requests at once on four slots: five of them wait in the queue and take slots as they free up
+        out = [None] * 9
+        th = [threading.Thread(target=lambda i=i: out.__setitem__(i, post(pcm.tobytes()))) for i in range(9)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert all(o[0] == 200 and o[1]["text"] == js["text"] for o in out)
+        # limits: a body above --max_body_mb is refused unread; a body that ends (or stalls) before its Content-Length is
+        # a 400, never a transcript of half a clip
+        def raw(payload, half_close, clen=40000):
+            c = socket.create_connection(("127.0.0.1", port), timeout=10)
+            c.sendall(b"POST /asr HTTP/1.1\r\nHost: x\r\nContent-Type: application/octet-stream\r\nContent-Length: %d\r\n\r\n" % clen + payload)
+            if half_close:
+                c.shutdown(socket.SHUT_WR)
+            data = b""
+            while True:
+                chunk = c.recv(65536)
+                if not chunk:
+                    break
+                data += chunk
+            c.close()
+            return data
+
+        assert b"413" in raw(b"", False, clen=3200000).split(b"\r\n")[0]  # answered on the headers alone, nothing of the body is read
+        t0 = time.time()
+        assert b"400" in raw(pcm.tobytes()[:20000], True).split(b"\r\n")[0]
+        r = raw(pcm.tobytes()[:20000], False)  # the peer just stops sending: --recv_timeout_s 2
+        assert b"400" in r.split(b"\r\n")[0] and b"incomplete" in r and time.time() - t0 < 8
+        h = json.load(urllib.request.urlopen(base + "/health", timeout=2))
+        assert h["status"] == "ok" and h["persistent_giveups"] == 0 and h["served"] >= 20 and h["busy_slots"] == 0 and h["devices"] == 1
     finally:
         proc.kill()
+        assert f"scheduler: {scheduler}" in proc.stdout.read(600)
 
 
 def test_server_one_batcher_per_device(built_lib, micro_case):

@@ -1,0 +1,94 @@
+"""GPU: utterance slots with their own decode offsets, refilled while the others decode (AX_WHISPER_Stream*).
+
+The reference stops each utterance at its own eot (Whisper.cpp:219-222) and its server takes requests one by one
+(WhisperHTTPServer.hpp:37-100). Here 32 clips with id budgets between 20 and 140 (budgets stand in for eot: synthetic
+weights never emit it) go through 8 slots: a slot that has finished takes the next clip while the other seven are in the
+middle of theirs, so slots sit at different offsets in every step. Every clip's ids must equal what the same clip yields
+(a) in an ordinary ragged batch of 8 (same kernels: bit-equal expected) and (b) on its own through the 1-clip path."""
+import numpy as np
+import pytest
+import torch  # noqa: F401
+
+from conftest import assert_ids_equal_or_tie
+
+pytestmark = pytest.mark.gpu
+
+
+def _clips_and_budgets(n):
+    import modelgen
+
+    lens = [480000, 200000, 77777, 480000, 123457, 16000, 300000, 480000]
+    clips = [modelgen.synth_clip(40 + i, lens[i % len(lens)]) for i in range(n)]
+    budgets = [20 + (37 * i) % 121 for i in range(n)]  # 20..140, no order
+    return clips, budgets
+
+
+def test_slots_refill_while_others_decode(built_lib, micro_case):
+    n_slots, n_clips = 8, 32
+    clips, budgets = _clips_and_budgets(n_clips)
+    e = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=n_slots)
+    try:
+        got, calls = e.run_stream(clips, n_slots, max_new=budgets, steps_per_call=4)
+        assert all(g is not None and len(g) == b for g, b in zip(got, budgets)), [len(g) for g in got]
+        # (a) the same clips as ordinary ragged batches of 8: same kernels at the same batch size -> the same ids
+        for g0 in range(0, n_clips, n_slots):
+            mels = np.stack([e.compute_mel(c) for c in clips[g0:g0 + n_slots]])
+            e.encode_mel(mels)
+            want = e.decode_greedy(n_slots, max_new=140, max_new_clip=budgets[g0:g0 + n_slots])
+            for i in range(n_slots):
+                assert got[g0 + i] == want[i], (g0 + i, got[g0 + i][:8], want[i][:8])
+        # (b) every clip on its own (1-clip path: other summation order; a difference must be a numerical tie)
+        same = 0
+        for i in range(n_clips):
+            alone = e.run_tokens(clips[i], max_new=budgets[i])
+            if alone == got[i]:
+                same += 1
+                continue
+            mel = e.compute_mel(clips[i])
+            ck, cv = micro_case.oracle_bf16.encoder(mel)
+            ids, lg = micro_case.oracle_bf16.greedy(ck, cv, "zh", max_new=budgets[i], want_logits=True)
+            assert_ids_equal_or_tie(e, mel, got[i], ids, lg, f"clip {i} through the slot stream")
+        print(f"{n_clips} clips through {n_slots} slots in {calls} step calls: {same}/{n_clips} identical to the stand-alone runs")
+        assert same >= n_clips - 2
+        # the batched entry points are refused while a stream is open, and work again after StreamClose
+        e.stream_open(4)
+        with pytest.raises(RuntimeError):
+            e.run_tokens(clips[0], max_new=4)
+        with pytest.raises(RuntimeError):
+            e.stream_admit(9, clips[0])       # no such slot
+        e.stream_admit(1, clips[0], 5)
+        with pytest.raises(RuntimeError):
+            e.stream_admit(1, clips[1], 5)    # busy
+        fin = []
+        for _ in range(40):
+            fin = e.stream_step(2)
+            if fin:
+                break
+        assert fin == [1] and e.stream_collect(1) == got[0][:5]
+        e.stream_close()
+        assert e.run_tokens(clips[0], max_new=5) is not None
+    finally:
+        e.close()
+
+
+def test_stream_one_and_two_slots_and_full_context(built_lib, micro_case):
+    """n_slots below 3 (the engine still runs the 3-slot step sequence underneath), a clip that runs to the end of the
+    context (444 ids, offset 447) next to short ones, and a slot reused six times."""
+    import modelgen
+
+    e = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=2)
+    try:
+        clips = [modelgen.synth_clip(70 + i, 160000) for i in range(7)]
+        budgets = [0, 9, 17, 3, 30, 12, 25]  # clip 0: no budget -> the whole context
+        got, _ = e.run_stream(clips, 2, max_new=budgets)
+        assert len(got[0]) == 444
+        for i in range(7):
+            alone = e.run_tokens(clips[i], max_new=budgets[i])
+            n = min(len(alone), len(got[i]))
+            assert len(alone) == len(got[i]) and (alone == got[i] or n > 0), i
+        ref = [e.run_tokens(c, max_new=b) for c, b in zip(clips, budgets)]
+        assert sum(r == g for r, g in zip(ref, got)) >= 6
+        got1, _ = e.run_stream(clips[1:4], 1, max_new=budgets[1:4])
+        assert got1 == got[1:4]
+    finally:
+        e.close()

@@ -43,6 +43,7 @@ SYMBOLS = {
     "AX_WHISPER_RunPCMBatch": (C.c_int, [C.c_void_p, C.POINTER(fp), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "AX_WHISPER_RunDeviceBatchTokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, ip, C.POINTER(C.c_int)]),
     "AX_WHISPER_Detokenize": (C.c_int, [C.c_void_p, ip, C.c_int, C.POINTER(C.c_void_p)]),
+    "AX_WHISPER_Transcript": (C.c_int, [C.c_void_p, ip, C.c_int, C.POINTER(C.c_void_p)]),
     "AX_WHISPER_ConvertT2S": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "AX_WHISPER_ComputeMel": (C.c_int, [C.c_void_p, fp, C.c_int, fp]),
     "AX_WHISPER_EncodeMel": (C.c_int, [C.c_void_p, fp, C.c_int]),
@@ -50,6 +51,12 @@ SYMBOLS = {
     "AX_WHISPER_DecodeForced": (C.c_int, [C.c_void_p, C.c_int, ip, C.c_int, fp, ip]),
     "AX_WHISPER_DecodeGreedy": (C.c_int, [C.c_void_p, C.c_int, C.c_int, ip, C.POINTER(C.c_int)]),
     "AX_WHISPER_DecodeGreedyRagged": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), ip, C.POINTER(C.c_int)]),
+    "AX_WHISPER_StreamOpen": (C.c_int, [C.c_void_p, C.c_int]),
+    "AX_WHISPER_StreamAdmit": (C.c_int, [C.c_void_p, C.c_int, fp, C.c_int, C.c_int]),
+    "AX_WHISPER_StreamAdmitBatch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(fp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
+    "AX_WHISPER_StreamStep": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "AX_WHISPER_StreamCollect": (C.c_int, [C.c_void_p, C.c_int, ip, C.POINTER(C.c_int)]),
+    "AX_WHISPER_StreamClose": (C.c_int, [C.c_void_p]),
     "AX_WHISPER_GetTimings": (C.c_int, [C.c_void_p, fp]),
     "AX_WHISPER_Bench": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, fp]),
 }
@@ -189,6 +196,12 @@ class Whisper:
             self.L._free(out.value)
         return b
 
+    def transcript(self, ids) -> str:
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        out = C.c_void_p()
+        self._check(self.L.AX_WHISPER_Transcript(self.h, a.ctypes.data_as(ip), len(a), C.byref(out)), "Transcript")
+        return self._take(out.value)
+
     def set_stream(self, stream_ptr: int):
         self._check(self.L.AX_WHISPER_SetStream(self.h, C.c_void_p(stream_ptr)), "SetStream")
 
@@ -229,6 +242,67 @@ class Whisper:
             mc = (C.c_int * batch)(*[int(x) for x in max_new_clip])
             self._check(self.L.AX_WHISPER_DecodeGreedyRagged(self.h, batch, max_new, mc, ids.ctypes.data_as(ip), n), "DecodeGreedyRagged")
         return [ids[b, : n[b]].tolist() for b in range(batch)]
+
+    # ---- utterance slots refilled while the others decode (AX_WHISPER_Stream*)
+    def stream_open(self, n_slots: int):
+        self._check(self.L.AX_WHISPER_StreamOpen(self.h, n_slots), "StreamOpen")
+        self._n_slots = n_slots
+
+    def stream_admit(self, slot: int, pcm, max_new: int = 0):
+        a = _f32(pcm)
+        self._check(self.L.AX_WHISPER_StreamAdmit(self.h, slot, a.ctypes.data_as(fp), len(a), max_new), "StreamAdmit")
+
+    def stream_admit_batch(self, slots, clips, max_new=None):
+        clips = [_f32(c) for c in clips]
+        n = len(clips)
+        sl = (C.c_int * n)(*[int(x) for x in slots])
+        ptrs = (fp * n)(*[c.ctypes.data_as(fp) for c in clips])
+        lens = (C.c_int * n)(*[len(c) for c in clips])
+        mn = (C.c_int * n)(*[int(x) for x in max_new]) if max_new is not None else None
+        self._check(self.L.AX_WHISPER_StreamAdmitBatch(self.h, sl, ptrs, lens, mn, n), "StreamAdmitBatch")
+
+    def stream_step(self, n_steps: int = 8):
+        fin = (C.c_int * max(self._n_slots, 3))()
+        n = C.c_int()
+        self._check(self.L.AX_WHISPER_StreamStep(self.h, n_steps, fin, C.byref(n)), "StreamStep")
+        return [fin[i] for i in range(n.value)]
+
+    def stream_collect(self, slot: int):
+        ids = np.zeros(self.n_text_ctx, dtype=np.int32)
+        n = C.c_int()
+        self._check(self.L.AX_WHISPER_StreamCollect(self.h, slot, ids.ctypes.data_as(ip), C.byref(n)), "StreamCollect")
+        return ids[: n.value].tolist()
+
+    def stream_close(self):
+        self._check(self.L.AX_WHISPER_StreamClose(self.h), "StreamClose")
+
+    def run_stream(self, clips, n_slots: int, max_new=0, steps_per_call: int = 8):
+        """Feed `clips` through n_slots refillable slots in arrival order; max_new: one budget or one per clip.
+        Returns (ids per clip, decoder-step calls made)."""
+        budgets = list(max_new) if hasattr(max_new, "__len__") else [max_new] * len(clips)
+        self.stream_open(n_slots)
+        try:
+            out = [None] * len(clips)
+            owner = {}
+            free = list(range(n_slots))
+            nxt = calls = 0
+            while nxt < len(clips) or owner:
+                k = min(len(free), len(clips) - nxt)
+                if k == 1:
+                    self.stream_admit(free[0], clips[nxt], budgets[nxt])
+                elif k > 1:  # every free slot is refilled by ONE batched front-end + encoder pass
+                    self.stream_admit_batch(free[:k], clips[nxt:nxt + k], budgets[nxt:nxt + k])
+                for i in range(k):
+                    owner[free.pop(0)] = nxt
+                    nxt += 1
+                calls += 1
+                for sl in self.stream_step(steps_per_call):
+                    if sl in owner:
+                        out[owner.pop(sl)] = self.stream_collect(sl)
+                        free.append(sl)
+            return out, calls
+        finally:
+            self.stream_close()
 
     def timings(self):
         t = (C.c_float * 5)()

@@ -257,6 +257,12 @@ AX_WHISPER_API int AX_WHISPER_Detokenize(AX_WHISPER_HANDLE handle, const int32_t
   return guarded(handle, [&](Engine& e) { *result = strdup(e.detokenize(ids, n).c_str()); });
 }
 
+AX_WHISPER_API int AX_WHISPER_Transcript(AX_WHISPER_HANDLE handle, const int32_t* ids, int n, char** result) {
+  if (!handle || (!ids && n > 0) || !result) return -1;
+  *result = nullptr;
+  return guarded(handle, [&](Engine& e) { *result = strdup(e.transcript(ids, n).c_str()); });
+}
+
 AX_WHISPER_API int AX_WHISPER_ConvertT2S(const char* config_path, const char* text, char** result) {
   if (!config_path || !text || !result) return -1;
   *result = nullptr;
@@ -340,6 +346,32 @@ AX_WHISPER_API int AX_WHISPER_DecodeGreedyRagged(AX_WHISPER_HANDLE handle, int b
                                                  int32_t* ids, int* n_ids) {
   if (!handle || !ids || !n_ids) return -1;
   return guarded(handle, [&](Engine& e) { e.decode_greedy(batch, max_new, max_new_clip, ids, n_ids); });
+}
+
+AX_WHISPER_API int AX_WHISPER_StreamOpen(AX_WHISPER_HANDLE handle, int n_slots) {
+  return guarded(handle, [&](Engine& e) { e.stream_open(n_slots); });
+}
+AX_WHISPER_API int AX_WHISPER_StreamAdmit(AX_WHISPER_HANDLE handle, int slot, const float* pcm, int num_samples, int max_new) {
+  if (!handle || !pcm || num_samples < 1) return -1;
+  return guarded(handle, [&](Engine& e) { const float* arr[1] = {pcm}; e.stream_admit(&slot, arr, &num_samples, &max_new, 1); });
+}
+AX_WHISPER_API int AX_WHISPER_StreamAdmitBatch(AX_WHISPER_HANDLE handle, const int* slots, const float* const* pcm,
+                                               const int* num_samples, const int* max_new, int count) {
+  if (!handle || !slots || !pcm || !num_samples || count < 1) return -1;
+  for (int i = 0; i < count; ++i) if (!pcm[i] || num_samples[i] < 1) return -1;
+  return guarded(handle, [&](Engine& e) { e.stream_admit(slots, pcm, num_samples, max_new, count); });
+}
+AX_WHISPER_API int AX_WHISPER_StreamStep(AX_WHISPER_HANDLE handle, int n_steps, int* finished_slots, int* n_finished) {
+  if (!handle || !finished_slots || !n_finished) return -1;
+  *n_finished = 0;
+  return guarded(handle, [&](Engine& e) { *n_finished = e.stream_step(n_steps, finished_slots); });
+}
+AX_WHISPER_API int AX_WHISPER_StreamCollect(AX_WHISPER_HANDLE handle, int slot, int32_t* ids, int* n_ids) {
+  if (!handle || !ids || !n_ids) return -1;
+  return guarded(handle, [&](Engine& e) { e.stream_collect(slot, ids, n_ids); });
+}
+AX_WHISPER_API int AX_WHISPER_StreamClose(AX_WHISPER_HANDLE handle) {
+  return guarded(handle, [&](Engine& e) { e.stream_close(); });
 }
 
 AX_WHISPER_API int AX_WHISPER_GetTimings(AX_WHISPER_HANDLE handle, float* out5) {

@@ -201,6 +201,7 @@ struct GemmParams {
   int d_model;                       // EPI_QKV / EPI_CROSS_KV
   int t_pad;                         // padded key count (multiple of 64)
   int n_batch_total;                 // EPI_CROSS_KV: slot count B in [l][B][h]...
+  const int* kv_slot_map;            // EPI_CROSS_KV: clip b of this launch -> slot kv_slot_map[b] (device), nullptr: slot b
   int n_layer;                       // EPI_CROSS_KV: decoder layers (weight rows: all K, then all V)
   int n_begin;                       // set by launch_gemm: first output column of this launch
   int n_tiles;                       // set by launch_gemm: 128-column tiles of this launch
@@ -249,10 +250,15 @@ void launch_mel_to_tm(const float* mel_ref, h16* mel_tm, int batch, int n_mels, 
 
 // ------------------------------------------------------------------ decoder
 struct DecState {          // device-resident loop state, one per engine
-  int step;                // global decode step = offset fed to this step
+  int step;                // decoder steps run since the last reset (bookkeeping; no kernel derives a position from it)
   int n_done;
   int pad0, pad1;
 };
+// Every utterance slot has its OWN offset (`off[b]`: the position fed to this step = number of cached self-attention keys
+// = the `offset` input of the reference's decoder graph, export_onnx.py:312-336 / Whisper.cpp:207-222, which handles one
+// utterance at a time and so has one): slots of one batch may be at different positions, a finished slot stops
+// advancing, and a new clip can be admitted into it while the others decode on (Engine::stream_*). Kernel parameter
+// structs carry `off` with the same clip origin as their other per-clip pointers.
 
 struct DecLayerW {
   const float *attn_ln_w, *attn_ln_b, *cross_ln_w, *cross_ln_b, *mlp_ln_w, *mlp_ln_b;
@@ -292,6 +298,7 @@ struct GemvParams {
   float* out;                 // [B][N]
   h16* k_cache; h16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;  // GEPI_QKV_CACHE (this layer)
   const DecState* state;
+  const int* off;                  // per-clip offsets [batch] (GEPI_QKV_CACHE: cache row; GEPI_LOGITS: skip while every clip is below skip_before_step)
   float* amax_val; int* amax_idx; int amax_stride;  // GEPI_LOGITS: partials [clip][amax_stride], one per workgroup
   float* logits_dump;              // optional logits row of this step for clip b at logits_dump + b*logits_dump_stride
   long logits_dump_stride;
@@ -300,8 +307,8 @@ struct GemvParams {
 void launch_gemv(const GemvParams& p, hipStream_t s);
 int gemv_grid(const GemvParams& p);  // number of workgroups launch_gemv will use
 
-// x[b] = tok_emb[tok[b]] + pos[step]
-void launch_embed(const h16* tok_emb, const float* pos, const int* tok, const DecState* st, float* x, int batch, int d,
+// x[b] = tok_emb[tok[b]] + pos[off[b]]
+void launch_embed(const h16* tok_emb, const float* pos, const int* tok, const int* off, float* x, int batch, int d,
                   hipStream_t s);
 
 // single-query attention over blocked K / row-major V, writes split partials [B][H][n_split][66]
@@ -310,9 +317,10 @@ struct DecAttnParams {
   const h16* k; const h16* v; long kv_batch_stride;   // this layer, slot 0
   float* part; int n_split;
   int batch, n_head, d_model;
-  int n_keys;                 // fixed key count (cross) or -1: state->step + 1 (self)
+  int n_keys;                 // fixed key count (cross) or -1: off[b] + 1 (self)
   int cap_blocks;             // allocated 64-key blocks per (slot, head): 24 cross, 7 self
   const DecState* state;
+  const int* off;             // per-clip offsets [B]
   const int* done;            // optional device [B]: clips whose flag is set are skipped (greedy loop past their eot)
   h16* out_hi; h16* out_lo; int nbs; // normalised output as a fragment-major h16 pair instead of partials; with n_split > 1
                                      // the splits of a (clip, head) meet through mpart / mcnt and the last one to arrive writes it
@@ -336,6 +344,7 @@ struct DecGemmParams {
   h16* out_hi; h16* out_lo;              // GEPI_GELU: h16 pair [batch][N]
   h16* k_cache; h16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;
   const DecState* state;
+  const int* off;                          // per-clip offsets [batch]
   float* amax_val; int* amax_idx; int amax_stride;
   float* logits_dump; long logits_dump_stride;
   int skip_before_step;
@@ -359,6 +368,7 @@ struct DecCGemmParams {
   h16* out_hi; h16* out_lo;              // GEPI_GELU: h16 pair
   h16* k_cache; h16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;
   const DecState* state;
+  const int* off;                          // per-clip offsets [batch]
 };
 void launch_decode_cgemm(const DecCGemmParams& p, hipStream_t s);
 int decode_gemm_grid(int N, int rt);
@@ -369,7 +379,7 @@ void launch_pack_weight_frag(const h16* w, h16* wp, int N, int K, hipStream_t s)
 
 struct AdvanceParams {
   const float* amax_val; const int* amax_idx; int n_part; int amax_stride;
-  DecState* state; int* tok; int* done; int* n_out; int* out_ids; int batch;
+  DecState* state; int* off; int* tok; int* done; int* n_out; int* out_ids; int batch;
   int n_ctx, eot, max_new, n_vocab;
   const int* max_new_clip;    // optional device [B]: per-clip id budget (a ragged batch), capped by max_new
   const int* sot;             // device [4]

@@ -188,9 +188,12 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
   if (wave + 8 < KS) load(f1, wave + 8);
   if (wave + 16 < KS) load(f2, wave + 16);
 
-  // the step counter is read after the operand loads are in flight
-  const int step = (p.epilogue == GEPI_LOGITS || p.epilogue == GEPI_QKV_CACHE) ? p.state->step : 0;
-  if (p.epilogue == GEPI_LOGITS && step < p.skip_before_step) return;
+  // the clips' offsets are read after the operand loads are in flight. SOT steps: logits are discarded
+  // (Whisper.cpp:214-217) — the launch has nothing to do while every clip is still below skip_before_step
+  if (p.epilogue == GEPI_LOGITS) {
+    const int o = lane < p.batch ? p.off[lane] : -1;
+    if (__ballot(o >= p.skip_before_step) == 0) return;
+  }
 
   for (int ks = wave; ks < KS; ks += 24) {
     mma(f0);
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
         if (n < d) {
           p.out[(long)b * d + n] = y;
         } else {
+          const int step = p.off[b];  // this clip's cache row
           const int cc = (n < 2 * d) ? n - d : n - 2 * d;
           const int head = cc >> 6, dd = cc & 63;
           const long base = (long)b * p.kv_batch_stride + (long)head * p.n_ctx_pad * 64;
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
   float bias_t = 0.f, old_t = 0.f;
   if (has_out && p.bias) bias_t = p.bias[o_n];
   if (has_out && p.epilogue == GEPI_RESID) old_t = p.out[(long)o_b * p.N + o_n];
-  const int step = p.epilogue == GEPI_QKV_CACHE ? p.state->step : 0;
+  const int step = (has_out && p.epilogue == GEPI_QKV_CACHE) ? p.off[o_b] : 0;  // this thread's clip: its own cache row
 
   const h16* wrow[RT];
 #pragma unroll
@@ -507,7 +511,10 @@ __global__ __launch_bounds__(512) void decode_logits_kernel(DecGemmParams p) {
   // resolves with a full drain); the tail re-reads the last block (L2 hits).
   h16x8 w0[CH], w1[CH], w2[CH];
   loadw(w0, blockIdx.x);
-  if (p.state->step < p.skip_before_step) return;  // SOT steps: logits are discarded (Whisper.cpp:214-217)
+  {  // SOT steps: logits are discarded (Whisper.cpp:214-217): nothing to do while every clip is below skip_before_step
+    const int o = lane < p.batch ? p.off[lane] : -1;
+    if (__ballot(o >= p.skip_before_step) == 0) return;
+  }
 
   constexpr int NU = (NB * 256 + 511) / 512;  // outputs per thread and iteration
   float bv[NU];

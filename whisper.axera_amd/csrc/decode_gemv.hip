@@ -126,10 +126,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p, int rows_per_wg
     for (int i = 0; i < CH; ++i) wnext[i] = *reinterpret_cast<const uint4*>(wrow + (j + LPR * i) * 8);
   }
 
-  // The step counter lives in device memory (written by the previous step's advance kernel); it is read
-  // only AFTER the weight loads are in flight so its round trip does not delay them.
-  const int step = (p.epilogue == GEPI_LOGITS || p.epilogue == GEPI_QKV_CACHE) ? p.state->step : 0;
-  if (p.epilogue == GEPI_LOGITS && step < p.skip_before_step) return;  // SOT steps: logits are discarded (Whisper.cpp:214-217)
+  // The clips' offsets live in device memory (written by the previous step's advance kernel); they are read
+  // only AFTER the weight loads are in flight so their round trip does not delay them.
+  int stepb[BT];
+  bool any_logits = false;
+#pragma unroll
+  for (int b = 0; b < BT; ++b) {
+    stepb[b] = ((p.epilogue == GEPI_LOGITS || p.epilogue == GEPI_QKV_CACHE) && b < p.batch) ? p.off[b] : 0;
+    any_logits |= b < p.batch && stepb[b] >= p.skip_before_step;
+  }
+  if (p.epilogue == GEPI_LOGITS && !any_logits) return;  // SOT steps: logits are discarded (Whisper.cpp:214-217)
 
   // epilogue operands of the first pass (bias, residual) ride along with the weight loads
   float bias0 = 0.f, resid0[BT];
@@ -216,6 +222,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvParams p, int rows_per_wg
               const int c = (n < 2 * d) ? n - d : n - 2 * d;
               const int head = c >> 6, dd = c & 63;
               const long base = (long)b * p.kv_batch_stride + (long)head * p.n_ctx_pad * 64;
+              const int step = stepb[b];
               if (n < 2 * d)  // blocked K: [blk][dd/8][key%64][8]
                 p.k_cache[base + (long)(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (h16)y;
               else            // row-major V: [key][64]
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvParams p, int rows_per_w
     }
   }
 
-  const int step = (p.epilogue == GEPI_LOGITS || p.epilogue == GEPI_QKV_CACHE) ? p.state->step : 0;
+  const int step = (p.epilogue == GEPI_LOGITS || p.epilogue == GEPI_QKV_CACHE) ? p.off[0] : 0;  // the one clip of this launch
   if (p.epilogue == GEPI_LOGITS && step < p.skip_before_step) return;  // SOT steps: logits are discarded (Whisper.cpp:214-217)
 
   float best_v = -INFINITY;
@@ -481,44 +488,50 @@ void launch_gemv(const GemvParams& p, hipStream_t s) {
 // ------------------------------------------------------------------------------- advance
 // Whisper.cpp:207-222: steps 0..2 feed the next SOT token and drop the logits; from step 3 on the
 // argmax is either the stop condition (eot / context full) or the next recorded + fed token.
-// One wave per clip merges the per-workgroup argmax partials (first max wins); 16 clips per workgroup. The step
-// counter is advanced by whichever workgroup finishes last (ticket in state->pad0), i.e. after every
-// workgroup has read it.
+// One wave per clip merges the per-workgroup argmax partials (first max wins); 16 clips per workgroup. Every clip
+// advances its OWN offset (the reference decodes one utterance at a time and stops it at its own eot,
+// Whisper.cpp:219-222): a finished clip stays where it is.
 // One wave per clip. The kernel is one dependent chain per decoder step (step counter -> argmax partials -> loop state ->
 // embedding row of the chosen token), so everything that does not depend on the previous link is requested early: the
 // loop state and the next position's embedding beside the partials, the step ticket right behind the step counter, and
 // the embedding row in 8-byte pieces that are all in flight before the first store (as `for (c = lane; c < d; c += 64)`
 // the row was 12 load -> add -> store round trips, 12.7 us per step at turbo dims).
 __global__ __launch_bounds__(1024) void advance_kernel(AdvanceParams p) {
-  const int s = p.state->step;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x * 16 + wave;
-  // every thread holds the step counter before this workgroup's ticket can let the last workgroup advance it
-  __syncthreads();
+  // the engine-wide step counter is bookkeeping only (steps run since the reset): whichever workgroup draws the last
+  // ticket bumps it. Positions come from the clips' own offsets.
   if (threadIdx.x == 0) {
     const int ticket = atomicAdd(&p.state->pad0, 1);
     if (ticket == (int)gridDim.x - 1) {
       p.state->pad0 = 0;
-      p.state->step = s + 1;
+      p.state->step = p.state->step + 1;
     }
   }
   if (b >= p.batch) return;
+  const int s = p.off[b];  // this clip's offset: the position that was fed in this step
   constexpr int MAXJ = 8;  // d_model <= 2048: lane l owns elements 4l + 256j
   const int d = p.d_model;
-  const bool embed = s + 1 < p.n_ctx;
+  // x of every slot is re-seeded every step, finished slots included (their rows of the linear layers keep running and
+  // must stay finite): a slot at the end of the context re-reads the last position row
+  const bool room = s + 1 < p.n_ctx;
+  const int pos_row = room ? s + 1 : p.n_ctx - 1;
   float4 pv[MAXJ];
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j)
-    if (embed && 4 * lane + 256 * j < d) pv[j] = *reinterpret_cast<const float4*>(p.pos + (long)(s + 1) * d + 4 * lane + 256 * j);
-  int tok = 0;
-  if (s < 3) {
+    if (4 * lane + 256 * j < d) pv[j] = *reinterpret_cast<const float4*>(p.pos + (long)pos_row * d + 4 * lane + 256 * j);
+  // loop state of this clip: requested beside the partials, used after the reduction
+  const int tok_old = p.tok[b];
+  const bool greedy = !p.forced;
+  const int done_b = greedy ? p.done[b] : 0;
+  int tok = tok_old;
+  bool advance = !done_b;  // a finished (or idle) slot keeps its offset: its cache row and position stay in bounds for good
+  if (done_b) {
+    // nothing: the slot waits for Engine::stream_admit or the end of the batch
+  } else if (s < 3) {
     tok = p.sot[s + 1];
     if (lane == 0) p.tok[b] = tok;
   } else {
-    // loop state of this clip: requested beside the partials, used after the reduction
-    const int tok_old = p.tok[b];
-    const bool greedy = !p.forced;
-    const int done_b = greedy ? p.done[b] : 0;
     const int n_out = greedy ? p.n_out[b] : 0;
     const int max_new = greedy ? (p.max_new_clip ? min(p.max_new_clip[b], p.max_new) : p.max_new) : 0;
     float v = -INFINITY;
@@ -533,13 +546,13 @@ __global__ __launch_bounds__(1024) void advance_kernel(AdvanceParams p) {
     // no logit compared greater than -inf (all NaN / -inf: non-finite audio): std::max_element returns index 0
     // (Whisper.cpp:42-45); never let the "no candidate" index reach the embedding lookup below
     if ((unsigned)idx >= (unsigned)p.n_vocab) idx = 0;
-    tok = tok_old;
     const int gi = s - 3;
     if (p.forced) {
       if (gi < p.n_forced) tok = p.forced[(long)b * p.n_forced + gi];
-    } else if (!done_b) {
-      if (idx == p.eot || s + 1 >= p.n_ctx || n_out >= max_new) {
+    } else {
+      if (idx == p.eot || s + 1 >= p.n_ctx || n_out >= max_new) {  // Whisper.cpp:219-222: this utterance ends HERE
         if (lane == 0) { p.done[b] = 1; atomicAdd(&p.state->n_done, 1); }
+        advance = false;
       } else {
         if (lane == 0) { p.out_ids[(long)b * p.n_ctx + n_out] = idx; p.n_out[b] = n_out + 1; }
         tok = idx;
@@ -550,8 +563,9 @@ __global__ __launch_bounds__(1024) void advance_kernel(AdvanceParams p) {
       p.tok[b] = tok;
     }
   }
-  // fused embedding of the NEXT step: x = tok_emb[token] + pos[step + 1]   (export_onnx.py:334-336)
-  if (embed) {
+  if (lane == 0 && advance && room) p.off[b] = s + 1;
+  // fused embedding of the NEXT step: x = tok_emb[token] + pos[offset + 1]   (export_onnx.py:334-336)
+  {
     h16x4 ev[MAXJ];
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j)

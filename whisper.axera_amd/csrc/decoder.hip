@@ -35,16 +35,16 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short u) { return __u
 
 // ------------------------------------------------------------------------------- embed
 __global__ __launch_bounds__(256) void embed_kernel(const h16* __restrict__ tok_emb, const float* __restrict__ pos,
-                                                    const int* __restrict__ tok, const DecState* __restrict__ st, float* __restrict__ x,
+                                                    const int* __restrict__ tok, const int* __restrict__ off, float* __restrict__ x,
                                                     int d) {
   const int b = blockIdx.x;
-  const int t = tok[b], step = st->step;
+  const int t = tok[b], step = off[b];
   for (int c = threadIdx.x; c < d; c += 256) x[(long)b * d + c] = (float)tok_emb[(long)t * d + c] + pos[(long)step * d + c];
 }
 
-void launch_embed(const h16* tok_emb, const float* pos, const int* tok, const DecState* st, float* x, int batch, int d,
+void launch_embed(const h16* tok_emb, const float* pos, const int* tok, const int* off, float* x, int batch, int d,
                   hipStream_t s) {
-  hipLaunchKernelGGL(embed_kernel, dim3(batch), dim3(256), 0, s, tok_emb, pos, tok, st, x, d);
+  hipLaunchKernelGGL(embed_kernel, dim3(batch), dim3(256), 0, s, tok_emb, pos, tok, off, x, d);
 }
 
 // ------------------------------------------------------------------------------- decode attention
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
     for (int c = 0; c < 64; ++c) qv[c] = qp[c];
   }
 
-  const int n_keys = p.n_keys >= 0 ? p.n_keys : p.state->step + 1;
+  const int n_keys = p.n_keys >= 0 ? p.n_keys : p.off[b] + 1;  // self-attention: this clip's own position
   const int blk_end = min((n_keys + 63) >> 6, blk_cap_end);
 
   float m_w = -INFINITY, l_lane = 0.f;

@@ -82,6 +82,9 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
   HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   for (auto& e : ev_) HIP_CHECK(hipEventCreate(&e));
   for (auto& b : branch_stream_) HIP_CHECK(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&admit_stream_, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+  for (auto& e : ev_poll_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
   for (auto& e : ev_join_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 
@@ -150,6 +153,12 @@ void Engine::destroy() {
   for (auto& e : ev_join_) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (ev_fork_) { (void)hipEventDestroy(ev_fork_); ev_fork_ = nullptr; }
   for (auto& b : branch_stream_) if (b) { (void)hipStreamDestroy(b); b = nullptr; }
+  if (admit_stream_) { (void)hipStreamDestroy(admit_stream_); admit_stream_ = nullptr; }
+  if (copy_stream_) { (void)hipStreamDestroy(copy_stream_); copy_stream_ = nullptr; }
+  for (auto& e : ev_poll_) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  for (auto& e : ev_admit_) if (e) (void)hipEventDestroy(e);
+  ev_admit_.clear();
+  if (h_done_) { (void)hipHostFree(h_done_); h_done_ = nullptr; }
   if (own_stream_) { (void)hipStreamDestroy(own_stream_); own_stream_ = nullptr; }
 }
 
@@ -540,6 +549,8 @@ void Engine::ensure_capacity(int batch) {
   d_amax_idx_ = (int*)A((size_t)n_amax_part_ * B * 4, true);
   d_tok_ = (int*)A((size_t)B * 4, true);
   d_done_ = (int*)A((size_t)B * 4, true);
+  d_off_ = (int*)A((size_t)B * 4, true);
+  d_slot_map_ = (int*)A((size_t)B * 4, true);
   d_attn_mpart_ = (float*)A((size_t)B * cfg_.n_text_head * kCrossSplitMax * 66 * 4, true);
   d_attn_mcnt_ = (unsigned*)A((size_t)B * cfg_.n_text_head * 4, true);  // zero: every launch leaves its tickets at zero
   d_nout_ = (int*)A((size_t)B * 4, true);
@@ -613,7 +624,7 @@ void Engine::run_frontend(const float* d_pcm, int stride, const int* n_samples, 
 }
 
 // ------------------------------------------------------------------------------ encoder
-void Engine::run_encoder(int batch) {
+void Engine::run_encoder(int batch, const int* d_slot_map) {
   const int d = cfg_.n_text_state, nm = cfg_.n_mels, T = cfg_.n_audio_ctx, H = cfg_.n_audio_head, L = cfg_.n_text_layer;
   hipStream_t s = stream();
   GemmParams g{};
@@ -696,6 +707,7 @@ void Engine::run_encoder(int batch) {
   c.A = d_ln_; c.lda = d; c.a_batch_stride = (long)T * d;
   c.W = w_cross_kv_; c.bias = b_cross_kv_;
   c.C = d_cross_k_; c.C2 = d_cross_v_;
+  c.kv_slot_map = d_slot_map;  // an admission pass (stream_admit) scatters its clips into whichever slots are idle
   c.M = T; c.N = 2 * L * d; c.K = d; c.batch = batch; c.d_model = d; c.t_pad = t_pad_;
   c.n_batch_total = cap_; c.n_layer = L; c.epilogue = EPI_CROSS_KV;
   launch_gemm(c, s);
@@ -713,11 +725,12 @@ void Engine::reset_decode_state(int batch, const int* max_new_clip) {
   }
   HIP_CHECK(hipMemsetAsync(d_state_, 0, sizeof(DecState), s));
   HIP_CHECK(hipMemsetAsync(d_done_, 0, (size_t)batch * 4, s));
+  HIP_CHECK(hipMemsetAsync(d_off_, 0, (size_t)batch * 4, s));
   HIP_CHECK(hipMemsetAsync(d_nout_, 0, (size_t)batch * 4, s));
   std::vector<int> t0(batch, sot_seq_[0]);
   HIP_CHECK(hipMemcpyAsync(d_tok_, t0.data(), (size_t)batch * 4, hipMemcpyHostToDevice, s));
   // x of step 0; every later step's embedding is produced by the previous step's advance kernel
-  launch_embed(tok_emb_, dec_pos_, d_tok_, d_state_, d_xdec_, batch, cfg_.n_text_state, s);
+  launch_embed(tok_emb_, dec_pos_, d_tok_, d_off_, d_xdec_, batch, cfg_.n_text_state, s);
   HIP_CHECK(hipStreamSynchronize(s));
 }
 
@@ -746,6 +759,7 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
     DecAttnParams a{};
     a.q = d_qdec_; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = part; a.n_split = n_split;
     a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
+    a.off = d_off_;
     a.done = d_forced ? nullptr : d_done_;
     if (step_mask_ & 2) launch_decode_attention(a, s);
   };
@@ -762,8 +776,8 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
     p.W = w.w_qkv; p.bias = w.b_qkv; p.N = 3 * d; p.K = d;
     p.prologue = PRO_LAYERNORM; p.in = d_xdec_; p.ln_w = w.attn_ln_w; p.ln_b = w.attn_ln_b;
     p.epilogue = GEPI_QKV_CACHE; p.out = d_qdec_; p.k_cache = sk; p.v_cache = sv; p.kv_batch_stride = self_stride;
-    p.d_model = d; p.n_ctx_pad = Tc; p.state = d_state_;
-    gemv(p, [&](GemvParams& q, int b0) { q.in += (long)b0 * d; q.out += (long)b0 * d; q.k_cache += b0 * self_stride; q.v_cache += b0 * self_stride; });
+    p.d_model = d; p.n_ctx_pad = Tc; p.state = d_state_; p.off = d_off_;
+    gemv(p, [&](GemvParams& q, int b0) { q.in += (long)b0 * d; q.out += (long)b0 * d; q.k_cache += b0 * self_stride; q.v_cache += b0 * self_stride; q.off += b0; });
     attn(sk, sv, self_stride, -1, Tc / 64, d_part_self_, split_self_);
     // x += out(attention)
     p = GemvParams{};
@@ -799,15 +813,15 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
   GemvParams p{};
   p.W = tok_emb_; p.bias = nullptr; p.N = cfg_.n_vocab; p.K = d;
   p.prologue = PRO_LAYERNORM; p.in = d_xdec_; p.ln_w = dec_ln_w_; p.ln_b = dec_ln_b_;
-  p.epilogue = GEPI_LOGITS; p.state = d_state_; p.amax_val = d_amax_val_; p.amax_idx = d_amax_idx_; p.amax_stride = n_amax_part_;
+  p.epilogue = GEPI_LOGITS; p.state = d_state_; p.off = d_off_; p.amax_val = d_amax_val_; p.amax_idx = d_amax_idx_; p.amax_stride = n_amax_part_;
   p.skip_before_step = 3; p.logits_dump = d_logits; p.logits_dump_stride = logits_stride;
   gemv(p, [&](GemvParams& q, int b0) {
-    q.in += (long)b0 * d; q.amax_val += (long)b0 * n_amax_part_; q.amax_idx += (long)b0 * n_amax_part_;
+    q.in += (long)b0 * d; q.amax_val += (long)b0 * n_amax_part_; q.amax_idx += (long)b0 * n_amax_part_; q.off += b0;
     if (q.logits_dump) q.logits_dump += (long)b0 * logits_stride;
   });
   AdvanceParams a{};
   a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = gemv_grid(p); a.amax_stride = n_amax_part_;
-  a.state = d_state_; a.tok = d_tok_; a.done = d_done_; a.n_out = d_nout_; a.out_ids = d_out_ids_; a.batch = batch;
+  a.state = d_state_; a.off = d_off_; a.tok = d_tok_; a.done = d_done_; a.n_out = d_nout_; a.out_ids = d_out_ids_; a.batch = batch;
   a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.n_vocab = cfg_.n_vocab; a.max_new_clip = d_max_new_clip_; a.sot = d_sot_;
   a.forced = d_forced; a.n_forced = n_forced; a.argmax_dump = d_argmax;
   a.tok_emb = tok_emb_; a.pos = dec_pos_; a.x = d_xdec_; a.d_model = d;
@@ -829,7 +843,7 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
   auto cgemm = [&](const h16* W, const float* bias, int N, int K, int epi, int rt) {
     DecCGemmParams c{};
     c.W = W; c.bias = bias; c.N = N; c.K = K; c.batch = nb; c.nbs = nbs_; c.epilogue = epi; c.rt = rt;
-    c.d_model = d; c.n_ctx_pad = Tc; c.state = d_state_;
+    c.d_model = d; c.n_ctx_pad = Tc; c.state = d_state_; c.off = d_off_ + b0;
     return c;
   };
   static const bool fuse_cq = [] { const char* e = getenv("AX_WHISPER_FUSE_CQ"); return !(e && e[0] == '0'); }();
@@ -849,6 +863,7 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
     DecAttnParams a{};
     a.q = qd; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = nullptr; a.n_split = 1;
     a.batch = nb; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
+    a.off = d_off_ + b0;
     a.done = done;
     a.out_hi = att_hi; a.out_lo = att_lo; a.nbs = nbs_;
     return a;
@@ -924,6 +939,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
       q.a_hi += (long)(b0 / 16) * 512;  // fragment-major: clip blocks are 512 elements apart within a k-step
       q.a_lo += (long)(b0 / 16) * 512;
       q.nbs = nbs_;
+      q.off = d_off_ + b0;
       offset(q, b0);
       if (step_mask_ & 1) launch_decode_gemm(q, s);
     }
@@ -954,6 +970,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     DecAttnParams a{};
     a.q = d_qdec_; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = nullptr; a.n_split = 1;
     a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
+    a.off = d_off_;
     a.done = d_forced ? nullptr : d_done_;
     a.out_hi = d_att_[0]; a.out_lo = d_att_[1]; a.nbs = nbs_;
     if (n_keys >= 0) {  // cross-attention: few (clip, head) pairs leave CUs with one workgroup beside CUs with two (turbo, 16 clips: 320)
@@ -1037,7 +1054,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
   });
   AdvanceParams a{};
   a.amax_val = d_amax_val_; a.amax_idx = d_amax_idx_; a.n_part = decode_gemm_grid(cfg_.n_vocab, vocab_rt); a.amax_stride = n_amax_part_;
-  a.state = d_state_; a.tok = d_tok_; a.done = d_done_; a.n_out = d_nout_; a.out_ids = d_out_ids_; a.batch = batch;
+  a.state = d_state_; a.off = d_off_; a.tok = d_tok_; a.done = d_done_; a.n_out = d_nout_; a.out_ids = d_out_ids_; a.batch = batch;
   a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.n_vocab = cfg_.n_vocab; a.max_new_clip = d_max_new_clip_; a.sot = d_sot_;
   a.forced = d_forced; a.n_forced = n_forced; a.argmax_dump = d_argmax;
   a.tok_emb = tok_emb_; a.pos = dec_pos_; a.x = d_xdec_; a.d_model = d;
@@ -1199,6 +1216,7 @@ void Engine::fetch_ids(int batch, int32_t* ids, int* n_ids) {
 void Engine::run_tokens(const float* const* pcm, const float* d_pcm, int d_stride, const int* n_samples, int batch, int max_new,
                         int32_t* ids, int* n_ids) {
   if (batch < 1) throw std::runtime_error("batch must be >= 1");
+  require_no_stream("run_tokens");
   HIP_CHECK(hipSetDevice(device_));
   auto t0 = std::chrono::steady_clock::now();
   ensure_capacity(batch);
@@ -1266,6 +1284,7 @@ void Engine::compute_mel(const float* pcm, int n_samples, float* mel_out) {
 }
 
 void Engine::encode_mel(const float* mel, int batch) {
+  require_no_stream("encode_mel");
   HIP_CHECK(hipSetDevice(device_));
   ensure_capacity(batch);
   HIP_CHECK(hipMemcpyAsync(d_mel_ref_, mel, (size_t)batch * cfg_.n_mels * kFramesOut * 4, hipMemcpyHostToDevice, stream()));
@@ -1298,6 +1317,7 @@ void Engine::get_cross_kv(int slot, float* k_out, float* v_out) {
 }
 
 void Engine::decode_forced(int batch, const int32_t* forced, int n_forced, float* logits, int32_t* argmax_ids) {
+  require_no_stream("decode_forced");
   HIP_CHECK(hipSetDevice(device_));
   if (batch < 1 || batch > cap_) throw std::runtime_error("decode_forced: batch exceeds the encoded slots");
   if (n_forced < 0 || n_forced + 4 > cfg_.n_text_ctx) throw std::runtime_error("decode_forced: n_forced out of range");
@@ -1332,6 +1352,7 @@ void Engine::decode_forced(int batch, const int32_t* forced, int n_forced, float
 }
 
 void Engine::decode_greedy(int batch, int max_new, const int* max_new_clip, int32_t* ids, int* n_ids) {
+  require_no_stream("decode_greedy");
   HIP_CHECK(hipSetDevice(device_));
   if (batch < 1 || batch > cap_) throw std::runtime_error("decode_greedy: batch exceeds the encoded slots");
   hipStream_t s = stream();
@@ -1346,7 +1367,163 @@ void Engine::decode_greedy(int batch, int max_new, const int* max_new_clip, int3
   timings[4] = (float)steps;
 }
 
+// ------------------------------------------------------------------------------ slot refill (continuous batching)
+// The reference stops every utterance at its own eot (Whisper.cpp:219-222) and serves requests one by one
+// (WhisperHTTPServer.hpp:37-100). With per-slot offsets (common.hpp: DecState) a slot whose clip has finished takes the
+// next clip while the other slots decode on; the step graph is the one the batched loop replays.
+void Engine::require_no_stream(const char* what) const {
+  if (stream_slots_ > 0) throw std::runtime_error(std::string(what) + ": a slot stream is open on this handle (AX_WHISPER_StreamClose first)");
+}
+
+__global__ static void slot_reset_kernel(int slot, int max_new, const int* sot, int* off, int* tok, int* done, int* n_out, int* max_new_clip,
+                                         const h16* tok_emb, const float* pos, float* x, int d) {
+  const int t = sot[0];
+  if (threadIdx.x == 0) { off[slot] = 0; tok[slot] = t; n_out[slot] = 0; max_new_clip[slot] = max_new; done[slot] = 0; }
+  for (int c = threadIdx.x; c < d; c += blockDim.x) x[(long)slot * d + c] = (float)tok_emb[(long)t * d + c] + pos[c];  // position 0
+}
+
+void Engine::stream_open(int n_slots) {
+  HIP_CHECK(hipSetDevice(device_));
+  if (n_slots < 1) throw std::runtime_error("stream_open: n_slots must be >= 1");
+  if (user_stream_) throw std::runtime_error("stream_open: not with a caller-supplied stream (AX_WHISPER_SetStream)");
+  stream_close();
+  ensure_capacity(std::max(n_slots, 3));
+  const int n = std::max(n_slots, 3);  // the step sequence of 3+ slots handles any mix of idle and active slots
+  hipStream_t s = stream();
+  reset_decode_state(n);
+  std::vector<int> ones(n, 1);         // every slot idle: its attention launches return at once
+  HIP_CHECK(hipMemcpy(d_done_, ones.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  if (h_done_) { (void)hipHostFree(h_done_); h_done_ = nullptr; }
+  HIP_CHECK(hipHostMalloc((void**)&h_done_, (size_t)2 * cap_ * 4, hipHostMallocDefault));
+  poll_parity_ = 0;
+  poll_pending_[0] = poll_pending_[1] = false;
+  while ((int)ev_admit_.size() < n) {
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ev_admit_.push_back(e);
+  }
+  (void)step_graph(n, cfg_.n_text_ctx - 4);  // captured here, outside the serving loop
+  HIP_CHECK(hipStreamSynchronize(s));
+  slot_state_.assign(n, kIdle);
+  slot_max_new_.assign(n, 0);
+  slot_act_call_.assign(n, 0);
+  call_no_ = 0;
+  stream_slots_ = n;
+  cfg_.ints["stream_slots"] = n_slots;
+}
+
+void Engine::stream_close() {
+  if (stream_slots_ == 0) return;
+  (void)hipStreamSynchronize(admit_stream_);
+  (void)hipStreamSynchronize(stream());
+  stream_slots_ = 0;
+  slot_state_.clear();
+  cfg_.ints["stream_slots"] = 0;
+}
+
+void Engine::stream_admit(const int* slots, const float* const* pcm, const int* n_samples, const int* max_new, int count) {
+  HIP_CHECK(hipSetDevice(device_));
+  if (stream_slots_ == 0) throw std::runtime_error("stream_admit: no stream open");
+  if (count < 1 || count > stream_slots_) throw std::runtime_error("stream_admit: count out of range");
+  for (int i = 0; i < count; ++i) {
+    if (slots[i] < 0 || slots[i] >= stream_slots_) throw std::runtime_error("stream_admit: slot out of range");
+    if (slot_state_[slots[i]] != kIdle) throw std::runtime_error("stream_admit: slot " + std::to_string(slots[i]) + " is busy");
+    for (int j = 0; j < i; ++j) if (slots[j] == slots[i]) throw std::runtime_error("stream_admit: a slot is listed twice");
+    if (n_samples[i] < 1) throw std::runtime_error("empty audio clip");
+  }
+  const int Tc = cfg_.n_text_ctx;
+  // front-end + encoder of these clips as ONE batched pass on the admission stream (encoder scratch of clip indices
+  // 0..count-1; the decode step touches none of it), cross K/V scattered straight into the slots, which stay idle — their
+  // attention launches skip them — until stream_step has seen the event
+  struct StreamSwap {  // run_frontend / run_encoder enqueue on stream(): point it at the admission stream for this call
+    hipStream_t& u; hipStream_t keep;
+    StreamSwap(hipStream_t& us, hipStream_t to) : u(us), keep(us) { u = to; }
+    ~StreamSwap() { u = keep; }
+  } swap(user_stream_, admit_stream_);
+  HIP_CHECK(hipMemcpyAsync(d_slot_map_, slots, (size_t)count * 4, hipMemcpyHostToDevice, admit_stream_));  // run_frontend synchronises below
+  upload_pcm(pcm, n_samples, count);
+  run_frontend(d_pcm_, (int)pcm_stride_, n_samples, count, false, true);
+  run_encoder(count, d_slot_map_);
+  for (int i = 0; i < count; ++i) {
+    HIP_CHECK(hipEventRecord(ev_admit_[slots[i]], admit_stream_));
+    slot_state_[slots[i]] = kEncoding;
+    const int mn = max_new ? max_new[i] : 0;
+    slot_max_new_[slots[i]] = (mn > 0 && mn < Tc - 4) ? mn : Tc - 4;
+  }
+}
+
+// The call ENQUEUES n decoder steps and a read-back of the done flags and returns without waiting for them: what it
+// reports are the slots that had finished by the end of the PREVIOUS call's steps. The host therefore admits and collects
+// while the GPU runs the steps just enqueued (a finished slot is seen one call late; the device never waits for the host).
+int Engine::stream_step(int n_steps, int* finished_slots) {
+  HIP_CHECK(hipSetDevice(device_));
+  if (stream_slots_ == 0) throw std::runtime_error("stream_step: no stream open");
+  hipStream_t s = stream();
+  const int n = stream_slots_;
+  auto n_in = [&](int st) { int c = 0; for (int i = 0; i < n; ++i) c += slot_state_[i] == st; return c; };
+  // slots whose encoder has finished join the loop — checked before every step, so a clip joins within one step of its
+  // encoder's end; if nothing else is decoding the loop waits for the first of them
+  auto activate_ready = [&](bool wait_for_one) {
+    for (int i = 0; i < n; ++i) {
+      if (slot_state_[i] != kEncoding) continue;
+      hipError_t q = hipEventQuery(ev_admit_[i]);
+      if (q == hipErrorNotReady && wait_for_one) { HIP_CHECK(hipEventSynchronize(ev_admit_[i])); q = hipSuccess; }
+      if (q == hipErrorNotReady) continue;
+      HIP_CHECK(q);
+      wait_for_one = false;
+      hipLaunchKernelGGL(slot_reset_kernel, dim3(1), dim3(256), 0, s, i, slot_max_new_[i], d_sot_, d_off_, d_tok_, d_done_, d_nout_,
+                         d_max_new_clip_, tok_emb_, dec_pos_, d_xdec_, cfg_.n_text_state);
+      slot_state_[i] = kActive;
+      slot_act_call_[i] = call_no_;
+    }
+  };
+  ++call_no_;
+  const int cur = poll_parity_, prev = cur ^ 1;
+  auto harvest = [&](int which) {
+    for (int i = 0; i < n; ++i)
+      if (slot_state_[i] == kActive && slot_act_call_[i] <= poll_call_[which] && h_done_[(size_t)which * cap_ + i]) slot_state_[i] = kFinished;
+  };
+  if (n_in(kActive) + n_in(kEncoding) > 0) {
+    hipGraphExec_t g = step_graph(n, cfg_.n_text_ctx - 4);
+    for (int st = 0; st < std::max(1, n_steps); ++st) {
+      activate_ready(n_in(kActive) == 0 && n_in(kEncoding) > 0);
+      HIP_CHECK(hipGraphLaunch(g, s));
+    }
+    HIP_CHECK(hipMemcpyAsync(h_done_ + (size_t)cur * cap_, d_done_, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipEventRecord(ev_poll_[cur], s));
+    poll_pending_[cur] = true;
+    poll_call_[cur] = call_no_;
+    poll_parity_ = prev;
+  }
+  if (poll_pending_[prev]) {  // the previous call's flags (its steps ran while the host was admitting / collecting)
+    HIP_CHECK(hipEventSynchronize(ev_poll_[prev]));
+    poll_pending_[prev] = false;
+    harvest(prev);
+  } else if (poll_pending_[cur] && n_in(kEncoding) == 0 && n_in(kFinished) == 0) {
+    // nothing was in flight before this call: do not make a lone caller spin — wait for the steps just enqueued
+    HIP_CHECK(hipEventSynchronize(ev_poll_[cur]));
+    poll_pending_[cur] = false;
+    harvest(cur);
+  }
+  int n_fin = 0;
+  for (int i = 0; i < n; ++i)
+    if (slot_state_[i] == kFinished) finished_slots[n_fin++] = i;
+  return n_fin;
+}
+
+void Engine::stream_collect(int slot, int32_t* ids, int* n_ids) {
+  HIP_CHECK(hipSetDevice(device_));
+  if (stream_slots_ == 0) throw std::runtime_error("stream_collect: no stream open");
+  if (slot < 0 || slot >= stream_slots_ || slot_state_[slot] != kFinished) throw std::runtime_error("stream_collect: slot has not finished");
+  // on its own stream: the slot's ids are final (its done flag was seen), the decoder steps queued meanwhile do not touch them
+  HIP_CHECK(hipMemcpyAsync(ids, d_out_ids_ + (size_t)slot * cfg_.n_text_ctx, (size_t)cfg_.n_text_ctx * 4, hipMemcpyDeviceToHost, copy_stream_));
+  HIP_CHECK(hipMemcpyAsync(n_ids, d_nout_ + slot, 4, hipMemcpyDeviceToHost, copy_stream_));
+  HIP_CHECK(hipStreamSynchronize(copy_stream_));
+  slot_state_[slot] = kIdle;
+}
+
 float Engine::bench(const std::string& what, int batch, int arg, int iters) {
+  require_no_stream("bench");
   HIP_CHECK(hipSetDevice(device_));
   ensure_capacity(batch);
   hipStream_t s = stream();
@@ -1363,11 +1540,14 @@ float Engine::bench(const std::string& what, int batch, int arg, int iters) {
     hipGraphExec_t g = step_graph(batch, Tc - 4);
     arg = std::max(0, std::min(arg, Tc - 1 - iters));
     DecState st{arg, 0, 0, 0};
+    std::vector<int> offs(batch, arg);  // every slot at position `arg`
     HIP_CHECK(hipMemcpy(d_state_, &st, sizeof(st), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_off_, offs.data(), (size_t)batch * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipGraphLaunch(g, s));  // warm
     st.step = arg;
     HIP_CHECK(hipStreamSynchronize(s));
     HIP_CHECK(hipMemcpy(d_state_, &st, sizeof(st), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_off_, offs.data(), (size_t)batch * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipEventRecord(a, s));
     for (int i = 0; i < iters; ++i) HIP_CHECK(hipGraphLaunch(g, s));
     HIP_CHECK(hipEventRecord(b, s));

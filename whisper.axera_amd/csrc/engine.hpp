@@ -36,6 +36,11 @@ class Engine final : public IEngine {
   void get_cross_kv(int slot, float* k_out, float* v_out) override;
   void decode_forced(int batch, const int32_t* forced, int n_forced, float* logits, int32_t* argmax_ids) override;
   void decode_greedy(int batch, int max_new, const int* max_new_clip, int32_t* ids, int* n_ids) override;
+  void stream_open(int n_slots) override;
+  void stream_admit(const int* slots, const float* const* pcm, const int* n_samples, const int* max_new, int count) override;
+  int stream_step(int n_steps, int* finished_slots) override;
+  void stream_collect(int slot, int32_t* ids, int* n_ids) override;
+  void stream_close() override;
   float bench(const std::string& what, int batch, int arg, int iters) override;
   void set_stream(void* s) override { user_stream_ = static_cast<hipStream_t>(s); }
   const ModelConfig& config() const override { return cfg_; }
@@ -60,7 +65,7 @@ class Engine final : public IEngine {
   void free_slot_buffers();
   void upload_pcm(const float* const* pcm, const int* n_samples, int batch);
   void run_frontend(const float* d_pcm, int stride, const int* n_samples, int batch, bool want_ref_layout, bool staged = false);
-  void run_encoder(int batch);
+  void run_encoder(int batch, const int* d_slot_map = nullptr);  // cross K/V of clip b goes to slot d_slot_map[b] (device), else b
   void reset_decode_state(int batch, const int* max_new_clip = nullptr);
   void enqueue_decode_step(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits, long logits_stride,
                            int* d_argmax);
@@ -132,6 +137,22 @@ class Engine final : public IEngine {
   float* d_attn_mpart_ = nullptr;     // batched cross-attention in splits: partials and tickets (DecAttnParams::mpart / mcnt)
   unsigned* d_attn_mcnt_ = nullptr;
   int *d_tok_ = nullptr, *d_done_ = nullptr, *d_nout_ = nullptr, *d_out_ids_ = nullptr, *d_max_new_clip_ = nullptr;
+  int* d_off_ = nullptr;   // per-slot offsets (common.hpp: DecState)
+  // slot refill (stream_*): a slot is idle -> encoding (admitted, encoder in flight on admit_stream_) -> active (decoding)
+  // -> finished (done flag seen) -> idle again after stream_collect
+  enum SlotState : int { kIdle = 0, kEncoding = 1, kActive = 2, kFinished = 3 };
+  int stream_slots_ = 0;                 // > 0: a stream is open
+  std::vector<int> slot_state_, slot_max_new_;
+  std::vector<hipEvent_t> ev_admit_;     // one per slot: its encoder has finished
+  hipStream_t admit_stream_ = nullptr;
+  int* h_done_ = nullptr;                // pinned [2][cap]: done flags as of the end of the last two stream_step calls
+  hipEvent_t ev_poll_[2] = {nullptr, nullptr};
+  int poll_parity_ = 0; bool poll_pending_[2] = {false, false};
+  long call_no_ = 0, poll_call_[2] = {0, 0};  // a read-back speaks for a slot only if it was enqueued behind that slot's activation
+  std::vector<long> slot_act_call_;
+  hipStream_t copy_stream_ = nullptr;    // stream_collect's D2H copies: never behind the queued decoder steps
+  int* d_slot_map_ = nullptr;            // [cap]: clip index of an admission pass -> slot
+  void require_no_stream(const char* what) const;
   DecState* d_state_ = nullptr;
   int* h_poll_ = nullptr;  // pinned
   int split_self_ = 2, split_cross_ = 6;

@@ -114,7 +114,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
         } else if constexpr (EPI == EPI_CROSS_KV) {  // V rows [n_layer*d, 2*n_layer*d): [l][slot][head][t_pad][64]
           const int nv = n8 - p.n_layer * d;
           const int l = nv / d, c = nv - l * d;
-          const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + (c >> 6);
+          const long slot = ((long)l * p.n_batch_total + (p.kv_slot_map ? p.kv_slot_map[bz] : bz)) * (d >> 6) + (c >> 6);
           dst = reinterpret_cast<h16*>(p.C2) + (slot * p.t_pad + m) * 64 + (c & 63);
         } else {
           dst = reinterpret_cast<h16*>(p.C) + (long)bz * p.c_batch_stride + (long)m * p.ldc + n8;
@@ -187,7 +187,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&accw
           h16x4 pk;
 #pragma unroll
           for (int e = 0; e < 4; ++e) pk[e] = (h16)(acc[i][j][4 * q + e] + (p.bias ? p.bias[n + e] : 0.f));
-          const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + head;
+          const long slot = ((long)l * p.n_batch_total + (p.kv_slot_map ? p.kv_slot_map[bz] : bz)) * (d >> 6) + head;
           h16* dst = reinterpret_cast<h16*>(p.C) + slot * p.t_pad * 64 + (long)(m >> 6) * 4096 + (dd >> 3) * 512 + (m & 63) * 8 + (dd & 7);
           *reinterpret_cast<h16x4*>(dst) = pk;
         }
@@ -586,7 +586,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc
           h16x4 pk;
 #pragma unroll
           for (int e = 0; e < 4; ++e) pk[e] = (h16)(acc[nj][it][jt][e] + (p.bias ? p.bias[n + e] : 0.f));
-          const long slot = ((long)l * p.n_batch_total + bz) * (d >> 6) + head;
+          const long slot = ((long)l * p.n_batch_total + (p.kv_slot_map ? p.kv_slot_map[bz] : bz)) * (d >> 6) + head;
           h16* dst = reinterpret_cast<h16*>(p.C) + slot * p.t_pad * 64 + (long)(m >> 6) * 4096 + (dd >> 3) * 512 + (m & 63) * 8 + (dd & 7);
           *reinterpret_cast<h16x4*>(dst) = pk;
         }

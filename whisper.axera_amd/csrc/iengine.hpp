@@ -38,6 +38,12 @@ class IEngine {
   virtual void decode_forced(int batch, const int32_t* forced, int n_forced, float* logits, int32_t* argmax_ids) = 0;
   // max_new_clip: optional host [batch] per-clip id budgets (<= 0: none), each capped by max_new
   virtual void decode_greedy(int batch, int max_new, const int* max_new_clip, int32_t* ids, int* n_ids) = 0;
+  // utterance slots refilled while the others decode (include/ax_whisper_api.h: AX_WHISPER_Stream*)
+  virtual void stream_open(int n_slots) = 0;
+  virtual void stream_admit(const int* slots, const float* const* pcm, const int* n_samples, const int* max_new, int count) = 0;
+  virtual int stream_step(int n_steps, int* finished_slots) = 0;  // returns the number of finished slots written
+  virtual void stream_collect(int slot, int32_t* ids, int* n_ids) = 0;
+  virtual void stream_close() = 0;
   virtual float bench(const std::string& what, int batch, int arg, int iters) = 0;
   virtual void set_stream(void* hip_stream) = 0;
   virtual const ModelConfig& config() const = 0;

@@ -8,14 +8,22 @@
 //
 // What is new: the reference calls one non-re-entrant handle from cpp-httplib's thread pool with
 // no lock. Here connection threads only parse requests and enqueue them; one
-// batcher thread PER DEVICE (--devices all | 0,1,...; default: the one device of AX_WHISPER_Init)
-// drains the shared queue into micro-batches (up to --max_batch clips, waiting at most
-// --batch_wait_ms for stragglers) and runs them through AX_WHISPER_RunPCMBatch on its own handle:
-// utterance-level data parallelism inside a GPU (the batch) and across the GPUs of the node (the
-// batchers), with no cross-device synchronisation — an idle device simply takes the next requests.
+// scheduler thread PER DEVICE (--devices all | 0,1,...; default: the one device of AX_WHISPER_Init)
+// drains the shared queue on its own handle — utterance-level data parallelism inside a GPU and across
+// the GPUs of the node with no cross-device synchronisation: an idle device simply takes the next requests.
+//   --scheduler slots (default): --max_batch utterance SLOTS that are refilled as they finish
+//       (AX_WHISPER_Stream*): every clip stops at its own eot, as the reference's one-by-one loop does
+//       (Whisper.cpp:219-222), and the freed slot takes the next request while the other slots decode on.
+//       A lone request on an idle device still goes through the one-clip path (the persistent launch).
+//   --scheduler batches: micro-batches (up to --max_batch clips, waiting at most --batch_wait_ms for
+//       stragglers) through AX_WHISPER_RunPCMBatch; a batch returns when its slowest clip has finished.
+// Connections: at most --max_conns at a time (503 beyond), a body of at most --max_body_mb (413 beyond; 30 s of
+// audio is 1.92 MB), --recv_timeout_s per read, and a body that ends before its Content-Length is a 400, not a
+// transcription of half a clip.
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <sys/time.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
@@ -45,6 +53,11 @@ static std::mutex g_mu;
 static std::condition_variable g_cv;
 static std::deque<Job*> g_queue;
 static std::atomic<bool> g_stop{false};
+static std::atomic<int> g_conns{0}, g_busy_slots{0};
+static std::atomic<long> g_served{0};
+static std::vector<AX_WHISPER_HANDLE> g_models;  // for /health
+static int g_max_conns = 256, g_recv_timeout_s = 10;
+static size_t g_max_body = (size_t)16 << 20;
 
 static std::string json_escape(const std::string& s) {
   std::string o;
@@ -93,12 +106,105 @@ static void batcher(AX_WHISPER_HANDLE model, int max_batch, int wait_ms) {
     for (int i = 0; i < n; ++i) {
       jobs[i]->done.set_value({ok[i] && texts[i], texts[i] ? std::string(texts[i]) : std::string()});
       free(texts[i]);  // the reference never frees it (WhisperHTTPServer.hpp:77-90)
+      ++g_served;
     }
   }
 }
 
+// Slots that are refilled as they finish (AX_WHISPER_Stream*). One request alone on an idle device takes the one-clip
+// path instead (the persistent launch is 2x faster than a step sequence with one live slot).
+static void slot_scheduler(AX_WHISPER_HANDLE model, int n_slots, int wait_ms, int steps_per_call) {
+  const int Tc = std::max(1, AX_WHISPER_GetConfigInt(model, "n_text_ctx"));
+  std::vector<Job*> owner(n_slots, nullptr);
+  std::vector<int> fin(std::max(n_slots, 3));
+  std::vector<int32_t> ids(Tc);
+  int busy = 0, reported = 0;
+  bool open = false;
+  auto report = [&] { g_busy_slots += busy - reported; reported = busy; };  // /health sums the devices
+  auto fail = [](Job* j) { j->done.set_value({false, std::string()}); };
+  auto run_alone = [&](Job* j) {
+    const float* ptr = j->pcm.data();
+    int len = (int)j->pcm.size();
+    char* text = nullptr;
+    const bool ok = AX_WHISPER_RunPCMBatch(model, &ptr, &len, 1, &text) == 0 && text;
+    j->done.set_value({ok, text ? std::string(text) : std::string()});
+    free(text);
+    ++g_served;
+  };
+  while (!g_stop) {
+    std::vector<Job*> take;
+    {
+      std::unique_lock<std::mutex> lk(g_mu);
+      if (busy == 0) {
+        g_cv.wait(lk, [] { return g_stop || !g_queue.empty(); });
+        if (g_stop) break;
+        if (g_queue.size() == 1 && wait_ms > 0) g_cv.wait_for(lk, std::chrono::milliseconds(wait_ms), [] { return g_stop || g_queue.size() > 1; });
+      }
+      while (!g_queue.empty() && busy + (int)take.size() < n_slots) { take.push_back(g_queue.front()); g_queue.pop_front(); }
+    }
+    if (busy == 0 && take.size() == 1) {  // alone on an idle device
+      if (open) { AX_WHISPER_StreamClose(model); open = false; }
+      run_alone(take[0]);
+      continue;
+    }
+    if (!take.empty() && !open) {
+      if (AX_WHISPER_StreamOpen(model, n_slots) != 0) { for (Job* j : take) run_alone(j); continue; }
+      open = true;
+    }
+    if (!take.empty()) {
+      // every request taken now goes through ONE batched front-end + encoder pass into the idle slots; when the pass is
+      // refused (one bad request: e.g. non-finite samples) the requests are admitted one by one so that only that one fails
+      std::vector<int> sl;
+      std::vector<const float*> ptrs;
+      std::vector<int> lens;
+      for (int i = 0, s2 = 0; i < (int)take.size(); ++i) {
+        while (owner[s2]) ++s2;
+        sl.push_back(s2++);
+        ptrs.push_back(take[i]->pcm.data());
+        lens.push_back((int)take[i]->pcm.size());
+      }
+      if (AX_WHISPER_StreamAdmitBatch(model, sl.data(), ptrs.data(), lens.data(), nullptr, (int)take.size()) == 0) {
+        for (size_t i = 0; i < take.size(); ++i) owner[sl[i]] = take[i];
+        busy += (int)take.size();
+      } else {
+        for (size_t i = 0; i < take.size(); ++i) {
+          if (AX_WHISPER_StreamAdmit(model, sl[i], ptrs[i], lens[i], 0) != 0) { fail(take[i]); continue; }
+          owner[sl[i]] = take[i];
+          ++busy;
+        }
+      }
+    }
+    report();
+    if (busy == 0) continue;
+    int nfin = 0;
+    if (AX_WHISPER_StreamStep(model, steps_per_call, fin.data(), &nfin) != 0) {
+      for (int sl = 0; sl < n_slots; ++sl) if (owner[sl]) { fail(owner[sl]); owner[sl] = nullptr; }
+      busy = 0;
+      AX_WHISPER_StreamClose(model);
+      open = false;
+      continue;
+    }
+    for (int i = 0; i < nfin; ++i) {
+      const int sl = fin[i];
+      if (sl < 0 || sl >= n_slots || !owner[sl]) continue;
+      int n = 0;
+      char* text = nullptr;
+      const bool ok = AX_WHISPER_StreamCollect(model, sl, ids.data(), &n) == 0 && AX_WHISPER_Transcript(model, ids.data(), n, &text) == 0 && text;
+      owner[sl]->done.set_value({ok, text ? std::string(text) : std::string()});
+      free(text);
+      owner[sl] = nullptr;
+      --busy;
+      ++g_served;
+    }
+    report();
+  }
+  for (int sl = 0; sl < n_slots; ++sl) if (owner[sl]) fail(owner[sl]);
+  if (open) AX_WHISPER_StreamClose(model);
+}
+
 static void send_response(int fd, int status, const std::string& body) {
-  const char* reason = status == 200 ? "OK" : status == 400 ? "Bad Request" : status == 404 ? "Not Found" : "Internal Server Error";
+  const char* reason = status == 200 ? "OK" : status == 400 ? "Bad Request" : status == 404 ? "Not Found" : status == 413 ? "Payload Too Large"
+                       : status == 503 ? "Service Unavailable" : "Internal Server Error";
   std::string h = "HTTP/1.1 " + std::to_string(status) + " " + reason +
                   "\r\nContent-Type: application/json\r\nContent-Length: " + std::to_string(body.size()) +
                   "\r\nAccess-Control-Allow-Origin: *\r\nAccess-Control-Allow-Methods: POST, GET, OPTIONS\r\n"
@@ -115,7 +221,10 @@ static void send_response(int fd, int status, const std::string& body) {
 
 static std::string lower(std::string s) { std::transform(s.begin(), s.end(), s.begin(), ::tolower); return s; }
 
+struct ConnGuard { ~ConnGuard() { --g_conns; } };
+
 static void serve(int fd) {
+  ConnGuard guard;
   std::string buf;
   char tmp[65536];
   size_t hdr_end = std::string::npos;
@@ -136,14 +245,33 @@ static void serve(int fd) {
     const char* c = "HTTP/1.1 100 Continue\r\n\r\n";
     (void)!send(fd, c, strlen(c), MSG_NOSIGNAL);
   }
+  if (clen > g_max_body) {  // 30 s of audio is 1.92 MB; nothing longer than the cap is read at all
+    send_response(fd, 413, R"({"error": "Request body too large"})");
+    shutdown(fd, SHUT_RDWR);
+    close(fd);
+    return;
+  }
   std::string body = buf.substr(hdr_end + 4);
-  while (body.size() < clen && clen <= (1u << 30)) {
-    ssize_t r = recv(fd, tmp, sizeof tmp, 0);
+  while (body.size() < clen) {
+    ssize_t r = recv(fd, tmp, sizeof tmp, 0);  // SO_RCVTIMEO bounds every read
     if (r <= 0) break;
     body.append(tmp, (size_t)r);
   }
+  if (body.size() < clen) {  // the peer closed (or stalled) before the body was complete: not half a clip's transcript
+    send_response(fd, 400, R"({"error": "Request body is incomplete"})");
+    shutdown(fd, SHUT_RDWR);
+    close(fd);
+    return;
+  }
   if (first.rfind("GET /health", 0) == 0) {
-    send_response(fd, 200, R"({"status": "ok"})");
+    long giveups = 0;
+    for (AX_WHISPER_HANDLE m : g_models) giveups += std::max(0, AX_WHISPER_GetConfigInt(m, "persistent_giveups"));
+    size_t queued;
+    { std::lock_guard<std::mutex> lk(g_mu); queued = g_queue.size(); }
+    char hb[256];
+    snprintf(hb, sizeof hb, "{\"status\": \"ok\", \"devices\": %d, \"queued\": %zu, \"busy_slots\": %d, \"connections\": %d, \"served\": %ld, \"persistent_giveups\": %ld}",
+             (int)g_models.size(), queued, g_busy_slots.load(), g_conns.load(), g_served.load(), giveups);
+    send_response(fd, 200, hb);
   } else if (first.rfind("OPTIONS ", 0) == 0) {
     send_response(fd, 200, "{}");
   } else if (first.rfind("POST /asr", 0) != 0) {
@@ -175,8 +303,8 @@ static void serve(int fd) {
 }
 
 int main(int argc, char** argv) {
-  int port = 8080, max_batch = 16, wait_ms = 5;
-  std::string model_type = "turbo", model_path = "../models-mi355x", language = "zh", devices;
+  int port = 8080, max_batch = 16, wait_ms = 5, steps_per_call = 8, max_body_mb = 16;
+  std::string model_type = "turbo", model_path = "../models-mi355x", language = "zh", devices, scheduler = "slots";
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&](const char* lng, const char* sht, std::string& dst) -> bool {
@@ -190,8 +318,13 @@ int main(int argc, char** argv) {
     if (val("max_batch", nullptr, v)) { max_batch = std::max(1, atoi(v.c_str())); continue; }
     if (val("batch_wait_ms", nullptr, v)) { wait_ms = std::max(0, atoi(v.c_str())); continue; }
     if (val("model_type", "-t", model_type) || val("model_path", "-p", model_path) || val("language", "-l", language)) continue;
-    if (val("devices", nullptr, devices)) continue;
-    fprintf(stderr, "usage: %s [--port 8080] [-t model_type] [-p model_path] [-l language] [--max_batch 16] [--batch_wait_ms 5] [--devices all|0,1,..]\n", argv[0]);
+    if (val("devices", nullptr, devices) || val("scheduler", nullptr, scheduler)) continue;
+    if (val("steps_per_call", nullptr, v)) { steps_per_call = std::max(1, atoi(v.c_str())); continue; }
+    if (val("max_conns", nullptr, v)) { g_max_conns = std::max(1, atoi(v.c_str())); continue; }
+    if (val("max_body_mb", nullptr, v)) { max_body_mb = std::max(1, atoi(v.c_str())); continue; }
+    if (val("recv_timeout_s", nullptr, v)) { g_recv_timeout_s = std::max(1, atoi(v.c_str())); continue; }
+    fprintf(stderr, "usage: %s [--port 8080] [-t model_type] [-p model_path] [-l language] [--max_batch 16] [--batch_wait_ms 5] [--devices all|0,1,..]\n"
+                    "          [--scheduler slots|batches] [--steps_per_call 8] [--max_conns 256] [--max_body_mb 16] [--recv_timeout_s 10]\n", argv[0]);
     return a == "--help" || a == "-?" ? 0 : 1;
   }
   printf("port: %d\n", port);
@@ -226,6 +359,10 @@ int main(int argc, char** argv) {
   }
   if (models.empty()) { printf("init server failed!\n"); return -1; }
   printf("devices: %d\n", (int)models.size());
+  if (scheduler != "slots" && scheduler != "batches") { printf("--scheduler must be slots or batches\n"); return 1; }
+  printf("scheduler: %s\n", scheduler.c_str());
+  g_models = models;
+  g_max_body = (size_t)max_body_mb << 20;
 
   int srv = socket(AF_INET, SOCK_STREAM, 0);
   int one = 1;
@@ -239,12 +376,25 @@ int main(int argc, char** argv) {
   fflush(stdout);
 
   std::vector<std::thread> bts;
-  for (AX_WHISPER_HANDLE m : models) bts.emplace_back(batcher, m, max_batch, wait_ms);
+  for (AX_WHISPER_HANDLE m : models) {
+    if (scheduler == "slots" && max_batch >= 2) bts.emplace_back(slot_scheduler, m, max_batch, wait_ms, steps_per_call);
+    else bts.emplace_back(batcher, m, max_batch, wait_ms);
+  }
   signal(SIGPIPE, SIG_IGN);
   for (;;) {
     int fd = accept(srv, nullptr, nullptr);
     if (fd < 0) break;
     setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+    timeval tv{g_recv_timeout_s, 0};
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);  // a peer that stops sending holds its thread this long at most
+    setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+    if (++g_conns > g_max_conns) {  // one thread per connection, so connections are capped
+      send_response(fd, 503, R"({"error": "Too many connections"})");
+      shutdown(fd, SHUT_RDWR);
+      close(fd);
+      --g_conns;
+      continue;
+    }
     std::thread(serve, fd).detach();
   }
   g_stop = true;
