@@ -201,3 +201,32 @@ def test_ragged_small_batch_with_split_cross_attention(built_lib, micro_case, B)
         assert again == uniform
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("model_type,B", [("micro", 37), ("w512", 20)])
+def test_tail_launch_is_bit_identical_to_the_launch_per_layer_sequence(built_lib, oracle_mod, tmp_path, monkeypatch, model_type, B):
+    """AX_WHISPER_TAIL=1: the second half of every decoder layer (cross-attention projection -> LayerNorm + mlp.0 + GELU ->
+    mlp.2 -> LayerNorm + Q,K,V of the next layer) as ONE launch with in-launch hand-offs per 16-clip cluster
+    (csrc/decode_tail.hip). Same operands, same summation order: logits and ids must be BIT-equal to the default sequence,
+    on ragged clip counts (a partial last clip block), with 2 graph branches (37 clips) and in the slot stream."""
+    from conftest import ModelCase
+
+    case = ModelCase(tmp_path / "m", model_type, 5)
+    mels = np.stack(_mels(B))
+    forced = np.tile(np.arange(100, 124, dtype=np.int32), (B, 1))
+    out = {}
+    for tail in ("0", "1"):
+        monkeypatch.setenv("AX_WHISPER_TAIL", tail)
+        e = built_lib.Whisper(model_type, case.root, "zh", device=0, max_batch=B)
+        try:
+            assert e.L.AX_WHISPER_GetConfigInt(e.h, b"decode_tail") == int(tail)
+            e.encode_mel(mels)
+            lg, am = e.decode_forced(B, forced)
+            ids = e.decode_greedy(B, max_new=70)  # past the first key block
+            ragged = e.decode_greedy(B, max_new=40, max_new_clip=[5 + (7 * b) % 30 for b in range(B)])
+            out[tail] = (lg, am, ids, ragged)
+            assert e.L.AX_WHISPER_GetConfigInt(e.h, b"decode_tail") == int(tail)  # no launch gave up
+        finally:
+            e.close()
+    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
+    assert out["0"][2] == out["1"][2] and out["0"][3] == out["1"][3]

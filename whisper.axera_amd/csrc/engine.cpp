@@ -102,6 +102,7 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
   {  // persistent batch-1 decode: one workgroup per CU for the whole utterance (decode_persistent.hip)
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device_));
+    n_cu_ = prop.multiProcessorCount;
     const char* mode = getenv("AX_WHISPER_DECODE");
     const bool want = !(mode && std::string(mode) == "graph");
     persistent_ok_ = want && decode_persistent_supported(cfg_.n_text_state, cfg_.n_text_head, cfg_.n_text_layer, prop.multiProcessorCount);
@@ -130,6 +131,16 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
     if (const char* t = getenv("AX_WHISPER_CROSS_SPLIT")) cross_split_env_ = atoi(t);
     // encoder attention: rescale threshold of the running softmax maximum (tests run 0 = rescale on every increase)
     if (const char* t = getenv("AX_WHISPER_ENC_RESCALE_THR")) enc_rescale_thr_ = std::max(0.f, std::min(16.f, (float)atof(t)));
+  }
+  {  // batched decode: the second half of a layer as ONE launch (decode_tail.hip); needs the clip-block sequence.
+    // OFF unless AX_WHISPER_TAIL=1: measured on MI355X (Whisper-small, profiles/r03_tail_ab.txt) the three in-launch
+    // hand-offs cost what the three launch boundaries they replace cost (16 clips: step 0.653 vs 0.653 ms) and more
+    // once two graph branches run their tails side by side (64 clips: 1.143 -> 1.212 ms). Results are bit-identical.
+    const char* e = getenv("AX_WHISPER_TAIL");
+    tail_ok_ = e && e[0] == '1' && batched_ln_ && decode_tail_supported(cfg_.n_text_state);
+    d_tail_sync_ = (unsigned*)dalloc((size_t)kMaxBranches * kTailSyncWords * 4, true);
+    allocs_.push_back(d_tail_sync_);
+    cfg_.ints["decode_tail"] = tail_ok_ ? 1 : 0;
   }
   cfg_.ints["t2s"] = t2s_ ? 1 : 0;
   cfg_.ints["fp16"] = AXW_F16;  // 16-bit storage / MFMA operand type of this engine: 0 bfloat16, 1 IEEE half
@@ -832,7 +843,7 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
 // consumer and the residual add the epilogue of its producer, so a layer is 7 launches instead of 11
 // (AX_WHISPER_BATCHED_LN=0: the older sequence with a separate LayerNorm/h16-pair preparation launch and split-K
 // partials). b0 is a multiple of 16: every per-clip buffer of the range starts at a whole clip block.
-void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
+void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced, int branch) {
   const int d = cfg_.n_text_state, H = cfg_.n_text_head, L = cfg_.n_text_layer, Tc = cfg_.n_text_ctx;
   const long self_stride = (long)H * Tc * 64, cross_stride = (long)H * t_pad_ * 64;
   const long frag0 = (long)(b0 / 16) * 512;  // fragment-major pair layouts: clip blocks are 512 elements apart within a k-step
@@ -872,6 +883,11 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
   // two row tiles per workgroup where one would make more workgroups than can be resident at once
   auto rt_for = [&](int N) { return (N / 16) * n_blk > 512 ? 2 : 1; };
 
+  // One launch for the second half of a layer (decode_tail.hip) when every workgroup of every branch can be resident at
+  // once: clusters of decode_tail_cluster(d) workgroups per clip block, one workgroup per CU
+  const int tail_w = decode_tail_cluster(d);
+  const bool tail = tail_ok_ && fuse_cq && (step_mask_ & 1) && branch < kMaxBranches && n_blk <= 15 && tail_w * step_blocks_ <= n_cu_;
+
   for (int l = 0; l < L; ++l) {
     const DecLayerW& w = dec_[l];
     const DecLayerWP& wq = dec_packed_[l];
@@ -882,7 +898,7 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
     DecCGemmParams c = cgemm(wq.w_qkv, w.b_qkv, 3 * d, d, GEPI_QKV_CACHE, rt_for(3 * d));
     c.x = x; c.ln_w = w.attn_ln_w; c.ln_b = w.attn_ln_b;
     c.out = qd; c.k_cache = sk; c.v_cache = sv; c.kv_batch_stride = self_stride;
-    cgo(c);
+    if (!tail || l == 0) cgo(c);  // with the tail launch, layer l's Q,K,V come out of layer l-1's tail
     if (step_mask_ & 2) launch_decode_attention(attn(sk, sv, self_stride, -1, Tc / 64), s);
     c = cgemm(wq.w_o, w.b_o, d, d, GEPI_RESID, 1);
     c.a_hi = att_hi; c.a_lo = att_lo; c.out = x;
@@ -901,6 +917,23 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
       c.x = x; c.ln_w = w.cross_ln_w; c.ln_b = w.cross_ln_b; c.out = qd;
       cgo(c);
       if (step_mask_ & 2) launch_decode_attention(attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64), s);
+    }
+    if (tail) {
+      DecTailParams t{};
+      t.w_co = wq.w_co; t.b_co = w.b_co; t.w_fc1 = wq.w_fc1; t.b_fc1 = w.b_fc1; t.w_fc2 = wq.w_fc2; t.b_fc2 = w.b_fc2;
+      t.ln2_w = w.mlp_ln_w; t.ln2_b = w.mlp_ln_b;
+      t.att_hi = att_hi; t.att_lo = att_lo; t.hid_hi = hid_hi; t.hid_lo = hid_lo; t.x = x;
+      if (l + 1 < L) {
+        t.w_qkv = dec_packed_[l + 1].w_qkv; t.b_qkv = dec_[l + 1].b_qkv; t.ln1_w = dec_[l + 1].attn_ln_w; t.ln1_b = dec_[l + 1].attn_ln_b;
+        t.q_out = qd;
+        t.k_cache = d_self_k_ + ((size_t)(l + 1) * cap_ + b0) * self_stride;
+        t.v_cache = d_self_v_ + ((size_t)(l + 1) * cap_ + b0) * self_stride;
+        t.kv_batch_stride = self_stride; t.n_ctx_pad = Tc; t.off = d_off_ + b0;
+      }
+      t.d = d; t.batch = nb; t.nbs = nbs_; t.wgs_per_cluster = tail_w;
+      t.sync = d_tail_sync_ + (size_t)branch * kTailSyncWords;
+      launch_decode_tail(t, s);
+      continue;
     }
     c = cgemm(wq.w_co, w.b_co, d, d, GEPI_RESID, 1);
     c.a_hi = att_hi; c.a_lo = att_lo; c.out = x;
@@ -998,8 +1031,13 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     // the ONE step graph, so one branch's latency-bound chain of small GEMMs overlaps the other's bandwidth-bound
     // attention launches (a single chain leaves the chip idle between its ~85 dependent launches).
     const int nbr = decode_branches(batch);
+    {  // clip blocks of all branches together: every workgroup of every tail launch in flight must fit the device
+      const int per = nbr == 1 ? batch : ((batch + nbr - 1) / nbr + 15) / 16 * 16;
+      step_blocks_ = 0;
+      for (int i = 0; i < nbr; ++i) step_blocks_ += (std::max(0, std::min(per, batch - i * per)) + 15) / 16;
+    }
     if (nbr == 1) {
-      enqueue_layers_cblock(0, batch, s, d_forced != nullptr);
+      enqueue_layers_cblock(0, batch, s, d_forced != nullptr, 0);
     } else {
       const int per = ((batch + nbr - 1) / nbr + 15) / 16 * 16;
       HIP_CHECK(hipEventRecord(ev_fork_, s));
@@ -1008,7 +1046,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
         if (nb <= 0) break;
         hipStream_t bs = i == 0 ? s : branch_stream_[i - 1];
         if (i > 0) HIP_CHECK(hipStreamWaitEvent(bs, ev_fork_, 0));
-        enqueue_layers_cblock(b0, nb, bs, d_forced != nullptr);
+        enqueue_layers_cblock(b0, nb, bs, d_forced != nullptr, i);
         if (i > 0) {
           HIP_CHECK(hipEventRecord(ev_join_[i - 1], bs));
           HIP_CHECK(hipStreamWaitEvent(s, ev_join_[i - 1], 0));
@@ -1085,6 +1123,25 @@ void Engine::persistent_succeeded() {
   cfg_.ints["persistent_decode"] = 1;
 }
 
+// A tail launch whose workgroups could not all be resident gives up after 50 ms and raises its branch's error word: the
+// results of that decode are void. The path is switched off for this engine and the caller runs the decode again.
+bool Engine::tail_failed() {
+  if (!tail_ok_) return false;
+  unsigned h[kMaxBranches * kTailSyncWords];
+  HIP_CHECK(hipMemcpy(h, d_tail_sync_, sizeof h, hipMemcpyDeviceToHost));
+  bool bad = false;
+  for (int b = 0; b < kMaxBranches; ++b) bad |= h[b * kTailSyncWords + 2] != 0;
+  if (!bad) return false;
+  fprintf(stderr, "[ax_whisper] a decoder tail launch gave up (its workgroups were not all resident); using the launch-per-layer sequence from now on\n");
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemset(d_tail_sync_, 0, sizeof h));
+  tail_ok_ = false;
+  cfg_.ints["decode_tail"] = 0;
+  for (auto& g : graphs_) (void)hipGraphExecDestroy(g.second);  // captured with the tail launches
+  graphs_.clear();
+  return true;
+}
+
 hipGraphExec_t Engine::step_graph(int batch, int max_new) {
   const long key = ((long)batch * 1024 + max_new) * 16 + step_mask_;
   auto it = graphs_.find(key);
@@ -1125,6 +1182,7 @@ int Engine::greedy_loop(int batch, int max_new, const int* max_new_clip) {
     if (b == batch) { persistent_succeeded(); return steps; }
     persistent_gave_up();  // these utterances (and the next few) take the launch-per-phase path
   }
+  for (int attempt = 0;; ++attempt) {
   reset_decode_state(batch, max_new_clip);
   hipGraphExec_t g = step_graph(batch, max_new);
   hipStream_t s = stream();
@@ -1145,7 +1203,12 @@ int Engine::greedy_loop(int batch, int max_new, const int* max_new_clip) {
       ++polls;
     }
   }
+  if (tail_ok_ && batch > gemv_max_) {  // a tail launch that gave up voids this decode: once more without that path
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (attempt == 0 && tail_failed()) continue;
+  }
   return steps;
+  }
 }
 
 int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float* d_logits, int* d_argmax, int slot) {
@@ -1347,6 +1410,15 @@ void Engine::decode_forced(int batch, const int32_t* forced, int n_forced, float
     enqueue_decode_step(batch, cfg_.n_text_ctx, d_forced, n_forced, lrow, (long)rows * nv, d_arg);
   }
   HIP_CHECK(hipStreamSynchronize(s));
+  if (!done && tail_failed()) {  // void results: the same steps again through the launch-per-layer sequence
+    reset_decode_state(batch);
+    for (int st = 0; st < 4 + n_forced; ++st) {
+      const int gi = st - 3;
+      float* lrow = (d_logits && gi >= 0) ? d_logits + (size_t)gi * nv : nullptr;
+      enqueue_decode_step(batch, cfg_.n_text_ctx, d_forced, n_forced, lrow, (long)rows * nv, d_arg);
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
   if (logits) HIP_CHECK(hipMemcpy(logits, d_logits, (size_t)batch * rows * nv * 4, hipMemcpyDeviceToHost));
   if (argmax_ids) HIP_CHECK(hipMemcpy(argmax_ids, d_arg, (size_t)batch * rows * 4, hipMemcpyDeviceToHost));
 }
