@@ -19,7 +19,8 @@
 // storing waves drain vmcnt, a workgroup barrier, ONE lane adds to the phase's counter (agent scope); the consumer's
 // lane 0 polls the counter with sc1 loads, a workgroup barrier, then every wave reads the payload with sc1 loads.
 // Arithmetic, operand layouts and summation order are decode_cgemm_kernel's (k-steps round-robin over 8 waves, hi then lo
-// MFMA per k-step, waves folded 0..7 onto the bias): results are bit-identical to the launch-per-layer sequence.
+// MFMA per k-step, waves folded 0..7 onto the bias): results are bit-identical to the launch-per-layer sequence at
+// d = 512 (tests/test_gpu_batched.py; at d = 128 the compiler contracts the two kernels' LayerNorm arithmetic differently: 2e-5).
 // Every wait is bounded in time; a workgroup that gives up sets an error word that the host checks (engine.cpp).
 #include "common.hpp"
 #include <algorithm>

@@ -135,7 +135,7 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
   {  // batched decode: the second half of a layer as ONE launch (decode_tail.hip); needs the clip-block sequence.
     // OFF unless AX_WHISPER_TAIL=1: measured on MI355X (Whisper-small, profiles/r03_tail_ab.txt) the three in-launch
     // hand-offs cost what the three launch boundaries they replace cost (16 clips: step 0.653 vs 0.653 ms) and more
-    // once two graph branches run their tails side by side (64 clips: 1.143 -> 1.212 ms). Results are bit-identical.
+    // once two graph branches run their tails side by side (64 clips: 1.143 -> 1.212 ms). Same results (bit-identical at d = 512, tests/test_gpu_batched.py).
     const char* e = getenv("AX_WHISPER_TAIL");
     tail_ok_ = e && e[0] == '1' && batched_ln_ && decode_tail_supported(cfg_.n_text_state);
     d_tail_sync_ = (unsigned*)dalloc((size_t)kMaxBranches * kTailSyncWords * 4, true);
