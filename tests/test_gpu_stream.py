@@ -92,3 +92,52 @@ def test_stream_one_and_two_slots_and_full_context(built_lib, micro_case):
         assert got1 == got[1:4]
     finally:
         e.close()
+
+
+def test_stream_edge_cases(built_lib, micro_case, oracle_mod):
+    """A clip longer than the 60 s staging row admitted into a slot next to short ones (its clamp floor still comes from ALL of
+    its frames), a poisoned clip (NaN) refused at admission without disturbing the slots that are decoding, collecting a slot
+    that has not finished, a step call with nothing admitted, and the half build of the engine (F16 weights) through the
+    same stream."""
+    import modelgen
+    from conftest import ModelCase
+
+    e = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=4)
+    try:
+        long_clip = modelgen.synth_long_clip(75, 70)
+        short = [modelgen.synth_clip(90 + i, 100000) for i in range(3)]
+        want_long = e.run_tokens(long_clip, max_new=12)
+        want_short = [e.run_tokens(c, max_new=12) for c in short]
+        e.stream_open(4)
+        assert e.stream_step(4) == []            # nothing admitted: returns at once
+        e.stream_admit_batch([2, 0], [short[0], long_clip], [12, 12])
+        bad = short[1].copy()
+        bad[5] = np.inf
+        with pytest.raises(RuntimeError):
+            e.stream_admit(1, bad, 12)            # refused; slot 1 stays idle
+        with pytest.raises(RuntimeError):
+            e.stream_collect(2)                   # not finished yet
+        e.stream_admit_batch([1, 3], short[1:], [12, 12])
+        got = {}
+        for _ in range(200):
+            for sl in e.stream_step(3):
+                got[sl] = e.stream_collect(sl)
+            if len(got) == 4:
+                break
+        e.stream_close()
+        assert got[0] == want_long and got[2] == want_short[0] and got[1] == want_short[1] and got[3] == want_short[2]
+    finally:
+        e.close()
+    case16 = ModelCase(micro_case.root + "_f16_stream", "micro", 11, dtype="F16")
+    e = built_lib.Whisper("micro", case16.root, "zh", device=0, max_batch=3)
+    try:
+        assert e.L.AX_WHISPER_GetConfigInt(e.h, b"fp16") == 1
+        clips = [modelgen.synth_clip(120 + i, 200000) for i in range(5)]
+        got, _ = e.run_stream(clips, 3, max_new=[9, 30, 4, 17, 11])
+        for i, c in enumerate(clips):
+            mel, _, _ = oracle_mod.log_mel(c, 80)
+            ck, cv = case16.oracle_bf16.encoder(mel)
+            ids, lg = case16.oracle_bf16.greedy(ck, cv, "zh", max_new=[9, 30, 4, 17, 11][i], want_logits=True)
+            assert_ids_equal_or_tie(e, mel, got[i], ids, lg, f"fp16 stream clip {i}")
+    finally:
+        e.close()
