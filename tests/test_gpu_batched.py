@@ -26,7 +26,7 @@ def engine(built_lib, micro_case):
     e.close()
 
 
-@pytest.mark.parametrize("B", [3, 4, 5, 16, 21, 50])  # 3-5 clips: cross-attention key blocks split over several workgroups
+@pytest.mark.parametrize("B", [3, 4, 5, 16, 21, 24, 44, 50])  # 3-5 clips: cross-attention key blocks split over several workgroups; 24 / 44 / 50 clips: 2 / 3 / 2 graph branches
 def test_batched_teacher_forced_logits_vs_oracle(engine, micro_case, B):
     mels = _mels(B)
     engine.encode_mel(np.stack(mels))

@@ -947,13 +947,26 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced, i
   }
 }
 
-// Branches of the batched step graph (see enqueue_decode_step_batched): 1 below 32 clips, else 2 (AX_WHISPER_DECODE_BRANCHES
-// overrides: 1, 2 or 4).
+// Branches of the batched step graph (see enqueue_decode_step_batched), whole clip blocks each (the last one may be
+// partial). Measured on MI355X, Whisper-small, step t = 224 (profiles/r03_branch_table.txt; A/B/A/B per clip count):
+//   up to 21 clips  1 branch   (21 clips: 0.720 ms with one, 0.723 with two)
+//   22 .. 39        2 branches (16 + rest: 22 clips 0.809 -> 0.735 ms, 24: 0.818 -> 0.754, 28: 0.840 -> 0.790, 31: 0.853 -> 0.817;
+//                               an attention launch of more than 256 workgroups — 22 clips x 12 heads — leaves a few CUs with two
+//                               workgroups and everybody waits for them; two launches side by side do not)
+//   40 .. 48        3 branches (16 + 16 + rest: 40 clips 0.955 -> 0.936 ms, 44: 1.006 -> 0.988, 48: 1.034 -> 1.005)
+//   49 and more     2 branches (4 branches at 56 / 64 clips: 1.093 -> 1.13-1.16 / 1.152 -> 1.22 ms)
+// AX_WHISPER_DECODE_BRANCHES overrides (1, 2, 3 or 4; AX_WHISPER_BRANCH_MIN: fewest clips per branch it may leave, default 6).
 int Engine::decode_branches(int batch) const {
   static const int forced = [] { const char* e = getenv("AX_WHISPER_DECODE_BRANCHES"); return e ? atoi(e) : 0; }();
-  int n = forced > 0 ? forced : (batch >= 32 ? 2 : 1);
+  static const int min_per = [] { const char* e = getenv("AX_WHISPER_BRANCH_MIN"); return e ? std::max(1, atoi(e)) : 6; }();
+  int n = forced > 0 ? forced : (batch < 22 ? 1 : batch < 40 ? 2 : batch <= 48 ? 3 : 2);
   n = std::min(n, kMaxBranches);
-  while (n > 1 && (batch + n - 1) / n < 16) n /= 2;  // at least one whole clip block per branch
+  // every branch gets whole clip blocks; the last one at least min_per clips
+  while (n > 1) {
+    const int per = ((batch + n - 1) / n + 15) / 16 * 16;
+    if (batch - (n - 1) * per >= min_per) break;
+    --n;
+  }
   return std::max(n, 1);
 }
 
