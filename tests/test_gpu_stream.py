@@ -141,3 +141,28 @@ def test_stream_edge_cases(built_lib, micro_case, oracle_mod):
             assert_ids_equal_or_tie(e, mel, got[i], ids, lg, f"fp16 stream clip {i}")
     finally:
         e.close()
+
+
+def test_stream_at_turbo_width(built_lib, tmp_path):
+    """d_model 1280 takes the other batched step sequence (split-K GEMMs + LayerNorm preparation launches, 128 mels): slots at
+    different offsets through it, against the same clips as one ragged batch and on their own."""
+    import modelgen
+    from conftest import ModelCase
+
+    case = ModelCase(tmp_path / "w1280", "w1280", 3)
+    e = built_lib.Whisper("w1280", case.root, "zh", device=0, max_batch=4)
+    try:
+        clips = [modelgen.synth_clip(150 + i, 90000 + 40000 * i) for i in range(9)]
+        budgets = [7, 33, 12, 70, 5, 21, 40, 9, 16]
+        got, _ = e.run_stream(clips, 4, max_new=budgets, steps_per_call=3)
+        assert [len(g) for g in got] == budgets
+        alone = [e.run_tokens(c, max_new=b) for c, b in zip(clips, budgets)]
+        assert sum(a == g for a, g in zip(alone, got)) >= 8
+        for g0 in (0, 4):
+            grp = clips[g0:g0 + 4]
+            mels = np.stack([e.compute_mel(c) for c in grp])
+            e.encode_mel(mels)
+            want = e.decode_greedy(4, max_new=70, max_new_clip=budgets[g0:g0 + 4])
+            assert want == got[g0:g0 + 4]
+    finally:
+        e.close()
