@@ -221,11 +221,15 @@ def test_server_one_batcher_per_device(built_lib, micro_case):
             r = urllib.request.urlopen(req, timeout=120)
             return r.status, json.load(r)
 
-        out = [None] * 9
-        th = [threading.Thread(target=lambda i=i: out.__setitem__(i, post(pcm.tobytes()))) for i in range(9)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        assert all(o[0] == 200 and o[1]["text"] == want for o in out)
+        # three bursts: the first one makes both handles grow their slot buffers and capture their step graphs AT THE SAME TIME
+        # on one device (round 3: without the per-device capture mutex they invalidated each other's capture and every later
+        # request of that handle failed)
+        for _ in range(3):
+            out = [None] * 9
+            th = [threading.Thread(target=lambda i=i: out.__setitem__(i, post(pcm.tobytes()))) for i in range(9)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert all(o is not None and o[0] == 200 and o[1]["text"] == want for o in out), out
     finally:
         proc.kill()
         head = proc.stdout.read(400)

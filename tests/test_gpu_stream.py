@@ -166,3 +166,42 @@ def test_stream_at_turbo_width(built_lib, tmp_path):
             assert want == got[g0:g0 + 4]
     finally:
         e.close()
+
+
+def test_two_handles_on_one_device_capture_side_by_side(built_lib, micro_case):
+    """Two handles on ONE GPU (whisper_srv --devices 0,0; a bf16 and an fp16 model in one process) that open their slot
+    streams, grow their buffers and capture their step graphs at the same moment from two host threads: allocation and
+    synchronous copies of one must not invalidate the stream capture of the other (per-device capture mutex, iengine.hpp)."""
+    import threading
+
+    import modelgen
+
+    clips = [modelgen.synth_clip(200 + i, 120000) for i in range(6)]
+    engines = [built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=1) for _ in range(2)]
+    try:
+        want = [engines[0].run_tokens(c, max_new=10) for c in clips]
+        res, err = [None, None], [None, None]
+        bar = threading.Barrier(2)
+
+        def work(k):
+            try:
+                bar.wait()
+                outs = []
+                for n_slots in (3, 5, 4):  # every open grows the capacity or captures a new graph
+                    got, _ = engines[k].run_stream(clips, n_slots, max_new=10, steps_per_call=2)
+                    outs.append(got)
+                    engines[k].run_tokens_batch(clips[:n_slots], max_new=3)  # and the batched entry point's graph of that size
+                res[k] = outs
+            except Exception as e:  # noqa: BLE001
+                err[k] = e
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert err == [None, None], err
+        for k in range(2):
+            for got in res[k]:
+                assert sum(g == w for g, w in zip(got, want)) >= 5 and all(len(g) == 10 for g in got)
+    finally:
+        for e in engines:
+            e.close()

@@ -28,6 +28,10 @@
 using Engine = axw::IEngine;
 
 namespace axw {
+std::recursive_mutex& device_capture_mutex(int device) {
+  static std::recursive_mutex mu[64];
+  return mu[device & 63];
+}
 std::mutex& persistent_launch_mutex(int device) {
   static std::mutex mu[64];  // one per device: engines of different GPUs never wait for each other
   return mu[device & 63];

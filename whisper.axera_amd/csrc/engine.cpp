@@ -77,6 +77,7 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
   }
   if (device >= n_dev) throw std::runtime_error("HIP device ordinal out of range");
   device_ = device;
+  std::lock_guard<std::recursive_mutex> capture_lock(device_capture_mutex(device_));  // allocations + synchronous copies (iengine.hpp)
   HIP_CHECK(hipSetDevice(device_));
   device_set_ = true;
   HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
@@ -152,6 +153,7 @@ Engine::~Engine() { destroy(); }
 
 void Engine::destroy() {
   if (!device_set_) return;  // nothing was created
+  std::lock_guard<std::recursive_mutex> capture_lock(device_capture_mutex(device_));
   (void)hipSetDevice(device_);
   (void)hipDeviceSynchronize();
   free_slot_buffers();  // also destroys the captured step graphs
@@ -512,6 +514,7 @@ void Engine::free_slot_buffers() {
 
 void Engine::ensure_capacity(int batch) {
   if (batch <= cap_) return;
+  std::lock_guard<std::recursive_mutex> capture_lock(device_capture_mutex(device_));
   HIP_CHECK(hipDeviceSynchronize());
   free_slot_buffers();
   const int B = batch, d = cfg_.n_text_state, nm = cfg_.n_mels, H = cfg_.n_text_head, L = cfg_.n_text_layer;
@@ -1155,20 +1158,46 @@ bool Engine::tail_failed() {
   return true;
 }
 
+// After a failed capture the engine's own streams may be left in capture state ("operation failed due to a previous error
+// during capture" on everything enqueued afterwards): they are replaced.
+void Engine::recover_streams() {
+  (void)hipGetLastError();
+  auto renew = [](hipStream_t& st) {
+    if (!st) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool bad = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    if (!bad) return;
+    (void)hipStreamDestroy(st);
+    st = nullptr;
+    (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  };
+  renew(own_stream_);
+  for (auto& b : branch_stream_) renew(b);
+  (void)hipGetLastError();
+}
+
 hipGraphExec_t Engine::step_graph(int batch, int max_new) {
   const long key = ((long)batch * 1024 + max_new) * 16 + step_mask_;
   auto it = graphs_.find(key);
   if (it != graphs_.end()) return it->second;
   hipStream_t s = stream();
   hipGraph_t graph = nullptr;
+  // nobody on this device allocates, copies synchronously or captures while this capture is open (iengine.hpp)
+  std::lock_guard<std::recursive_mutex> capture_lock(device_capture_mutex(device_));
   HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  hipError_t cap_err = hipSuccess;
   try {
     enqueue_decode_step(batch, max_new, nullptr, 0, nullptr, 0, nullptr);
+    cap_err = hipStreamEndCapture(s, &graph);
   } catch (...) {
     (void)hipStreamEndCapture(s, &graph);
+    recover_streams();
     throw;
   }
-  HIP_CHECK(hipStreamEndCapture(s, &graph));
+  if (cap_err != hipSuccess || !graph) {  // an invalidated capture must not leave the engine's streams unusable for good
+    recover_streams();
+    throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(cap_err) + " capturing the decoder step");
+  }
   hipGraphExec_t exec = nullptr;
   HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
   HIP_CHECK(hipGraphDestroy(graph));
@@ -1371,6 +1400,7 @@ void Engine::encode_mel(const float* mel, int batch) {
 
 // back to the reference's layout [n_text_layer][1500][d] fp32 (export_onnx.py:212-213)
 void Engine::get_cross_kv(int slot, float* k_out, float* v_out) {
+  std::lock_guard<std::recursive_mutex> capture_lock(device_capture_mutex(device_));
   HIP_CHECK(hipSetDevice(device_));
   if (slot < 0 || slot >= cap_) throw std::runtime_error("slot out of range");
   const int d = cfg_.n_text_state, H = cfg_.n_text_head, L = cfg_.n_text_layer, T = cfg_.n_audio_ctx;
@@ -1394,6 +1424,7 @@ void Engine::get_cross_kv(int slot, float* k_out, float* v_out) {
 
 void Engine::decode_forced(int batch, const int32_t* forced, int n_forced, float* logits, int32_t* argmax_ids) {
   require_no_stream("decode_forced");
+  std::lock_guard<std::recursive_mutex> capture_lock(device_capture_mutex(device_));
   HIP_CHECK(hipSetDevice(device_));
   if (batch < 1 || batch > cap_) throw std::runtime_error("decode_forced: batch exceeds the encoded slots");
   if (n_forced < 0 || n_forced + 4 > cfg_.n_text_ctx) throw std::runtime_error("decode_forced: n_forced out of range");
@@ -1468,6 +1499,7 @@ __global__ static void slot_reset_kernel(int slot, int max_new, const int* sot, 
 }
 
 void Engine::stream_open(int n_slots) {
+  std::lock_guard<std::recursive_mutex> capture_lock(device_capture_mutex(device_));
   HIP_CHECK(hipSetDevice(device_));
   if (n_slots < 1) throw std::runtime_error("stream_open: n_slots must be >= 1");
   if (user_stream_) throw std::runtime_error("stream_open: not with a caller-supplied stream (AX_WHISPER_SetStream)");

@@ -74,6 +74,7 @@ class Engine final : public IEngine {
   void enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced, int branch = 0);
   int decode_branches(int batch) const;
   hipGraphExec_t step_graph(int batch, int max_new);
+  void recover_streams();
   int greedy_loop(int batch, int max_new, const int* max_new_clip = nullptr);
   // batch 1: the whole loop as one persistent launch (decode_persistent.hip); returns steps run, -1 if it gave up
   int run_persistent(int max_new, const int* d_forced, int n_forced, float* d_logits, int* d_argmax, int slot = 0);

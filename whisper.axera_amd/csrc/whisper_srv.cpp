@@ -349,7 +349,8 @@ int main(int argc, char** argv) {
   }
   std::vector<AX_WHISPER_HANDLE> models;
   for (int d : devs) {
-    AX_WHISPER_HANDLE m = AX_WHISPER_InitEx(model_type.c_str(), model_path.c_str(), language.c_str(), d, max_batch);
+    // (the slot stream runs at least three slots underneath: capacity for them is allocated here, not at the first request)
+    AX_WHISPER_HANDLE m = AX_WHISPER_InitEx(model_type.c_str(), model_path.c_str(), language.c_str(), d, std::max(max_batch, 3));
     if (!m) {
       printf("init server failed!\n");
       for (AX_WHISPER_HANDLE o : models) AX_WHISPER_Uninit(o);
