@@ -132,7 +132,9 @@ AX_WHISPER_API int AX_WHISPER_Transcript(AX_WHISPER_HANDLE handle, const int32_t
  *   StreamOpen(n_slots)  all slots idle; the batched entry points above are refused until StreamClose
  *   StreamAdmit(slot..)  front-end + encoder of one clip on a second stream into an idle slot's cross-K/V; the slot joins
  *                        the decode loop at the first StreamStep after its encoder has finished
- *   StreamStep(n_steps)  n decoder steps over all slots (captured step graph); returns the slots that have finished
+ *   StreamStep(n_steps)  up to n decoder steps over all slots (captured step graph); finished slots are seen through
+ *                        host-mapped flags between two steps (no wait), their successors join at once; returns the slots
+ *                        that have finished
  *   StreamCollect(slot)  ids of a finished slot; the slot is idle again */
 AX_WHISPER_API int AX_WHISPER_StreamOpen(AX_WHISPER_HANDLE handle, int n_slots);
 /** max_new <= 0: until eot or the end of the context. pcm is copied before the call returns. -1 if the slot is busy. */

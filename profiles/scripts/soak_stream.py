@@ -3,7 +3,7 @@ weights never emit it; real utterances of 5-30 s end in that range) through
   (a) refilled slots (AX_WHISPER_Stream*: a finished slot takes the next clip at once), and
   (b) micro-batches of the same size (AX_WHISPER_RunPCMBatchTokens-style: a batch returns with its slowest clip),
 both with host PCM, front-end and encoder included. Prints clips/s of both and checks the ids agree.
-usage: soak_stream.py [model small] [n_clips 192] [slots 16,32,64]"""
+usage: soak_stream.py [model small] [n_clips 384] [slots 16,32,64]"""
 import os
 import sys
 import time
@@ -17,7 +17,7 @@ import modelgen  # noqa: E402
 import whisper_axera_amd as wa  # noqa: E402
 
 model = sys.argv[1] if len(sys.argv) > 1 else "small"
-n_clips = int(sys.argv[2]) if len(sys.argv) > 2 else 192
+n_clips = int(sys.argv[2]) if len(sys.argv) > 2 else 384
 slot_list = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "16,32,64").split(",")]
 mdir = os.environ.get("AXW_BENCH_MODEL_DIR", "/tmp/axw_bench_models")
 if not os.path.exists(os.path.join(mdir, model, model + ".safetensors")):
@@ -30,7 +30,8 @@ for n_slots in slot_list:
     e = wa.Whisper(model, mdir, "zh", device=0, max_batch=n_slots)
     e.run_stream(clips[:n_slots], n_slots, max_new=4)  # warm: graph capture, encoder workspaces
     t0 = time.perf_counter()
-    got, calls = e.run_stream(clips, n_slots, max_new=budgets, steps_per_call=8)
+    got, calls = e.run_stream(clips, n_slots, max_new=budgets, steps_per_call=int(os.environ.get("AXW_STEPS_PER_CALL", "8")),
+                              min_admit=int(os.environ.get("AXW_MIN_ADMIT", "1")))
     t_stream = time.perf_counter() - t0
     # micro-batches: front-end + encoder + ragged decode per group of n_slots (the existing batched entry points)
     e.run_tokens_batch(clips[:n_slots], max_new=4)

@@ -276,9 +276,10 @@ class Whisper:
     def stream_close(self):
         self._check(self.L.AX_WHISPER_StreamClose(self.h), "StreamClose")
 
-    def run_stream(self, clips, n_slots: int, max_new=0, steps_per_call: int = 8):
+    def run_stream(self, clips, n_slots: int, max_new=0, steps_per_call: int = 8, min_admit: int = 1):
         """Feed `clips` through n_slots refillable slots in arrival order; max_new: one budget or one per clip.
-        Returns (ids per clip, decoder-step calls made)."""
+        min_admit: free slots to wait for before an admission pass (a larger encoder batch per pass; the last clips are
+        admitted as they come). Returns (ids per clip, decoder-step calls made)."""
         budgets = list(max_new) if hasattr(max_new, "__len__") else [max_new] * len(clips)
         self.stream_open(n_slots)
         try:
@@ -288,6 +289,8 @@ class Whisper:
             nxt = calls = 0
             while nxt < len(clips) or owner:
                 k = min(len(free), len(clips) - nxt)
+                if k < min(min_admit, len(clips) - nxt) and owner:
+                    k = 0  # wait for more slots to free up (something is still decoding)
                 if k == 1:
                     self.stream_admit(free[0], clips[nxt], budgets[nxt])
                 elif k > 1:  # every free slot is refilled by ONE batched front-end + encoder pass

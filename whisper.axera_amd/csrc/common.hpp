@@ -397,6 +397,8 @@ void launch_decode_tail(const DecTailParams& p, hipStream_t s);
 struct AdvanceParams {
   const float* amax_val; const int* amax_idx; int n_part; int amax_stride;
   DecState* state; int* off; int* tok; int* done; int* n_out; int* out_ids; int batch;
+  int* done_host;             // optional host-mapped [batch]: set (behind a system-scope fence) when a clip finishes, so that the
+                              // host sees it without a copy or a synchronisation (Engine::stream_step)
   int n_ctx, eot, max_new, n_vocab;
   const int* max_new_clip;    // optional device [B]: per-clip id budget (a ragged batch), capped by max_new
   const int* sot;             // device [4]

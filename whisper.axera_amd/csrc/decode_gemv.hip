@@ -551,7 +551,14 @@ __global__ __launch_bounds__(1024) void advance_kernel(AdvanceParams p) {
       if (gi < p.n_forced) tok = p.forced[(long)b * p.n_forced + gi];
     } else {
       if (idx == p.eot || s + 1 >= p.n_ctx || n_out >= max_new) {  // Whisper.cpp:219-222: this utterance ends HERE
-        if (lane == 0) { p.done[b] = 1; atomicAdd(&p.state->n_done, 1); }
+        if (lane == 0) {
+          p.done[b] = 1;
+          atomicAdd(&p.state->n_done, 1);
+          if (p.done_host) {  // ids and count of this clip are final: make them visible before the host can see the flag
+            __threadfence_system();
+            __hip_atomic_store(p.done_host + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
         advance = false;
       } else {
         if (lane == 0) { p.out_ids[(long)b * p.n_ctx + n_out] = idx; p.n_out[b] = n_out + 1; }

@@ -85,7 +85,9 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
   for (auto& b : branch_stream_) HIP_CHECK(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&admit_stream_, hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-  for (auto& e : ev_poll_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : ev_ring_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : ev_step_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_upload_, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
   for (auto& e : ev_join_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 
@@ -168,10 +170,13 @@ void Engine::destroy() {
   for (auto& b : branch_stream_) if (b) { (void)hipStreamDestroy(b); b = nullptr; }
   if (admit_stream_) { (void)hipStreamDestroy(admit_stream_); admit_stream_ = nullptr; }
   if (copy_stream_) { (void)hipStreamDestroy(copy_stream_); copy_stream_ = nullptr; }
-  for (auto& e : ev_poll_) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  for (auto& e : ev_ring_) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  for (auto& e : ev_step_) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  if (ev_upload_) { (void)hipEventDestroy(ev_upload_); ev_upload_ = nullptr; }
+  if (h_admit_ring_) { (void)hipHostFree(h_admit_ring_); h_admit_ring_ = nullptr; }
   for (auto& e : ev_admit_) if (e) (void)hipEventDestroy(e);
   ev_admit_.clear();
-  if (h_done_) { (void)hipHostFree(h_done_); h_done_ = nullptr; }
+  if (h_done_live_) { (void)hipHostFree(h_done_live_); h_done_live_ = nullptr; }
   if (own_stream_) { (void)hipStreamDestroy(own_stream_); own_stream_ = nullptr; }
 }
 
@@ -565,6 +570,10 @@ void Engine::ensure_capacity(int batch) {
   d_done_ = (int*)A((size_t)B * 4, true);
   d_off_ = (int*)A((size_t)B * 4, true);
   d_slot_map_ = (int*)A((size_t)B * 4, true);
+  if (h_done_live_) { (void)hipHostFree(h_done_live_); h_done_live_ = nullptr; }
+  HIP_CHECK(hipHostMalloc((void**)&h_done_live_, (size_t)B * 4, hipHostMallocMapped));
+  memset(h_done_live_, 0, (size_t)B * 4);
+  HIP_CHECK(hipHostGetDevicePointer((void**)&d_done_live_, h_done_live_, 0));
   d_attn_mpart_ = (float*)A((size_t)B * cfg_.n_text_head * kCrossSplitMax * 66 * 4, true);
   d_attn_mcnt_ = (unsigned*)A((size_t)B * cfg_.n_text_head * 4, true);  // zero: every launch leaves its tickets at zero
   d_nout_ = (int*)A((size_t)B * 4, true);
@@ -588,8 +597,8 @@ void Engine::upload_pcm(const float* const* pcm, const int* n_samples, int batch
     if (n_samples[b] > pcm_stride_) over_total += (size_t)n_samples[b] - (size_t)pcm_stride_;
   }
   over_used_ = over_total > 0;
+  if (over_total > 0) HIP_CHECK(hipStreamSynchronize(stream()));  // rare path: an earlier pass on this stream may still read the tails
   if (over_total > over_cap_) {
-    HIP_CHECK(hipStreamSynchronize(stream()));
     if (d_over_) { (void)hipFree(d_over_); d_over_ = nullptr; over_cap_ = 0; }
     HIP_CHECK(hipMalloc((void**)&d_over_, over_total * 4));
     over_cap_ = over_total;
@@ -616,7 +625,8 @@ void Engine::upload_pcm(const float* const* pcm, const int* n_samples, int batch
 
 // staged: the clips came through upload_pcm (tails of clips beyond a staging row sit in d_over_); otherwise d_pcm is the
 // caller's device buffer and a clip ends at its row's end
-void Engine::run_frontend(const float* d_pcm, int stride, const int* n_samples, int batch, bool want_ref_layout, bool staged) {
+void Engine::run_frontend(const float* d_pcm, int stride, const int* n_samples, int batch, bool want_ref_layout, bool staged,
+                          int* pinned_ns) {
   std::vector<int> ns(batch);
   int max_frames = 1;
   for (int b = 0; b < batch; ++b) {
@@ -625,8 +635,13 @@ void Engine::run_frontend(const float* d_pcm, int stride, const int* n_samples, 
     max_frames = std::max(max_frames, 1 + ns[b] / kHop);
   }
   if (feature_openai_) max_frames = kFramesOut;
-  HIP_CHECK(hipMemcpyAsync(d_nsamp_, ns.data(), (size_t)batch * 4, hipMemcpyHostToDevice, stream()));
-  HIP_CHECK(hipStreamSynchronize(stream()));  // ns is a stack vector
+  if (pinned_ns) {  // the caller keeps this buffer alive until the pass has run: no wait here
+    memcpy(pinned_ns, ns.data(), (size_t)batch * 4);
+    HIP_CHECK(hipMemcpyAsync(d_nsamp_, pinned_ns, (size_t)batch * 4, hipMemcpyHostToDevice, stream()));
+  } else {
+    HIP_CHECK(hipMemcpyAsync(d_nsamp_, ns.data(), (size_t)batch * 4, hipMemcpyHostToDevice, stream()));
+    HIP_CHECK(hipStreamSynchronize(stream()));  // ns is a stack vector
+  }
   FrontendParams p{};
   p.pcm = d_pcm; p.stride = stride; p.n_samples = d_nsamp_; p.batch = batch; p.n_mels = cfg_.n_mels;
   p.twiddle = twiddle_; p.window = window_; p.mel_basis = mel_basis_t_;
@@ -839,6 +854,7 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
   a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.n_vocab = cfg_.n_vocab; a.max_new_clip = d_max_new_clip_; a.sot = d_sot_;
   a.forced = d_forced; a.n_forced = n_forced; a.argmax_dump = d_argmax;
   a.tok_emb = tok_emb_; a.pos = dec_pos_; a.x = d_xdec_; a.d_model = d;
+  a.done_host = d_forced ? nullptr : d_done_live_;
   if (step_mask_ & 4) launch_advance(a, s);
 }
 
@@ -1112,6 +1128,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
   a.n_ctx = Tc; a.eot = cfg_.eot; a.max_new = max_new; a.n_vocab = cfg_.n_vocab; a.max_new_clip = d_max_new_clip_; a.sot = d_sot_;
   a.forced = d_forced; a.n_forced = n_forced; a.argmax_dump = d_argmax;
   a.tok_emb = tok_emb_; a.pos = dec_pos_; a.x = d_xdec_; a.d_model = d;
+  a.done_host = d_forced ? nullptr : d_done_live_;
   if (step_mask_ & 4) launch_advance(a, s);
 }
 
@@ -1510,10 +1527,9 @@ void Engine::stream_open(int n_slots) {
   reset_decode_state(n);
   std::vector<int> ones(n, 1);         // every slot idle: its attention launches return at once
   HIP_CHECK(hipMemcpy(d_done_, ones.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-  if (h_done_) { (void)hipHostFree(h_done_); h_done_ = nullptr; }
-  HIP_CHECK(hipHostMalloc((void**)&h_done_, (size_t)2 * cap_ * 4, hipHostMallocDefault));
-  poll_parity_ = 0;
-  poll_pending_[0] = poll_pending_[1] = false;
+  if (h_admit_ring_) { (void)hipHostFree(h_admit_ring_); h_admit_ring_ = nullptr; }
+  HIP_CHECK(hipHostMalloc((void**)&h_admit_ring_, (size_t)kAdmitRing * 2 * cap_ * 4, hipHostMallocDefault));
+  admit_seq_ = 0;
   while ((int)ev_admit_.size() < n) {
     hipEvent_t e;
     HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1523,8 +1539,8 @@ void Engine::stream_open(int n_slots) {
   HIP_CHECK(hipStreamSynchronize(s));
   slot_state_.assign(n, kIdle);
   slot_max_new_.assign(n, 0);
-  slot_act_call_.assign(n, 0);
-  call_no_ = 0;
+  memset(h_done_live_, 0, (size_t)cap_ * 4);
+  step_seq_ = 0;
   stream_slots_ = n;
   cfg_.ints["stream_slots"] = n_slots;
 }
@@ -1557,71 +1573,73 @@ void Engine::stream_admit(const int* slots, const float* const* pcm, const int* 
     StreamSwap(hipStream_t& us, hipStream_t to) : u(us), keep(us) { u = to; }
     ~StreamSwap() { u = keep; }
   } swap(user_stream_, admit_stream_);
-  HIP_CHECK(hipMemcpyAsync(d_slot_map_, slots, (size_t)count * 4, hipMemcpyHostToDevice, admit_stream_));  // run_frontend synchronises below
+  // Nothing below waits for an earlier pass's ENCODER: the ring entry of this pass was last used kAdmitRing passes ago, the
+  // PCM staging rows by the pass before (its uploads are the first thing it enqueued)
+  const int ring = (int)(admit_seq_ % kAdmitRing);
+  if (admit_seq_ >= kAdmitRing) HIP_CHECK(hipEventSynchronize(ev_ring_[ring]));
+  if (admit_seq_ > 0) HIP_CHECK(hipEventSynchronize(ev_upload_));
+  int* h_ns = h_admit_ring_ + (size_t)ring * 2 * cap_;
+  int* h_map = h_ns + cap_;
+  memcpy(h_map, slots, (size_t)count * 4);
+  HIP_CHECK(hipMemcpyAsync(d_slot_map_, h_map, (size_t)count * 4, hipMemcpyHostToDevice, admit_stream_));
   upload_pcm(pcm, n_samples, count);
-  run_frontend(d_pcm_, (int)pcm_stride_, n_samples, count, false, true);
+  HIP_CHECK(hipEventRecord(ev_upload_, admit_stream_));
+  run_frontend(d_pcm_, (int)pcm_stride_, n_samples, count, false, true, h_ns);
   run_encoder(count, d_slot_map_);
+  HIP_CHECK(hipEventRecord(ev_ring_[ring], admit_stream_));
+  ++admit_seq_;
   for (int i = 0; i < count; ++i) {
     HIP_CHECK(hipEventRecord(ev_admit_[slots[i]], admit_stream_));
+    h_done_live_[slots[i]] = 0;
     slot_state_[slots[i]] = kEncoding;
     const int mn = max_new ? max_new[i] : 0;
     slot_max_new_[slots[i]] = (mn > 0 && mn < Tc - 4) ? mn : Tc - 4;
   }
 }
 
-// The call ENQUEUES n decoder steps and a read-back of the done flags and returns without waiting for them: what it
-// reports are the slots that had finished by the end of the PREVIOUS call's steps. The host therefore admits and collects
-// while the GPU runs the steps just enqueued (a finished slot is seen one call late; the device never waits for the host).
+// Up to n decoder steps. Between two steps the host looks at the host-mapped done flags (advance_kernel raises a clip's flag,
+// behind a system-scope fence, the moment its ids are final): a finished slot is seen without a copy or a wait, and a slot
+// whose encoder has finished joins before the next step. (Measured and not kept: extra slots holding already-encoded clips
+// that take over the moment a decoding slot frees — the step then runs its linear layers over more rows and its attention
+// launches over more workgroups, and that costs more than the refill latency it removes: 32 + 8 slots 224 -> 202 clips/s.)
 int Engine::stream_step(int n_steps, int* finished_slots) {
   HIP_CHECK(hipSetDevice(device_));
   if (stream_slots_ == 0) throw std::runtime_error("stream_step: no stream open");
   hipStream_t s = stream();
   const int n = stream_slots_;
   auto n_in = [&](int st) { int c = 0; for (int i = 0; i < n; ++i) c += slot_state_[i] == st; return c; };
-  // slots whose encoder has finished join the loop — checked before every step, so a clip joins within one step of its
-  // encoder's end; if nothing else is decoding the loop waits for the first of them
-  auto activate_ready = [&](bool wait_for_one) {
+  auto harvest = [&] {
+    for (int i = 0; i < n; ++i)
+      if (slot_state_[i] == kActive && __atomic_load_n(&h_done_live_[i], __ATOMIC_ACQUIRE)) slot_state_[i] = kFinished;
+  };
+  // slots whose encoder has finished join; if nothing decodes the loop waits for the first encoder
+  auto activate_ready = [&] {
+    int active = n_in(kActive);
     for (int i = 0; i < n; ++i) {
       if (slot_state_[i] != kEncoding) continue;
       hipError_t q = hipEventQuery(ev_admit_[i]);
-      if (q == hipErrorNotReady && wait_for_one) { HIP_CHECK(hipEventSynchronize(ev_admit_[i])); q = hipSuccess; }
+      if (q == hipErrorNotReady && active == 0) { HIP_CHECK(hipEventSynchronize(ev_admit_[i])); q = hipSuccess; }
       if (q == hipErrorNotReady) continue;
       HIP_CHECK(q);
-      wait_for_one = false;
       hipLaunchKernelGGL(slot_reset_kernel, dim3(1), dim3(256), 0, s, i, slot_max_new_[i], d_sot_, d_off_, d_tok_, d_done_, d_nout_,
                          d_max_new_clip_, tok_emb_, dec_pos_, d_xdec_, cfg_.n_text_state);
       slot_state_[i] = kActive;
-      slot_act_call_[i] = call_no_;
+      ++active;
     }
   };
-  ++call_no_;
-  const int cur = poll_parity_, prev = cur ^ 1;
-  auto harvest = [&](int which) {
-    for (int i = 0; i < n; ++i)
-      if (slot_state_[i] == kActive && slot_act_call_[i] <= poll_call_[which] && h_done_[(size_t)which * cap_ + i]) slot_state_[i] = kFinished;
-  };
-  if (n_in(kActive) + n_in(kEncoding) > 0) {
-    hipGraphExec_t g = step_graph(n, cfg_.n_text_ctx - 4);
-    for (int st = 0; st < std::max(1, n_steps); ++st) {
-      activate_ready(n_in(kActive) == 0 && n_in(kEncoding) > 0);
-      HIP_CHECK(hipGraphLaunch(g, s));
-    }
-    HIP_CHECK(hipMemcpyAsync(h_done_ + (size_t)cur * cap_, d_done_, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipEventRecord(ev_poll_[cur], s));
-    poll_pending_[cur] = true;
-    poll_call_[cur] = call_no_;
-    poll_parity_ = prev;
+  hipGraphExec_t g = step_graph(n, cfg_.n_text_ctx - 4);
+  // The host runs two steps ahead of the device (it waits for step k-2 before it enqueues step k): the queue never runs dry,
+  // and what the host sees in the flags is at most two steps old, so a waiting clip takes a freed slot within two steps.
+  for (int st = 0; st < std::max(1, n_steps); ++st) {
+    if (step_seq_ >= 2) HIP_CHECK(hipEventSynchronize(ev_step_[(step_seq_ - 2) % 3]));
+    harvest();
+    activate_ready();
+    if (n_in(kActive) == 0) break;  // nothing decodes and nothing is ready: a step would be the GEMM chain for nobody
+    HIP_CHECK(hipGraphLaunch(g, s));
+    HIP_CHECK(hipEventRecord(ev_step_[step_seq_ % 3], s));
+    ++step_seq_;
   }
-  if (poll_pending_[prev]) {  // the previous call's flags (its steps ran while the host was admitting / collecting)
-    HIP_CHECK(hipEventSynchronize(ev_poll_[prev]));
-    poll_pending_[prev] = false;
-    harvest(prev);
-  } else if (poll_pending_[cur] && n_in(kEncoding) == 0 && n_in(kFinished) == 0) {
-    // nothing was in flight before this call: do not make a lone caller spin — wait for the steps just enqueued
-    HIP_CHECK(hipEventSynchronize(ev_poll_[cur]));
-    poll_pending_[cur] = false;
-    harvest(cur);
-  }
+  harvest();
   int n_fin = 0;
   for (int i = 0; i < n; ++i)
     if (slot_state_[i] == kFinished) finished_slots[n_fin++] = i;

@@ -64,7 +64,9 @@ class Engine final : public IEngine {
   void ensure_capacity(int batch);
   void free_slot_buffers();
   void upload_pcm(const float* const* pcm, const int* n_samples, int batch);
-  void run_frontend(const float* d_pcm, int stride, const int* n_samples, int batch, bool want_ref_layout, bool staged = false);
+  // pinned_ns: optional pinned host [batch] the clip lengths are staged through (then nothing here waits for the stream)
+  void run_frontend(const float* d_pcm, int stride, const int* n_samples, int batch, bool want_ref_layout, bool staged = false,
+                    int* pinned_ns = nullptr);
   void run_encoder(int batch, const int* d_slot_map = nullptr);  // cross K/V of clip b goes to slot d_slot_map[b] (device), else b
   void reset_decode_state(int batch, const int* max_new_clip = nullptr);
   void enqueue_decode_step(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits, long logits_stride,
@@ -153,13 +155,20 @@ class Engine final : public IEngine {
   std::vector<int> slot_state_, slot_max_new_;
   std::vector<hipEvent_t> ev_admit_;     // one per slot: its encoder has finished
   hipStream_t admit_stream_ = nullptr;
-  int* h_done_ = nullptr;                // pinned [2][cap]: done flags as of the end of the last two stream_step calls
-  hipEvent_t ev_poll_[2] = {nullptr, nullptr};
-  int poll_parity_ = 0; bool poll_pending_[2] = {false, false};
-  long call_no_ = 0, poll_call_[2] = {0, 0};  // a read-back speaks for a slot only if it was enqueued behind that slot's activation
-  std::vector<long> slot_act_call_;
+  int* h_done_live_ = nullptr; int* d_done_live_ = nullptr;  // host-mapped [cap] (and its device alias): advance_kernel raises a clip's
+                                                             // flag the moment it finishes; the host reads it without any wait
+  hipEvent_t ev_step_[3] = {nullptr, nullptr, nullptr};  // the host stays two steps ahead of the device (stream_step)
+  long step_seq_ = 0;
   hipStream_t copy_stream_ = nullptr;    // stream_collect's D2H copies: never behind the queued decoder steps
   int* d_slot_map_ = nullptr;            // [cap]: clip index of an admission pass -> slot
+  // admission passes do not wait for one another's encoder: clip lengths and slot maps go through a pinned ring of
+  // kAdmitRing entries (an entry is reused once the pass that filled it has finished), the PCM staging rows are reused once
+  // the previous pass's uploads have landed
+  static constexpr int kAdmitRing = 4;
+  int* h_admit_ring_ = nullptr;          // pinned [kAdmitRing][2][cap]
+  hipEvent_t ev_ring_[kAdmitRing] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_upload_ = nullptr;
+  long admit_seq_ = 0;
   void require_no_stream(const char* what) const;
   DecState* d_state_ = nullptr;
   int* h_poll_ = nullptr;  // pinned
