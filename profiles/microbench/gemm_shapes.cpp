@@ -87,6 +87,33 @@ int main(int argc, char** argv) {
       if (err > max_err) max_err = err;
       if (qkv && err > 4e-3 && getenv("GEMM_SHAPES_DEBUG")) fprintf(stderr, "  qkv mismatch m=%ld (clip %ld row %ld) n=%d got %.5f want %.5f\n", m, m / sh.M, m % sh.M, n, got, acc);
     }
+#ifdef AXW_GEMM_TIMING  // one stamped launch of the stream kernel: where a tile's time goes (100 MHz ticks -> us)
+    if (sh.batch > 1) {
+      const size_t n_st = (size_t)256 * 32 * 2 * 5;
+      unsigned long long* d_st; CK(hipMalloc(&d_st, n_st * 8)); CK(hipMemset(d_st, 0, n_st * 8));
+      GemmParams q = p; q.part = reinterpret_cast<float*>(d_st);
+      launch_gemm(q, s); CK(hipStreamSynchronize(s));
+      std::vector<unsigned long long> st(n_st);
+      CK(hipMemcpy(st.data(), d_st, n_st * 8, hipMemcpyDeviceToHost));
+      double sum[2][6] = {}; long cnt[2] = {};
+      for (int wg = 0; wg < 256; ++wg)
+        for (int t = 0; t + 1 < 32; ++t)
+          for (int g = 0; g < 2; ++g) {
+            const unsigned long long* a = &st[(((size_t)wg * 32 + t) * 2 + g) * 5];
+            const unsigned long long* b = a + 10;
+            if (!a[0] || !a[4] || b[0] <= a[4]) continue;
+            sum[g][0] += (double)(a[1] - a[0]); sum[g][1] += (double)(a[2] - a[1]); sum[g][2] += (double)(a[3] - a[2]);
+            sum[g][3] += (double)(a[4] - a[3]); sum[g][4] += (double)(b[0] - a[4]); sum[g][5] += (double)(b[0] - a[0]);
+            ++cnt[g];
+          }
+      for (int g = 0; g < 2; ++g)
+        if (cnt[g])
+          printf("    wave group %d, %ld tiles: first 2 k-tiles %.2f us | rest of the k-loop %.2f (%d k-tiles) | wait for the other group %.2f | epilogue %.2f | to the next tile %.2f | tile %.2f\n",
+                 g, cnt[g], sum[g][0] / cnt[g] / 100, sum[g][1] / cnt[g] / 100, sh.K / 64 - 2, sum[g][2] / cnt[g] / 100, sum[g][3] / cnt[g] / 100,
+                 sum[g][4] / cnt[g] / 100, sum[g][5] / cnt[g] / 100);
+      (void)hipFree(d_st);
+    }
+#endif
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 2; ++i) launch_gemm(p, s);
     CK(hipEventRecord(e0, s));

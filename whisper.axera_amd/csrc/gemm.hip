@@ -1000,6 +1000,19 @@ __global__ __launch_bounds__(512) void gemm256ps_bf16_kernel(GemmParams p) {
 
   const int nk = p.K / BK;  // even, >= 4 (launch_one)
   float* lw = reinterpret_cast<float*>(smem + 2 * KT4_BYTES) + wave * SLAB_FLOATS;
+#ifdef AXW_GEMM_TIMING  // profiles/microbench/gemm_shapes.cpp: p.part = [workgroup][32 tiles][2 wave groups][5 stamps], 100 MHz ticks
+  int stamp_tile = 0;
+#define AXW_STAMP(i)                                                                                                   \
+  do {                                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    if ((wave & 3) == 0 && lane == 0 && stamp_tile < 32 && p.part)                                                     \
+      reinterpret_cast<unsigned long long*>(p.part)[(((long)blockIdx.x * 32 + stamp_tile) * 2 + wr) * 5 + (i)] = wall_clock64(); \
+    if ((i) == 4) ++stamp_tile;                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  } while (0)
+#else
+#define AXW_STAMP(i) do {} while (0)
+#endif
 
   // the stream's first k-tile and three half-tiles of its second
   stage(I2_{}, I0_{}, ao_cur, wn_cur, 0);
@@ -1027,10 +1040,12 @@ __global__ __launch_bounds__(512) void gemm256ps_bf16_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind the first inside a tile
     __builtin_amdgcn_sched_barrier(0);
+    AXW_STAMP(0);
     int kt = 0;
     for (; kt + 2 < nk; kt += 2) {
       ktile(I0_{}, I1_{}, I1_{}, ao_cur, wn_cur, kt + 1, ao_cur, wn_cur, kt + 2);
       ktile(I1_{}, I1_{}, I1_{}, ao_cur, wn_cur, kt + 2, ao_cur, wn_cur, kt + 3);
+      if (kt == 0) { AXW_STAMP(1); }
     }
     // the last two k-tiles prefetch the next tile's first two; the last tile "prefetches" its own again (one code
     // path; 112 KB of L2 reads per workgroup, drained at the end)
@@ -1041,8 +1056,10 @@ __global__ __launch_bounds__(512) void gemm256ps_bf16_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     ktile(I0_{}, I1_{}, I1_{}, ao_cur, wn_cur, kt + 1, ao_nxt, wn_nxt, 0);
     ktile(I1_{}, I1_{}, I1_{}, ao_nxt, wn_nxt, 0, ao_nxt, wn_nxt, 1);
+    AXW_STAMP(2);
     if (wr == 0) __builtin_amdgcn_s_barrier();  // back in step for the epilogue
     __builtin_amdgcn_sched_barrier(0);
+    AXW_STAMP(3);
 
     // epilogue: 16-row slabs through this wave's 4 KB (the staging buffers belong to the next tile already)
     const int mbw = m0 + wr * 128, nbw = n0 + wc * 64;
@@ -1081,6 +1098,7 @@ __global__ __launch_bounds__(512) void gemm256ps_bf16_kernel(GemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
           }
     }
+    AXW_STAMP(4);
     if (!has_next) break;
     t_cur = t_nxt;
     n0 = n0n; m0 = m0n; bz = bzn;
@@ -1092,6 +1110,7 @@ __global__ __launch_bounds__(512) void gemm256ps_bf16_kernel(GemmParams p) {
   }
 #undef AXW_PHASE_MFMA_BEGIN
 #undef AXW_PHASE_MFMA_END
+#undef AXW_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
