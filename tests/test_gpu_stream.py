@@ -71,6 +71,31 @@ def test_slots_refill_while_others_decode(built_lib, micro_case):
         e.close()
 
 
+def test_stream_beyond_64_slots(built_lib, micro_case):
+    """72 slots (three graph branches: 32 + 32 + 8 clips; the vocabulary projection as two launches) fed 150 clips: the slot
+    count is a deployment knob (one step costs 17.9 us per clip at 64 clips and 13.1 at 256, engine.cpp decode_branches), so
+    the stream has to be right on both sides of the 64-clip launch boundary. Every clip against its stand-alone run."""
+    n_slots, n_clips = 72, 150
+    clips8, _ = _clips_and_budgets(8)
+    clips = [clips8[i % 8] for i in range(n_clips)]
+    budgets = [6 + (11 * i) % 23 for i in range(n_clips)]
+    e = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=n_slots)
+    try:
+        got, calls = e.run_stream(clips, n_slots, max_new=budgets, steps_per_call=4)
+        assert all(g is not None and len(g) == b for g, b in zip(got, budgets)), [len(g) for g in got]
+        alone = [e.run_tokens(c, max_new=28) for c in clips8]
+        diff = [i for i in range(n_clips) if got[i] != alone[i % 8][:budgets[i]]]
+        print(f"{n_clips} clips through {n_slots} slots in {calls} step calls: {n_clips - len(diff)}/{n_clips} identical to the stand-alone runs")
+        for i in diff:  # another summation order: a difference must be a numerical tie
+            mel = e.compute_mel(clips[i])
+            ck, cv = micro_case.oracle_bf16.encoder(mel)
+            ids, lg = micro_case.oracle_bf16.greedy(ck, cv, "zh", max_new=budgets[i], want_logits=True)
+            assert_ids_equal_or_tie(e, mel, got[i], ids, lg, f"clip {i} through 72 slots")
+        assert len(diff) <= 8
+    finally:
+        e.close()
+
+
 def test_stream_one_and_two_slots_and_full_context(built_lib, micro_case):
     """n_slots below 3 (the engine still runs the 3-slot step sequence underneath), a clip that runs to the end of the
     context (444 ids, offset 447) next to short ones, and a slot reused six times."""

@@ -973,12 +973,16 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced, i
 //                               an attention launch of more than 256 workgroups — 22 clips x 12 heads — leaves a few CUs with two
 //                               workgroups and everybody waits for them; two launches side by side do not)
 //   40 .. 48        3 branches (16 + 16 + rest: 40 clips 0.955 -> 0.936 ms, 44: 1.006 -> 0.988, 48: 1.034 -> 1.005)
-//   49 and more     2 branches (4 branches at 56 / 64 clips: 1.093 -> 1.13-1.16 / 1.152 -> 1.22 ms)
+//   49 .. 64        2 branches (4 branches at 56 / 64 clips: 1.093 -> 1.13-1.16 / 1.152 -> 1.22 ms)
+//   65 .. 96        3 branches (32 + 32 + rest: 72 clips 1.338 -> 1.301 ms, 80: 1.374 -> 1.367, 96: 1.664 -> 1.568)
+//   97 and more     2 branches (112 clips: 1.745 with two, 1.811 with three; 128: 1.907 / 1.969; 192, 256: within 1 %)
+// One step costs 17.9 us per clip at 64 clips, 14.9 at 128, 13.1 at 256 (the chain of small GEMMs is paid once per step): the
+// slot scheduler's rate grows with its slot count (profiles/r03_big_batches.txt).
 // AX_WHISPER_DECODE_BRANCHES overrides (1, 2, 3 or 4; AX_WHISPER_BRANCH_MIN: fewest clips per branch it may leave, default 6).
 int Engine::decode_branches(int batch) const {
   static const int forced = [] { const char* e = getenv("AX_WHISPER_DECODE_BRANCHES"); return e ? atoi(e) : 0; }();
   static const int min_per = [] { const char* e = getenv("AX_WHISPER_BRANCH_MIN"); return e ? std::max(1, atoi(e)) : 6; }();
-  int n = forced > 0 ? forced : (batch < 22 ? 1 : batch < 40 ? 2 : batch <= 48 ? 3 : 2);
+  int n = forced > 0 ? forced : (batch < 22 ? 1 : batch < 40 ? 2 : batch <= 48 ? 3 : batch <= 64 ? 2 : batch <= 96 ? 3 : 2);
   n = std::min(n, kMaxBranches);
   // every branch gets whole clip blocks; the last one at least min_per clips
   while (n > 1) {
