@@ -6,7 +6,7 @@ resident in HBM: log-mel front-end -> encoder -> greedy decode (4 SOT steps + up
 synthetic weights eot practically never wins, so every clip runs the full 448-step context) -> ids.
 
     python bench.py                      # N=1: BASELINE configs[1] (Whisper-small, batch 1) as the headline value,
-                                         #      plus a "batch64" object = configs[2] timed in the same run
+                                         #      plus a "batch64" object = configs[2] timed in the same run (and "batch256": the same at 256 clips)
     python bench.py --batch 64           # configs[2] as the headline value
     python bench.py --gpus 8             # configs[4]: spawns 8 ranks (one per GPU, RCCL), 64 clips per GPU
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8     # the same, launched by the driver
@@ -48,6 +48,7 @@ def parse_args(argv=None):
                     help="16-bit storage / MFMA operand type; default: bf16, fp16 for --model turbo (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch64", action="store_true", help="N=1, batch 1 only: skip the batch-64 leg")
+    ap.add_argument("--no-batch256", action="store_true", help="N=1, batch 1 only: skip the batch-256 leg (not a BASELINE config: what one GPU's HBM allows)")
     ap.add_argument("--no-turbo", action="store_true", help="N=1, batch 1 only: skip the turbo fp16 batch-16 leg (configs[3])")
     ap.add_argument("--no-config0", action="store_true", help="N=1, batch 1 only: skip the tiny / demo.wav CPU-vs-GPU leg (configs[0])")
     ap.add_argument("--no-extras", action="store_true",
@@ -630,6 +631,12 @@ def run_rank(args) -> int:
                 leg, ids2 = batch_leg(torch, dev, dev_index, sync, "small", dtype, 64, n2, args.max_new, args.model_dir)
                 leg["clip0_ids_equal_batch1"] = ids2[0] == ids[0]
                 out["batch64"] = leg
+            if not args.no_batch256 and args.max_new == 0:
+                # not a BASELINE config: the same workload at the batch 288 GB of HBM invite (19 GB of K/V caches). A decoder
+                # step's chain of small GEMMs is paid once whatever the batch: 17.9 us per clip and step at 64, 13.1 at 256.
+                leg, ids3 = batch_leg(torch, dev, dev_index, sync, "small", dtype, 256, min(n2, 2), 0, args.model_dir)
+                leg["clip0_ids_equal_batch1"] = ids3[0] == ids[0]
+                out["batch256"] = leg
             if not args.no_turbo and args.max_new == 0 and dtype == "bf16":
                 leg, _ = batch_leg(torch, dev, dev_index, sync, "turbo", "fp16", 16, min(n2, 3), 0, args.model_dir)
                 out["turbo_fp16_b16"] = leg
@@ -654,7 +661,7 @@ def run_rank(args) -> int:
 def main():
     args = parse_args()
     if args.no_extras:
-        args.no_batch64 = args.no_turbo = args.no_config0 = args.no_cpu_baseline = True
+        args.no_batch64 = args.no_batch256 = args.no_turbo = args.no_config0 = args.no_cpu_baseline = True
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         return 2
