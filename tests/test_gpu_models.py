@@ -177,6 +177,38 @@ def test_server_asr_round_trip(built_lib, micro_case, scheduler):
         assert b"400" in raw(pcm.tobytes()[:20000], True).split(b"\r\n")[0]
         r = raw(pcm.tobytes()[:20000], False)  # the peer just stops sending: --recv_timeout_s 2
         assert b"400" in r.split(b"\r\n")[0] and b"incomplete" in r and time.time() - t0 < 8
+        # malformed and hostile requests (the server parses HTTP itself): whatever they get, the server keeps serving
+        hdr = b"POST /asr HTTP/1.1\r\nHost: x\r\nContent-Type: application/octet-stream\r\n"
+        rng = np.random.default_rng(5)
+        junk = [b"", b"\r\n\r\n", b"\x00" * 5000, rng.integers(0, 256, 3000, dtype=np.uint8).tobytes(),
+                b"GET /../../etc/passwd HTTP/1.1\r\n\r\n", b"POST /asr\r\n\r\n", b"OPTIONS /asr HTTP/1.1\r\n\r\n",
+                hdr + b"Content-Length: -5\r\n\r\n", hdr + b"Content-Length: 99999999999999999999999\r\n\r\n",
+                hdr + b"Content-Length: abc\r\n\r\n", hdr + b"Content-Length: 8\r\n\r\n" + np.array([np.nan, np.inf], np.float32).tobytes(),
+                hdr + b"Content-Length: 4\r\n\r\n" + np.float32(0.25).tobytes(),
+                hdr + b"Transfer-Encoding: chunked\r\n\r\n5\r\nabcde\r\n0\r\n\r\n",
+                hdr + b"Content-Length: 16\r\nContent-Length: 4\r\n\r\n" + b"\x00" * 16,
+                b"POST /asr HTTP/1.1\r\n" + b"X-Pad: " + b"a" * 1200000,  # headers that never end: dropped at 1 MB
+                hdr.replace(b"octet-stream", b"OCTET-STREAM") + b"Content-Length: 64\r\n\r\n" + b"\x00" * 64]
+
+        def shoot(payload):
+            try:
+                c = socket.create_connection(("127.0.0.1", port), timeout=5)
+                try:
+                    c.sendall(payload)
+                    c.shutdown(socket.SHUT_WR)
+                    while c.recv(65536):
+                        pass
+                finally:
+                    c.close()
+            except OSError:
+                pass  # reset by the server: fine
+
+        th = [threading.Thread(target=shoot, args=(junk[i % len(junk)],)) for i in range(4 * len(junk))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert proc.poll() is None
+        st2, js2 = post(pcm.tobytes())
+        assert st2 == 200 and js2["text"] == js["text"]
         h = json.load(urllib.request.urlopen(base + "/health", timeout=2))
         assert h["status"] == "ok" and h["persistent_giveups"] == 0 and h["served"] >= 20 and h["busy_slots"] == 0 and h["devices"] == 1
     finally:
