@@ -135,6 +135,31 @@ def test_ragged_batch_leaves_the_loop_clip_by_clip(built_lib, small_case):
         e.close()
 
 
+def test_slot_stream_at_whisper_small_dims(built_lib, small_case):
+    """The serving path at the stated model size: 120 thirty-second clips through 48 slots (three graph branches; the
+    encoder's batched kernels at 1-48 clips per admission pass), budgets 15-70 ids, and the same clips through 96 slots
+    (three branches of 32). Every id sequence against the ragged batch path; a difference must be a logit tie."""
+    n_clips = 120
+    clips16 = _clips(16)
+    clips = [clips16[i % 16] for i in range(n_clips)]
+    budgets = [15 + (29 * i) % 56 for i in range(n_clips)]
+    e = built_lib.Whisper("small", small_case.root, "zh", device=0, max_batch=96)
+    try:
+        want16 = e.run_tokens_batch(clips16, max_new=72)
+        for n_slots in (48, 96):
+            got, calls = e.run_stream(clips, n_slots, max_new=budgets)
+            diff = [i for i in range(n_clips) if got[i] != want16[i % 16][:budgets[i]]]
+            print(f"{n_clips} clips through {n_slots} slots at Whisper-small dims in {calls} step calls: {n_clips - len(diff)}/{n_clips} identical to the batch path")
+            for i in diff:
+                pos = next(k for k in range(budgets[i]) if got[i][k] != want16[i % 16][k])
+                e.encode_mel(e.compute_mel(clips[i]))
+                lg, _ = e.decode_forced(1, np.asarray(want16[i % 16][:max(pos, 1)], np.int32))
+                assert abs(float(lg[0, pos, got[i][pos]]) - float(lg[0, pos, want16[i % 16][pos]])) < 2e-3, (n_slots, i, pos)
+            assert len(diff) <= 6
+    finally:
+        e.close()
+
+
 def test_config3_turbo_fp16_batch16(built_lib, oracle_mod, tmp_path_factory):
     """Full-size large-v3-turbo dims (d 1280, 20 heads, 32 encoder + 4 decoder layers, 128 mels, 51866 ids, 100
     languages), batch 16, in fp16 as BASELINE configs[3] states: F16 weights file -> the engine's IEEE-half build."""
