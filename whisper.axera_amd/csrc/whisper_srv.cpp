@@ -304,7 +304,7 @@ static void serve(int fd) {
 }
 
 int main(int argc, char** argv) {
-  int port = 8080, max_batch = 16, wait_ms = 5, steps_per_call = 8, max_body_mb = 16;
+  int port = 8080, max_batch = 64, wait_ms = 5, steps_per_call = 8, max_body_mb = 16;
   std::string model_type = "turbo", model_path = "../models-mi355x", language = "zh", devices, scheduler = "slots";
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -324,7 +324,7 @@ int main(int argc, char** argv) {
     if (val("max_conns", nullptr, v)) { g_max_conns = std::max(1, atoi(v.c_str())); continue; }
     if (val("max_body_mb", nullptr, v)) { max_body_mb = std::max(1, atoi(v.c_str())); continue; }
     if (val("recv_timeout_s", nullptr, v)) { g_recv_timeout_s = std::max(1, atoi(v.c_str())); continue; }
-    fprintf(stderr, "usage: %s [--port 8080] [-t model_type] [-p model_path] [-l language] [--max_batch 16] [--batch_wait_ms 5] [--devices all|0,1,..]\n"
+    fprintf(stderr, "usage: %s [--port 8080] [-t model_type] [-p model_path] [-l language] [--max_batch 64] [--batch_wait_ms 5] [--devices all|0,1,..]\n"
                     "          [--scheduler slots|batches] [--steps_per_call 8] [--max_conns 256] [--max_body_mb 16] [--recv_timeout_s 10]\n", argv[0]);
     return a == "--help" || a == "-?" ? 0 : 1;
   }
