@@ -212,7 +212,9 @@ class Oracle:
         return (np.zeros((m.n_text_layer, m.n_text_ctx, m.n_text_state), dtype=np.float32),
                 np.zeros((m.n_text_layer, m.n_text_ctx, m.n_text_state), dtype=np.float32))
 
-    def greedy(self, ck, cv, language="zh", max_new=444, forced=None, want_logits=False):
+    def greedy(self, ck, cv, language="zh", max_new=444, forced=None, want_logits=False, eot=None):
+        """eot: the id that ends the loop (Whisper.cpp:219); default the config's, -1 = never (calibration runs of
+        tests/eot_case.py)."""
         m = self.m
         sot = (C.c_int * 4)(*self.sot_seq(language))
         out = (C.c_int * m.n_text_ctx)()
@@ -220,7 +222,7 @@ class Oracle:
         fa = (C.c_int * max(nf, 1))(*(forced if nf else [0]))
         n_steps = (nf if nf else max_new) + 1
         logits = np.zeros((n_steps, m.n_vocab), dtype=np.float32) if want_logits else None
-        n = self.L.orc_greedy(C.byref(m), C.byref(self.policy), _p(ck), _p(cv), sot, int(self.cfg["eot"]),
+        n = self.L.orc_greedy(C.byref(m), C.byref(self.policy), _p(ck), _p(cv), sot, int(self.cfg["eot"] if eot is None else eot),
                               int(max_new), fa if nf else None, nf, out, _p(logits) if want_logits else None)
         ids = [out[i] for i in range(n)]
         return (ids, logits[: n + 1]) if want_logits else ids

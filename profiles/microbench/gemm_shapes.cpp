@@ -20,7 +20,7 @@ struct Shape { const char* name; int M, batch, N, K, epi; };
 
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 10;
-  gemm_force_tile = argc > 2 ? atoi(argv[2]) : 0;  // 0 auto, 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 phased
+  gemm_force_tile = argc > 2 ? atoi(argv[2]) : 0;  // 0 auto, 1: 128x128, 2: 256x128, 5: 256x256 stream per CU
   printf("tile selection %d\n", gemm_force_tile);
   const Shape shapes[] = {
       {"attn.out / cq  (N=768  K=768,  resid f32)", 1500, 64, 768, 768, EPI_RESID_F32},

@@ -201,44 +201,3 @@ def test_ragged_small_batch_with_split_cross_attention(built_lib, micro_case, B)
         assert again == uniform
     finally:
         e.close()
-
-
-@pytest.mark.parametrize("model_type,B", [("micro", 37), ("w512", 20)])
-def test_tail_launch_equals_the_launch_per_layer_sequence(built_lib, oracle_mod, tmp_path, monkeypatch, model_type, B):
-    """AX_WHISPER_TAIL=1: the second half of every decoder layer (cross-attention projection -> LayerNorm + mlp.0 + GELU ->
-    mlp.2 -> LayerNorm + Q,K,V of the next layer) as ONE launch with in-launch hand-offs per 16-clip cluster
-    (csrc/decode_tail.hip). Same operands, same summation order: at d = 512 logits and ids are BIT-equal to the default
-    sequence; at d = 128 the compiler contracts the LayerNorm arithmetic of the two kernels differently (2e-5 on the
-    logits, measured), so there the bar is 1e-4 and ids equal up to ties. Ragged clip counts (a partial last clip block),
-    2 graph branches (37 clips), greedy runs past the first key block, a ragged batch."""
-    from conftest import ModelCase
-
-    case = ModelCase(tmp_path / "m", model_type, 5)
-    mels = np.stack(_mels(B))
-    forced = np.tile(np.arange(100, 124, dtype=np.int32), (B, 1))
-    out = {}
-    for tail in ("0", "1"):
-        monkeypatch.setenv("AX_WHISPER_TAIL", tail)
-        e = built_lib.Whisper(model_type, case.root, "zh", device=0, max_batch=B)
-        try:
-            assert e.L.AX_WHISPER_GetConfigInt(e.h, b"decode_tail") == int(tail)
-            e.encode_mel(mels)
-            lg, am = e.decode_forced(B, forced)
-            ids = e.decode_greedy(B, max_new=70)  # past the first key block
-            ragged = e.decode_greedy(B, max_new=40, max_new_clip=[5 + (7 * b) % 30 for b in range(B)])
-            out[tail] = (lg, am, ids, ragged)
-            assert e.L.AX_WHISPER_GetConfigInt(e.h, b"decode_tail") == int(tail)  # no launch gave up
-        finally:
-            e.close()
-    (lg0, am0, ids0, rag0), (lg1, am1, ids1, rag1) = out["0"], out["1"]
-    if model_type == "w512":
-        assert np.array_equal(lg0, lg1) and np.array_equal(am0, am1) and ids0 == ids1 and rag0 == rag1
-        return
-    err = float(np.abs(lg0 - lg1).max())
-    print("tail vs default logits:", err)
-    assert err < 1e-4
-    srt = np.sort(lg0, axis=2)
-    tie = (srt[:, :, -1] - srt[:, :, -2]) < 2e-4
-    assert np.all((am0 == am1) | tie)
-    for a, b in ((ids0, ids1), (rag0, rag1)):
-        assert sum(x == y for x, y in zip(a, b)) >= B - 2 and all(len(x) == len(y) for x, y in zip(a, b))

@@ -54,8 +54,8 @@ def test_fp16_encoder_cross_kv_vs_oracle(built_lib, micro16):
         ek, ev = np.abs(k - kb).max(), np.abs(v - vb).max()
         print(f"fp16 cross K/V vs half-policy oracle {ek:.2e} {ev:.2e}; vs fp32 oracle {np.abs(k - kf).max():.2e}")
         # one half ulp at |x| ~ 2-4 is 2e-3 (bfloat16: 1.6e-2)
-        assert ek < 6e-3 and ev < 6e-3
-        assert np.abs(k - kf).max() < 2e-2
+        assert ek < 2e-3 and ev < 2e-3  # one half ulp at 1..2 is 9.8e-4, and that is what is measured
+        assert np.abs(k - kf).max() < 3e-3  # measured 9.5e-4
     finally:
         e.close()
 
@@ -93,7 +93,7 @@ def test_fp16_decode_paths_vs_oracle(built_lib, micro16, monkeypatch, batch, mod
                 i = next(i for i in range(n) if got[b][i] != ids[i])
                 assert srt[i, -1] - srt[i, -2] < 2 * err[i] + 1e-4, (b, i, got[b], ids)
         print(f"fp16 {mode} B={batch}: logits err vs half-policy oracle {worst:.2e}")
-        assert worst < 2e-2
+        assert worst < 2e-4  # measured 2.1e-5 .. 3.9e-5
     finally:
         e.close()
 
@@ -113,6 +113,6 @@ def test_fp16_end_to_end_vs_fp32_oracle(built_lib, oracle_mod, tmp_path):
         logits, _ = e.decode_forced(1, np.array([ids], dtype=np.int32))
         err = float(np.abs(logits[0] - lg).max())
         print(f"tiny fp16 / demo.wav: {agree}/{len(ids)} ids equal to the fp32 oracle, logits err {err:.2e}")
-        assert err < 5e-3
+        assert err < 1.5e-3  # measured 2.8e-4 (fp16 build vs the PURE fp32 oracle)
     finally:
         e.close()

@@ -24,7 +24,7 @@ def engine(built_lib, small_case):
 
 def _check(ids_gpu, ids_ref, logits_ref, logits_gpu):
     err = np.abs(logits_gpu - logits_ref).max(axis=1)
-    assert err.max() < 2e-2, err.max()
+    assert err.max() < 6e-3, err.max()  # measured 1.6e-3 .. 1.8e-3 at d = 768 (12 layers of bf16 storage points), logit std 0.5
     if ids_gpu != ids_ref:
         i = next(i for i in range(len(ids_ref)) if ids_ref[i] != ids_gpu[i])
         srt = np.sort(logits_ref[i])
@@ -42,7 +42,11 @@ def test_small_single_clip_end_to_end(engine, small_case, oracle_mod):
     engine.encode_mel(engine.compute_mel(pcm))
     logits, _ = engine.decode_forced(1, np.array([ids]))
     k, v = engine.get_cross_kv(0)
-    assert np.abs(k - ck).max() < 4e-2 and np.abs(v - cv).max() < 4e-2
+    # stored bf16 on both sides: a value may fall on either side of a rounding boundary -> two bf16 ulps of its magnitude
+    dk, dv = np.abs(k - ck), np.abs(v - cv)
+    print("small B=1 cross K/V max diff", dk.max(), dv.max(), "mean", dk.mean(), dv.mean(), "scale", np.abs(ck).max())
+    assert (dk <= 2.0 ** -7 * np.maximum(np.abs(ck), 1.0)).all() and (dv <= 2.0 ** -7 * np.maximum(np.abs(cv), 1.0)).all()
+    assert dk.mean() < 2e-3 and dv.mean() < 2e-3
     print("small B=1 logits err", _check(got, ids, lg, logits[0]))
 
 

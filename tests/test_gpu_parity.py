@@ -2,11 +2,14 @@
 
 Tolerances (written here, justified in DESIGN.md §Numerics):
   front-end        2e-4 abs on the normalised log-mel (fp32 both sides; same bar the oracle meets vs the reference)
-  cross K/V        vs bf16-policy oracle: 3e-2 abs (values up to ~2; one bf16 ulp at 2.0 is 1.6e-2), mean abs 2e-3
-                   vs fp32 oracle:        6e-2 abs
-  logits           vs bf16-policy oracle: 2e-2 abs; vs fp32 oracle 5e-2 abs (logit std ~0.25-0.55)
+  cross K/V        vs bf16-policy oracle: 2e-2 abs (values up to ~2; ONE bf16 ulp at 2.0 is 1.56e-2 and that is what is
+                   measured: a value on a rounding boundary lands on either side), mean abs 1.5e-3 (measured 5.3e-4)
+                   vs fp32 oracle:        2e-2 abs (measured 8.7e-3 = half an ulp of storage + the arithmetic)
+  logits           vs bf16-policy oracle: 1e-3 abs (measured 1.4e-4 .. 1.8e-4); vs fp32 oracle 5e-3 abs (measured 1.1e-3);
+                   logit std ~0.23
   token ids        equal to the bf16-policy oracle's, except where the oracle's own top-2 margin is below 2x the
-                   measured logit error at that step (a numerical tie)
+                   measured logit error at that step + 1e-4 (a numerical tie)
+(round 4: every bound cut to at most ~5x what the test prints on MI355X — a 1e-2 logit defect cannot pass anywhere.)
 """
 import os
 
@@ -101,7 +104,7 @@ def test_encoder_cross_kv_vs_oracle(engine, micro_case):
         ef = max(np.abs(k - kf).max(), np.abs(v - vf).max())
         mb = max(np.abs(k - kb).mean(), np.abs(v - vb).mean())
         print(f"slot {slot}: vs bf16-policy max {eb:.3e} mean {mb:.3e}; vs fp32 max {ef:.3e}; scale {np.abs(kf).max():.2f}")
-        assert eb < 3e-2 and mb < 2e-3 and ef < 6e-2
+        assert eb < 2e-2 and mb < 1.5e-3 and ef < 2e-2
 
 
 def test_encoder_vs_transformers_golden(engine):
@@ -112,8 +115,9 @@ def test_encoder_vs_transformers_golden(engine):
     assert int(g["seed"]) == 11
     engine.encode_mel(golden_mel("micro_demo"))
     k, v = engine.get_cross_kv(0)
-    assert np.abs(k[:, ::53, ::7] - g["cross_k_sub"]).max() < 6e-2
-    assert np.abs(v[:, ::53, ::7] - g["cross_v_sub"]).max() < 6e-2
+    ek, ev = np.abs(k[:, ::53, ::7] - g["cross_k_sub"]).max(), np.abs(v[:, ::53, ::7] - g["cross_v_sub"]).max()
+    print("cross K/V vs the transformers golden (fp32)", ek, ev)
+    assert ek < 2e-2 and ev < 2e-2
     assert abs(np.abs(k).astype(np.float64).sum() / float(g["cross_k_abs"]) - 1) < 5e-3
 
 
@@ -146,7 +150,7 @@ def test_encoder_attention_rescale_threshold(built_lib, micro_case, monkeypatch)
             k, v = o[i]
             err = max(np.abs(k - kb).max(), np.abs(v - vb).max())
             print(f"mel {i} threshold {thr}: vs bf16-policy oracle {err:.3e}")
-            assert err < 3e-2
+            assert err < 2e-2
         for thr in ("0.5", None):
             dk = max(np.abs(outs[thr][i][0] - outs["0"][i][0]).max(), np.abs(outs[thr][i][1] - outs["0"][i][1]).max())
             print(f"mel {i} threshold {thr} vs 0: {dk:.3e}")
@@ -171,15 +175,15 @@ def test_decoder_teacher_forced_logits(engine, micro_case):
         ref = ref_logits[b]
         err = np.abs(logits[b] - ref).max(axis=1)
         print(f"clip {b}: logits err max {err.max():.3e}, logit std {ref.std():.3f}")
-        assert err.max() < 2e-2
+        assert err.max() < 1e-3
         srt = np.sort(ref, axis=1)
         margin = srt[:, -1] - srt[:, -2]
         for s in range(ref.shape[0]):
-            assert am[b, s] == int(ref[s].argmax()) or margin[s] < 2 * err[s], (b, s, margin[s], err[s])
+            assert am[b, s] == int(ref[s].argmax()) or margin[s] < 2 * err[s] + 1e-4, (b, s, margin[s], err[s])
 
 
 def test_decoder_given_oracle_cross_kv_isolated(engine, micro_case):
-    """fp32 oracle end to end as the loosest bar: logits within 5e-2 abs."""
+    """fp32 oracle end to end as the loosest bar: logits within 5e-3 abs (measured 1.1e-3)."""
     mel = _mels()[0]
     engine.encode_mel(mel)
     ck, cv = micro_case.oracle_fp32.encoder(mel)
@@ -187,7 +191,7 @@ def test_decoder_given_oracle_cross_kv_isolated(engine, micro_case):
     logits, _ = engine.decode_forced(1, np.array([ids]))
     err = np.abs(logits[0, : len(lg)] - lg).max()
     print("vs fp32 oracle logits err", err)
-    assert err < 5e-2
+    assert err < 5e-3
 
 
 def test_greedy_ids_match_oracle(engine, micro_case):

@@ -56,6 +56,8 @@ def test_slots_refill_while_others_decode(built_lib, micro_case):
             e.run_tokens(clips[0], max_new=4)
         with pytest.raises(RuntimeError):
             e.stream_admit(9, clips[0])       # no such slot
+        with pytest.raises(RuntimeError):
+            e.compute_mel(clips[0])           # would overwrite the staging rows an admission pass may still be reading
         e.stream_admit(1, clips[0], 5)
         with pytest.raises(RuntimeError):
             e.stream_admit(1, clips[1], 5)    # busy
@@ -67,6 +69,22 @@ def test_slots_refill_while_others_decode(built_lib, micro_case):
         assert fin == [1] and e.stream_collect(1) == got[0][:5]
         e.stream_close()
         assert e.run_tokens(clips[0], max_new=5) is not None
+        # StreamOpen(1): the step graph is built for 3 slots, but the caller opened ONE: slots 1 and 2 are not his, and
+        # finished_slots (host [n_slots]) can never receive more than one entry
+        e.stream_open(1)
+        for bad_slot in (1, 2):
+            with pytest.raises(RuntimeError):
+                e.stream_admit(bad_slot, clips[0], 5)
+        e.stream_admit(0, clips[0], 5)
+        fin = []
+        for _ in range(40):
+            fin = e.stream_step(2)
+            if fin:
+                break
+        assert fin == [0] and e.stream_collect(0) == got[0][:5]
+        with pytest.raises(RuntimeError):
+            e.stream_collect(1)
+        e.stream_close()
     finally:
         e.close()
 

@@ -10,7 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "whisper.axera_amd", "csrc")
-KERNEL_FILES = ["frontend", "gemm", "encoder_attn", "decoder", "decode_gemv", "decode_gemm", "decode_tail", "decode_persistent"]
+KERNEL_FILES = ["frontend", "gemm", "encoder_attn", "decoder", "decode_gemv", "decode_gemm", "decode_persistent"]
 
 
 @pytest.mark.parametrize("f16", [0, 1], ids=["bf16", "fp16"])  # both builds of every kernel file (csrc/common.hpp AXW_F16)

@@ -28,9 +28,12 @@
 using Engine = axw::IEngine;
 
 namespace axw {
-std::recursive_mutex& device_capture_mutex(int device) {
-  static std::recursive_mutex mu[64];
-  return mu[device & 63];
+std::recursive_mutex& device_capture_mutex(int) {
+  // ONE mutex for the whole process, not one per device: whether an allocation on device 1 can invalidate a thread-local
+  // capture on device 0 was never observable on a one-GPU box, so the exclusion does not depend on the answer. The cost is
+  // that engines of one AX_WHISPER_InitMulti handle are constructed one after the other (seconds, once per handle).
+  static std::recursive_mutex mu;
+  return mu;
 }
 std::mutex& persistent_launch_mutex(int device) {
   static std::mutex mu[64];  // one per device: engines of different GPUs never wait for each other

@@ -377,23 +377,6 @@ void launch_act_prep(float* x, const float* g, const float* be, h16* hi, h16* lo
                      const float* part, int n_part, int part_batch, const float* part_bias, hipStream_t s);
 void launch_pack_weight_frag(const h16* w, h16* wp, int N, int K, hipStream_t s);
 
-// Second half of a decoder layer as one launch (decode_tail.hip): cross-attention output projection -> LayerNorm + mlp.0
-// + GELU -> mlp.2 -> LayerNorm + Q,K,V of the next layer, per 16-clip cluster of workgroups with in-launch hand-offs.
-struct DecTailParams {
-  const h16 *w_co, *w_fc1, *w_fc2, *w_qkv;        // fragment-major packed weights; w_qkv == nullptr: last layer, no phase D
-  const float *b_co, *b_fc1, *b_fc2, *b_qkv;
-  const float *ln2_w, *ln2_b, *ln1_w, *ln1_b;      // mlp_ln of this layer, attn_ln of the next
-  const h16 *att_hi, *att_lo;                      // cross-attention output pair (this launch's first clip block)
-  h16 *hid_hi, *hid_lo;                            // mlp hidden pair (scratch, same origin)
-  float* x;                                        // residual stream [batch][d]
-  float* q_out; h16* k_cache; h16* v_cache; long kv_batch_stride; int n_ctx_pad; const int* off;  // phase D (next layer's caches)
-  int d, batch, nbs, wgs_per_cluster;
-  unsigned* sync;                                  // [8 + 8 * clip blocks] words of this launch group, zero at start
-};
-int decode_tail_cluster(int d);     // workgroups per 16-clip cluster
-bool decode_tail_supported(int d);
-void launch_decode_tail(const DecTailParams& p, hipStream_t s);
-
 struct AdvanceParams {
   const float* amax_val; const int* amax_idx; int n_part; int amax_stride;
   DecState* state; int* off; int* tok; int* done; int* n_out; int* out_ids; int batch;

@@ -135,16 +135,6 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
     // encoder attention: rescale threshold of the running softmax maximum (tests run 0 = rescale on every increase)
     if (const char* t = getenv("AX_WHISPER_ENC_RESCALE_THR")) enc_rescale_thr_ = std::max(0.f, std::min(16.f, (float)atof(t)));
   }
-  {  // batched decode: the second half of a layer as ONE launch (decode_tail.hip); needs the clip-block sequence.
-    // OFF unless AX_WHISPER_TAIL=1: measured on MI355X (Whisper-small, profiles/r03_tail_ab.txt) the three in-launch
-    // hand-offs cost what the three launch boundaries they replace cost (16 clips: step 0.653 vs 0.653 ms) and more
-    // once two graph branches run their tails side by side (64 clips: 1.143 -> 1.212 ms). Same results (bit-identical at d = 512, tests/test_gpu_batched.py).
-    const char* e = getenv("AX_WHISPER_TAIL");
-    tail_ok_ = e && e[0] == '1' && batched_ln_ && decode_tail_supported(cfg_.n_text_state);
-    d_tail_sync_ = (unsigned*)dalloc((size_t)kMaxBranches * kTailSyncWords * 4, true);
-    allocs_.push_back(d_tail_sync_);
-    cfg_.ints["decode_tail"] = tail_ok_ ? 1 : 0;
-  }
   cfg_.ints["t2s"] = t2s_ ? 1 : 0;
   cfg_.ints["fp16"] = AXW_F16;  // 16-bit storage / MFMA operand type of this engine: 0 bfloat16, 1 IEEE half
   ensure_capacity(std::max(1, max_batch));
@@ -592,12 +582,19 @@ void Engine::upload_pcm(const float* const* pcm, const int* n_samples, int batch
   std::vector<long long> off(batch, 0);
   size_t over_total = 0;
   for (int b = 0; b < batch; ++b) {
-    if (n_samples[b] > (1 << 30)) throw std::runtime_error("clip " + std::to_string(b) + ": more than 2^30 samples");
+    // (the reflect-pad index of the STFT is 2n - 2 - j in 32-bit arithmetic: 2^29 samples = 9.3 hours is the cap)
+    if (n_samples[b] > (1 << 29)) throw std::runtime_error("clip " + std::to_string(b) + ": more than 2^29 samples");
     off[b] = (long long)over_total;
     if (n_samples[b] > pcm_stride_) over_total += (size_t)n_samples[b] - (size_t)pcm_stride_;
   }
   over_used_ = over_total > 0;
-  if (over_total > 0) HIP_CHECK(hipStreamSynchronize(stream()));  // rare path: an earlier pass on this stream may still read the tails
+  // rare path (clips beyond a 60 s staging row): allocation and synchronous copies, which must not run beside another
+  // handle's stream capture (iengine.hpp)
+  std::unique_lock<std::recursive_mutex> capture_lock(device_capture_mutex(device_), std::defer_lock);
+  if (over_total > 0) {
+    capture_lock.lock();
+    HIP_CHECK(hipStreamSynchronize(stream()));  // an earlier pass on this stream may still read the tails
+  }
   if (over_total > over_cap_) {
     if (d_over_) { (void)hipFree(d_over_); d_over_ = nullptr; over_cap_ = 0; }
     HIP_CHECK(hipMalloc((void**)&d_over_, over_total * 4));
@@ -862,7 +859,7 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
 // consumer and the residual add the epilogue of its producer, so a layer is 7 launches instead of 11
 // (AX_WHISPER_BATCHED_LN=0: the older sequence with a separate LayerNorm/h16-pair preparation launch and split-K
 // partials). b0 is a multiple of 16: every per-clip buffer of the range starts at a whole clip block.
-void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced, int branch) {
+void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
   const int d = cfg_.n_text_state, H = cfg_.n_text_head, L = cfg_.n_text_layer, Tc = cfg_.n_text_ctx;
   const long self_stride = (long)H * Tc * 64, cross_stride = (long)H * t_pad_ * 64;
   const long frag0 = (long)(b0 / 16) * 512;  // fragment-major pair layouts: clip blocks are 512 elements apart within a k-step
@@ -902,11 +899,6 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced, i
   // two row tiles per workgroup where one would make more workgroups than can be resident at once
   auto rt_for = [&](int N) { return (N / 16) * n_blk > 512 ? 2 : 1; };
 
-  // One launch for the second half of a layer (decode_tail.hip) when every workgroup of every branch can be resident at
-  // once: clusters of decode_tail_cluster(d) workgroups per clip block, one workgroup per CU
-  const int tail_w = decode_tail_cluster(d);
-  const bool tail = tail_ok_ && fuse_cq && (step_mask_ & 1) && branch < kMaxBranches && n_blk <= 15 && tail_w * step_blocks_ <= n_cu_;
-
   for (int l = 0; l < L; ++l) {
     const DecLayerW& w = dec_[l];
     const DecLayerWP& wq = dec_packed_[l];
@@ -917,7 +909,7 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced, i
     DecCGemmParams c = cgemm(wq.w_qkv, w.b_qkv, 3 * d, d, GEPI_QKV_CACHE, rt_for(3 * d));
     c.x = x; c.ln_w = w.attn_ln_w; c.ln_b = w.attn_ln_b;
     c.out = qd; c.k_cache = sk; c.v_cache = sv; c.kv_batch_stride = self_stride;
-    if (!tail || l == 0) cgo(c);  // with the tail launch, layer l's Q,K,V come out of layer l-1's tail
+    cgo(c);
     if (step_mask_ & 2) launch_decode_attention(attn(sk, sv, self_stride, -1, Tc / 64), s);
     c = cgemm(wq.w_o, w.b_o, d, d, GEPI_RESID, 1);
     c.a_hi = att_hi; c.a_lo = att_lo; c.out = x;
@@ -936,23 +928,6 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced, i
       c.x = x; c.ln_w = w.cross_ln_w; c.ln_b = w.cross_ln_b; c.out = qd;
       cgo(c);
       if (step_mask_ & 2) launch_decode_attention(attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64), s);
-    }
-    if (tail) {
-      DecTailParams t{};
-      t.w_co = wq.w_co; t.b_co = w.b_co; t.w_fc1 = wq.w_fc1; t.b_fc1 = w.b_fc1; t.w_fc2 = wq.w_fc2; t.b_fc2 = w.b_fc2;
-      t.ln2_w = w.mlp_ln_w; t.ln2_b = w.mlp_ln_b;
-      t.att_hi = att_hi; t.att_lo = att_lo; t.hid_hi = hid_hi; t.hid_lo = hid_lo; t.x = x;
-      if (l + 1 < L) {
-        t.w_qkv = dec_packed_[l + 1].w_qkv; t.b_qkv = dec_[l + 1].b_qkv; t.ln1_w = dec_[l + 1].attn_ln_w; t.ln1_b = dec_[l + 1].attn_ln_b;
-        t.q_out = qd;
-        t.k_cache = d_self_k_ + ((size_t)(l + 1) * cap_ + b0) * self_stride;
-        t.v_cache = d_self_v_ + ((size_t)(l + 1) * cap_ + b0) * self_stride;
-        t.kv_batch_stride = self_stride; t.n_ctx_pad = Tc; t.off = d_off_ + b0;
-      }
-      t.d = d; t.batch = nb; t.nbs = nbs_; t.wgs_per_cluster = tail_w;
-      t.sync = d_tail_sync_ + (size_t)branch * kTailSyncWords;
-      launch_decode_tail(t, s);
-      continue;
     }
     c = cgemm(wq.w_co, w.b_co, d, d, GEPI_RESID, 1);
     c.a_hi = att_hi; c.a_lo = att_lo; c.out = x;
@@ -1067,13 +1042,8 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     // the ONE step graph, so one branch's latency-bound chain of small GEMMs overlaps the other's bandwidth-bound
     // attention launches (a single chain leaves the chip idle between its ~85 dependent launches).
     const int nbr = decode_branches(batch);
-    {  // clip blocks of all branches together: every workgroup of every tail launch in flight must fit the device
-      const int per = nbr == 1 ? batch : ((batch + nbr - 1) / nbr + 15) / 16 * 16;
-      step_blocks_ = 0;
-      for (int i = 0; i < nbr; ++i) step_blocks_ += (std::max(0, std::min(per, batch - i * per)) + 15) / 16;
-    }
     if (nbr == 1) {
-      enqueue_layers_cblock(0, batch, s, d_forced != nullptr, 0);
+      enqueue_layers_cblock(0, batch, s, d_forced != nullptr);
     } else {
       const int per = ((batch + nbr - 1) / nbr + 15) / 16 * 16;
       HIP_CHECK(hipEventRecord(ev_fork_, s));
@@ -1082,7 +1052,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
         if (nb <= 0) break;
         hipStream_t bs = i == 0 ? s : branch_stream_[i - 1];
         if (i > 0) HIP_CHECK(hipStreamWaitEvent(bs, ev_fork_, 0));
-        enqueue_layers_cblock(b0, nb, bs, d_forced != nullptr, i);
+        enqueue_layers_cblock(b0, nb, bs, d_forced != nullptr);
         if (i > 0) {
           HIP_CHECK(hipEventRecord(ev_join_[i - 1], bs));
           HIP_CHECK(hipStreamWaitEvent(s, ev_join_[i - 1], 0));
@@ -1160,25 +1130,6 @@ void Engine::persistent_succeeded() {
   cfg_.ints["persistent_decode"] = 1;
 }
 
-// A tail launch whose workgroups could not all be resident gives up after 50 ms and raises its branch's error word: the
-// results of that decode are void. The path is switched off for this engine and the caller runs the decode again.
-bool Engine::tail_failed() {
-  if (!tail_ok_) return false;
-  unsigned h[kMaxBranches * kTailSyncWords];
-  HIP_CHECK(hipMemcpy(h, d_tail_sync_, sizeof h, hipMemcpyDeviceToHost));
-  bool bad = false;
-  for (int b = 0; b < kMaxBranches; ++b) bad |= h[b * kTailSyncWords + 2] != 0;
-  if (!bad) return false;
-  fprintf(stderr, "[ax_whisper] a decoder tail launch gave up (its workgroups were not all resident); using the launch-per-layer sequence from now on\n");
-  HIP_CHECK(hipDeviceSynchronize());
-  HIP_CHECK(hipMemset(d_tail_sync_, 0, sizeof h));
-  tail_ok_ = false;
-  cfg_.ints["decode_tail"] = 0;
-  for (auto& g : graphs_) (void)hipGraphExecDestroy(g.second);  // captured with the tail launches
-  graphs_.clear();
-  return true;
-}
-
 // After a failed capture the engine's own streams may be left in capture state ("operation failed due to a previous error
 // during capture" on everything enqueued afterwards): they are replaced.
 void Engine::recover_streams() {
@@ -1245,7 +1196,6 @@ int Engine::greedy_loop(int batch, int max_new, const int* max_new_clip) {
     if (b == batch) { persistent_succeeded(); return steps; }
     persistent_gave_up();  // these utterances (and the next few) take the launch-per-phase path
   }
-  for (int attempt = 0;; ++attempt) {
   reset_decode_state(batch, max_new_clip);
   hipGraphExec_t g = step_graph(batch, max_new);
   hipStream_t s = stream();
@@ -1266,12 +1216,7 @@ int Engine::greedy_loop(int batch, int max_new, const int* max_new_clip) {
       ++polls;
     }
   }
-  if (tail_ok_ && batch > gemv_max_) {  // a tail launch that gave up voids this decode: once more without that path
-    HIP_CHECK(hipStreamSynchronize(s));
-    if (attempt == 0 && tail_failed()) continue;
-  }
   return steps;
-  }
 }
 
 int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float* d_logits, int* d_argmax, int slot) {
@@ -1400,6 +1345,8 @@ std::string Engine::detokenize(const int32_t* ids, int n) const {
 }
 
 void Engine::compute_mel(const float* pcm, int n_samples, float* mel_out) {
+  // an open stream's admission pass may still be reading the staging rows and front-end buffers this call overwrites
+  require_no_stream("compute_mel");
   HIP_CHECK(hipSetDevice(device_));
   ensure_capacity(1);
   const float* arr[1] = {pcm};
@@ -1475,15 +1422,6 @@ void Engine::decode_forced(int batch, const int32_t* forced, int n_forced, float
     enqueue_decode_step(batch, cfg_.n_text_ctx, d_forced, n_forced, lrow, (long)rows * nv, d_arg);
   }
   HIP_CHECK(hipStreamSynchronize(s));
-  if (!done && tail_failed()) {  // void results: the same steps again through the launch-per-layer sequence
-    reset_decode_state(batch);
-    for (int st = 0; st < 4 + n_forced; ++st) {
-      const int gi = st - 3;
-      float* lrow = (d_logits && gi >= 0) ? d_logits + (size_t)gi * nv : nullptr;
-      enqueue_decode_step(batch, cfg_.n_text_ctx, d_forced, n_forced, lrow, (long)rows * nv, d_arg);
-    }
-    HIP_CHECK(hipStreamSynchronize(s));
-  }
   if (logits) HIP_CHECK(hipMemcpy(logits, d_logits, (size_t)batch * rows * nv * 4, hipMemcpyDeviceToHost));
   if (argmax_ids) HIP_CHECK(hipMemcpy(argmax_ids, d_arg, (size_t)batch * rows * 4, hipMemcpyDeviceToHost));
 }
@@ -1546,6 +1484,7 @@ void Engine::stream_open(int n_slots) {
   memset(h_done_live_, 0, (size_t)cap_ * 4);
   step_seq_ = 0;
   stream_slots_ = n;
+  stream_user_slots_ = n_slots;
   cfg_.ints["stream_slots"] = n_slots;
 }
 
@@ -1554,6 +1493,7 @@ void Engine::stream_close() {
   (void)hipStreamSynchronize(admit_stream_);
   (void)hipStreamSynchronize(stream());
   stream_slots_ = 0;
+  stream_user_slots_ = 0;
   slot_state_.clear();
   cfg_.ints["stream_slots"] = 0;
 }
@@ -1561,9 +1501,10 @@ void Engine::stream_close() {
 void Engine::stream_admit(const int* slots, const float* const* pcm, const int* n_samples, const int* max_new, int count) {
   HIP_CHECK(hipSetDevice(device_));
   if (stream_slots_ == 0) throw std::runtime_error("stream_admit: no stream open");
-  if (count < 1 || count > stream_slots_) throw std::runtime_error("stream_admit: count out of range");
+  if (count < 1 || count > stream_user_slots_) throw std::runtime_error("stream_admit: count out of range");
   for (int i = 0; i < count; ++i) {
-    if (slots[i] < 0 || slots[i] >= stream_slots_) throw std::runtime_error("stream_admit: slot out of range");
+    // the slots the caller opened, not the 3 the step graph is rounded up to: finished_slots of StreamStep is [n_slots]
+    if (slots[i] < 0 || slots[i] >= stream_user_slots_) throw std::runtime_error("stream_admit: slot out of range");
     if (slot_state_[slots[i]] != kIdle) throw std::runtime_error("stream_admit: slot " + std::to_string(slots[i]) + " is busy");
     for (int j = 0; j < i; ++j) if (slots[j] == slots[i]) throw std::runtime_error("stream_admit: a slot is listed twice");
     if (n_samples[i] < 1) throw std::runtime_error("empty audio clip");
@@ -1653,7 +1594,7 @@ int Engine::stream_step(int n_steps, int* finished_slots) {
 void Engine::stream_collect(int slot, int32_t* ids, int* n_ids) {
   HIP_CHECK(hipSetDevice(device_));
   if (stream_slots_ == 0) throw std::runtime_error("stream_collect: no stream open");
-  if (slot < 0 || slot >= stream_slots_ || slot_state_[slot] != kFinished) throw std::runtime_error("stream_collect: slot has not finished");
+  if (slot < 0 || slot >= stream_user_slots_ || slot_state_[slot] != kFinished) throw std::runtime_error("stream_collect: slot has not finished");
   // on its own stream: the slot's ids are final (its done flag was seen), the decoder steps queued meanwhile do not touch them
   HIP_CHECK(hipMemcpyAsync(ids, d_out_ids_ + (size_t)slot * cfg_.n_text_ctx, (size_t)cfg_.n_text_ctx * 4, hipMemcpyDeviceToHost, copy_stream_));
   HIP_CHECK(hipMemcpyAsync(n_ids, d_nout_ + slot, 4, hipMemcpyDeviceToHost, copy_stream_));

@@ -73,7 +73,7 @@ class Engine final : public IEngine {
                            int* d_argmax);
   void enqueue_decode_step_batched(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits,
                                    long logits_stride, int* d_argmax);
-  void enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced, int branch = 0);
+  void enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced);
   int decode_branches(int batch) const;
   hipGraphExec_t step_graph(int batch, int max_new);
   void recover_streams();
@@ -141,17 +141,12 @@ class Engine final : public IEngine {
   unsigned* d_attn_mcnt_ = nullptr;
   int *d_tok_ = nullptr, *d_done_ = nullptr, *d_nout_ = nullptr, *d_out_ids_ = nullptr, *d_max_new_clip_ = nullptr;
   int* d_off_ = nullptr;   // per-slot offsets (common.hpp: DecState)
-  // second half of a decoder layer as one launch (decode_tail.hip): sync words per graph branch; AX_WHISPER_TAIL=0 disables
-  bool tail_ok_ = false;
   int n_cu_ = 0;            // compute units of the device
-  int step_blocks_ = 0;     // clip blocks of the step being enqueued, summed over its branches (residency of the tail launches)
-  unsigned* d_tail_sync_ = nullptr;
-  static constexpr int kTailSyncWords = 128;  // per branch: error word + 8 words per clip block (<= 15 blocks), decode_tail.hip
-  bool tail_failed();  // reads the error words; true (and the path is switched off) if a launch gave up
   // slot refill (stream_*): a slot is idle -> encoding (admitted, encoder in flight on admit_stream_) -> active (decoding)
   // -> finished (done flag seen) -> idle again after stream_collect
   enum SlotState : int { kIdle = 0, kEncoding = 1, kActive = 2, kFinished = 3 };
-  int stream_slots_ = 0;                 // > 0: a stream is open
+  int stream_slots_ = 0;                 // > 0: a stream is open (slots of the step graph: at least 3)
+  int stream_user_slots_ = 0;            // the n_slots the caller asked for: the slot indices it may use
   std::vector<int> slot_state_, slot_max_new_;
   std::vector<hipEvent_t> ev_admit_;     // one per slot: its encoder has finished
   hipStream_t admit_stream_ = nullptr;

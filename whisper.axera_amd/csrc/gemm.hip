@@ -12,8 +12,8 @@
 //   gemm_bf16_kernel       128x128, 4 waves, two LDS buffers (this comment)        few tiles: one to four clips
 //   gemm256_bf16_kernel    256x128, 8 waves, 3-stage LDS-DMA ring                  mid-size launches
 //   gemm256ps_bf16_kernel  256x256, phased 16x16x32 k-loop, one k-tile STREAM per CU the batched encoder (>= 256 tiles)
-//   gemm256ph_bf16_kernel  the same k-loop, one tile per workgroup                 operands beyond 4 GB / A-B runs
-//   gemm256sq_bf16_kernel  256x256, two-stage 32x32x16 loop (round 1)              odd k-tile counts
+// (Two more 256x256 kernels of rounds 1-2 — a two-stage 32x32x16 loop and the phased loop with one tile per workgroup —
+// served only odd k-tile counts and operands beyond 4 GB; those corner cases now take the 256x128 kernel.)
 // All share the swizzled LDS image, the tile order and the epilogues (epilogue_rows).
 // Tiling of the smallest (wave64): 128x128 output tile, BK = 64, 256 threads = 4 waves in 2x2, each wave a
 // 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs). A and W tiles are staged by LDS-DMA
@@ -416,126 +416,11 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmParams p) {
   gemm_epilogue<EPI, SWAPPED>(p, acc, reinterpret_cast<float*>(smem) + wave * 4096, m0 + wm * 64, n0 + wn * 64, bz, lane);
 }
 
-// ---------------------------------------------------------------------------- 256 x 256 tile, 128 x 64 per wave
-// For launches with enough 256-square tiles to fill the chip. 8 waves as 2 (M) x 4 (N), each a 128x64 sub-tile =
-// 4x2 accumulator tiles (128 VGPRs): per k-step a wave reads 6 fragments for 8 MFMAs (the 64x64 sub-tile: 4 for 4),
-// and a k-tile costs 64 KB of staging for 4.2 MFLOP x 4 = 128 FLOP per staged byte (256x128: 85) — the k-loop of
-// these kernels is bound by how many staged bytes can be in flight, not by the matrix pipe. Two 64 KB stages: k-tile
-// t+1 streams in (LDS-DMA) while k-tile t is multiplied. Same swizzled LDS image and epilogues as above.
+// ---------------------------------------------------------------------------- 256 x 256 tile
+// For launches with enough 256-square tiles to fill the chip: 8 waves as 2 (M) x 4 (N), each a 128x64 sub-tile; a k-tile
+// costs 64 KB of staging for 128 FLOP per staged byte (256x128: 85) — the k-loop of these kernels is bound by how many
+// staged bytes can be in flight, not by the matrix pipe.
 constexpr int BM3 = 256, BN3 = 256;
-constexpr int A3_BYTES = BM3 * BK * 2;      // 32 KB
-constexpr int STAGE3_BYTES = 2 * A3_BYTES;  // A | W
-
-template <int EPI, bool SWAPPED>
-__global__ __launch_bounds__(512) void gemm256sq_bf16_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 32 KB | W 32 KB]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int r = lane & 31, h = lane >> 5;
-  int n0, m0, bz;
-  {
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
-    const int nt = p.n_tiles, mt = (p.M + BM3 - 1) / BM3;
-    // Wide launches (the cross-K/V projection: 36-40 column tiles, 14-26 MB of weights) walk the columns in groups of
-    // 8 tiles: an XCD sweeps its A panels against ONE group (3 MB of weights, which stay in its 4 MB L2) before it moves
-    // to the next, instead of streaming all the weights past every panel (5.7 GB fetched per launch at 64 clips).
-    constexpr int G = 8;
-    int nl, rest;
-    if (nt <= G) {
-      nl = wg % nt;
-      rest = wg / nt;
-    } else {
-      const int panels = mt * p.batch, full = nt / G, in_full = full * G * panels;
-      if (wg < in_full) {
-        const int g = wg / (G * panels), within = wg % (G * panels);
-        rest = within / G;
-        nl = g * G + within % G;
-      } else {
-        const int gl = nt - full * G, w2 = wg - in_full;
-        rest = w2 / gl;
-        nl = full * G + w2 % gl;
-      }
-    }
-    n0 = p.n_begin + nl * BN3;
-    m0 = (rest % mt) * BM3;
-    bz = rest / mt;
-  }
-  const h16* A = p.A + (long)bz * p.a_batch_stride;
-  const h16* W = p.W;
-
-  const int ld_row = tid >> 3, ld_c = tid & 7;  // lane l of wave w: tile row 8w + l/8 (+64 i), chunk position l%8
-  const h16* a_src[4];
-  const h16* w_src[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = ld_row + 64 * i;
-    const int gc = (ld_c ^ ((row >> 1) & 7)) * 8;
-    a_src[i] = A + (long)min(m0 + row, p.M - 1) * p.lda + gc;
-    w_src[i] = W + (long)(n0 + row) * p.K + gc;
-  }
-  auto stage = [&](int buf, int kt) {  // 8 LDS-DMA pieces (1 KiB each) per wave
-    char* base = smem + buf * STAGE3_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + kt * BK), (lds_ptr_t)(base + (64 * i + 8 * wave) * (BK * 2)), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + kt * BK), (lds_ptr_t)(base + A3_BYTES + (64 * i + 8 * wave) * (BK * 2)), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  auto compute = [&](int buf) {
-    const char* Ab = smem + buf * STAGE3_BYTES;
-    const char* Wb = Ab + A3_BYTES;
-    h16x8 af[2][4], wf[2][2];
-    auto frags = [&](int s, int set) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) wf[set][j] = *reinterpret_cast<const h16x8*>(Wb + swz(wn * 64 + j * 32 + r, 2 * s + h));
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[set][i] = *reinterpret_cast<const h16x8*>(Ab + swz(wm * 128 + i * 32 + r, 2 * s + h));
-    };
-    frags(0, 0);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s < 3) frags(s + 1, (s + 1) & 1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = SWAPPED ? AXW_MFMA_32x32x16(wf[s & 1][j], af[s & 1][i], acc[i][j])
-                              : AXW_MFMA_32x32x16(af[s & 1][i], wf[s & 1][j], acc[i][j]);
-    }
-  };
-
-  const int nk = p.K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // k-tile kt is in LDS (every wave's pieces); every wave is done reading k-tile kt-1
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    compute(kt & 1);
-  }
-#ifdef AXW_GEMM_NO_EPILOGUE  // microbenchmark: the k-loop alone (accumulators kept alive)
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
-  return;
-#endif
-  __syncthreads();  // the staging buffers now hold the parked sub-tiles (8 x 16 KB), one 64-row half at a time
-  float* lw = reinterpret_cast<float*>(smem) + wave * 4096;
-  gemm_epilogue<EPI, SWAPPED, 4, 0>(p, acc, lw, m0 + wm * 128, n0 + wn * 64, bz, lane);
-  gemm_epilogue<EPI, SWAPPED, 4, 2>(p, acc, lw, m0 + wm * 128 + 64, n0 + wn * 64, bz, lane);
-}
 
 // ---------------------------------------------------------------------------- 256 x 256 tile, phased k-loop
 // The batched encoder's kernel (launches with at least one 256-square tile per CU and an even number of k-tiles).
@@ -608,206 +493,8 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc
   }
 }
 
-template <int EPI, bool SWAPPED>
-__global__ __launch_bounds__(512) void gemm256ph_bf16_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 k-tiles][A0 | A1 | W0 | W1]
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
-  const int wr = wave >> 2, wc = wave & 3;
-  const int fr = lane & 15, fq = lane >> 4;
-  int n0, m0, bz;
-  {
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
-    const int nt = p.n_tiles, mt = (p.M + BM3 - 1) / BM3;
-    constexpr int G = 8;  // wide launches walk the columns in groups of 8 tiles (see gemm256sq_bf16_kernel)
-    int nl, rest;
-    if (nt <= G) {
-      nl = wg % nt;
-      rest = wg / nt;
-    } else {
-      const int panels = mt * p.batch, full = nt / G, in_full = full * G * panels;
-      if (wg < in_full) {
-        const int g = wg / (G * panels), within = wg % (G * panels);
-        rest = within / G;
-        nl = g * G + within % G;
-      } else {
-        const int gl = nt - full * G, w2 = wg - in_full;
-        rest = w2 / gl;
-        nl = full * G + w2 % gl;
-      }
-    }
-    n0 = p.n_begin + nl * BN3;
-    m0 = (rest % mt) * BM3;
-    bz = rest / mt;
-  }
-  const h16* A = p.A + (long)bz * p.a_batch_stride;
-  const h16* W = p.W;
-
-  // LDS-DMA sources: piece q of a half-tile = its rows q*64 + 8*wave + lane/8 (1 KiB per wave instruction, linear in
-  // LDS), chunk position lane%8 holding global chunk position ^ ((row>>1)&7) (swz(): the involution the reads apply)
-  const h16* a_src[2][2];
-  const h16* w_src[2][2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int lr = q * 64 + 8 * wave + (lane >> 3);
-    const int gc = ((lane & 7) ^ ((lr >> 1) & 7)) * 8;
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int arow = (lr >> 6) * 128 + hh * 64 + (lr & 63);
-      const int wrow = (lr >> 5) * 64 + hh * 32 + (lr & 31);
-      a_src[hh][q] = A + (long)min(m0 + arow, p.M - 1) * p.lda + gc;
-      w_src[hh][q] = W + (long)(n0 + wrow) * p.K + gc;
-    }
-  }
-  // which: 0 A0, 1 A1, 2 W0, 3 W1
-  auto stage = [&](auto WHICH, auto BUF, int kt) {
-    constexpr int which = decltype(WHICH)::value, buf = decltype(BUF)::value;
-    char* base = smem + buf * KT4_BYTES + which * HALF_BYTES + 8 * wave * (BK * 2);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const h16* src = (which < 2 ? a_src[which & 1][q] : w_src[which & 1][q]) + kt * BK;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(base + q * 64 * (BK * 2)), 16, 0, 0);
-    }
-  };
-  using I0_ = std::integral_constant<int, 0>;
-  using I1_ = std::integral_constant<int, 1>;
-  using I2_ = std::integral_constant<int, 2>;
-  using I3_ = std::integral_constant<int, 3>;
-
-  // fragment addresses: row-tile it (jt) adds 16 rows = 2048 B, k-step s flips chunk bit 2 (64 B); both fold into
-  // the ds_read's immediate offset or one XOR
-  const int swz_c = (fq ^ (fr >> 1)) * 16;
-  const int a_off = (wr * 64 + fr) * (BK * 2) + swz_c;
-  const int w_off = (wc * 32 + fr) * (BK * 2) + swz_c;
-
-  f32x4 acc[2][2][4][2];  // [mi][nj][it][jt]
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-      for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) acc[mi][nj][it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  h16x8 af[4][2], wf0[2][2], wf1[2][2];
-  auto read_a = [&](const char* half) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) af[it][s] = *reinterpret_cast<const h16x8*>(half + ((a_off + it * 2048) ^ (s * 64)));
-  };
-  auto read_w = [&](const char* half, h16x8 (&wf)[2][2]) {
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) wf[jt][s] = *reinterpret_cast<const h16x8*>(half + ((w_off + jt * 2048) ^ (s * 64)));
-  };
-  auto quadrant = [&](f32x4 (&c)[4][2], const h16x8 (&wf)[2][2]) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-          c[it][jt] = SWAPPED ? AXW_MFMA_16x16x32(wf[jt][s], af[it][s], c[it][jt]) : AXW_MFMA_16x16x32(af[it][s], wf[jt][s], c[it][jt]);
-  };
-#define AXW_PHASE_MFMA_BEGIN()                             \
-  __builtin_amdgcn_sched_barrier(0);                       \
-  __builtin_amdgcn_s_barrier();                            \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
-  __builtin_amdgcn_sched_barrier(0);                       \
-  __builtin_amdgcn_s_setprio(1)
-#define AXW_PHASE_MFMA_END()                               \
-  __builtin_amdgcn_s_setprio(0);                           \
-  __builtin_amdgcn_sched_barrier(0);                       \
-  __builtin_amdgcn_s_barrier();                            \
-  __builtin_amdgcn_sched_barrier(0)
-
-  // one k-tile out of LDS buffer BUF; NEXT1 / NEXT2: k-tiles kt+1 / kt+2 exist (their prefetches are issued here)
-  auto ktile = [&](auto BUF, auto NEXT1, auto NEXT2, int kt) {
-    constexpr int buf = decltype(BUF)::value;
-    constexpr bool next1 = decltype(NEXT1)::value != 0, next2 = decltype(NEXT2)::value != 0;
-    using OTHER = std::integral_constant<int, buf ^ 1>;
-    const char* base = smem + buf * KT4_BYTES;
-    // phase 1
-    read_w(base + 2 * HALF_BYTES, wf0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_a(base);
-    if constexpr (next1) stage(I1_{}, OTHER{}, kt + 1);
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-    AXW_PHASE_MFMA_BEGIN();
-    quadrant(acc[0][0], wf0);
-    AXW_PHASE_MFMA_END();
-    // phase 2
-    read_w(base + 3 * HALF_BYTES, wf1);
-    if constexpr (next2) stage(I2_{}, BUF, kt + 2);
-    AXW_PHASE_MFMA_BEGIN();
-    quadrant(acc[0][1], wf1);
-    AXW_PHASE_MFMA_END();
-    // phase 3
-    read_a(base + HALF_BYTES);
-    if constexpr (next2) stage(I0_{}, BUF, kt + 2);
-    AXW_PHASE_MFMA_BEGIN();
-    quadrant(acc[1][1], wf1);
-    AXW_PHASE_MFMA_END();
-    // phase 4
-    if constexpr (next2) {
-      stage(I3_{}, BUF, kt + 2);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else if constexpr (next1) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    AXW_PHASE_MFMA_BEGIN();
-    quadrant(acc[1][0], wf0);
-    AXW_PHASE_MFMA_END();
-  };
-
-  const int nk = p.K / BK;  // even, >= 4 (launch_one)
-  stage(I2_{}, I0_{}, 0);
-  stage(I0_{}, I0_{}, 0);
-  stage(I3_{}, I0_{}, 0);
-  stage(I1_{}, I0_{}, 0);
-  stage(I2_{}, I1_{}, 1);
-  stage(I0_{}, I1_{}, 1);
-  stage(I3_{}, I1_{}, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind the first from here on
-  __builtin_amdgcn_sched_barrier(0);
-  int kt = 0;
-  for (; kt + 2 < nk; kt += 2) {
-    ktile(I0_{}, I1_{}, I1_{}, kt);
-    ktile(I1_{}, I1_{}, I1_{}, kt + 1);
-  }
-  ktile(I0_{}, I1_{}, I0_{}, kt);
-  ktile(I1_{}, I0_{}, I0_{}, kt + 1);
-  if (wr == 0) __builtin_amdgcn_s_barrier();  // back in step: every wave is done with the staging buffers
-  __builtin_amdgcn_sched_barrier(0);
-#undef AXW_PHASE_MFMA_BEGIN
-#undef AXW_PHASE_MFMA_END
-#ifdef AXW_GEMM_NO_EPILOGUE
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-      for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) asm volatile("" ::"v"(acc[mi][nj][it][jt]));
-  return;
-#endif
-  float* lw = reinterpret_cast<float*>(smem) + wave * 4096;  // the buffers now hold the parked sub-tiles, one 64-row half at a time
-  gemm_epilogue16<EPI, SWAPPED>(p, acc[0], lw, m0 + wr * 128, n0 + wc * 64, bz, lane);
-  gemm_epilogue16<EPI, SWAPPED>(p, acc[1], lw, m0 + wr * 128 + 64, n0 + wc * 64, bz, lane);
-}
-
 // ---------------------------------------------------------------------------- 256 x 256 tiles, one k-tile STREAM per CU
-// gemm256ph_bf16_kernel's k-loop, but a workgroup per CU that walks its share of the tiles, so that the LDS-DMA
+// The phased k-loop above, run by a workgroup per CU that walks its share of the tiles, so that the LDS-DMA
 // pipeline never drains at a tile boundary: the last two k-tiles of a tile prefetch the first two of the NEXT tile
 // exactly where the steady state would prefetch k-tiles t+1 / t+2, and the epilogue runs with three half-tiles in
 // flight instead of being followed by a cold prologue (first loads of a 256-row A panel from HBM: 2-3 us of a ~30 us
@@ -843,7 +530,10 @@ __global__ __launch_bounds__(512) void gemm256ps_bf16_kernel(GemmParams p) {
   if (t_cur >= t_last) return;  // (whole workgroup)
 
   auto decode = [&](int wg, int& n0, int& m0, int& bz) {
-    constexpr int G = 8;  // wide launches walk the columns in groups of 8 tiles (see gemm256sq_bf16_kernel)
+    // Wide launches (the cross-K/V projection: 36-40 column tiles, 14-26 MB of weights) walk the columns in groups of
+    // 8 tiles: an XCD sweeps its A panels against ONE group (3 MB of weights, which stay in its 4 MB L2) before it moves
+    // to the next, instead of streaming all the weights past every panel (5.7 GB fetched per launch at 64 clips).
+    constexpr int G = 8;
     int nl, rest;
     if (nt <= G) {
       nl = wg % nt;
@@ -957,7 +647,7 @@ __global__ __launch_bounds__(512) void gemm256ps_bf16_kernel(GemmParams p) {
   __builtin_amdgcn_s_barrier();                            \
   __builtin_amdgcn_sched_barrier(0)
 
-  // One k-tile out of LDS buffer BUF (phases and hazards: gemm256ph_bf16_kernel). ISSUE1: phase 1 prefetches A1 of the
+  // One k-tile out of LDS buffer BUF (phases and hazards: the comment above HALF_BYTES). ISSUE1: phase 1 prefetches A1 of the
   // stream's next k-tile = (ao1, kt1); ISSUE2: phases 2-4 prefetch W0, A0, W1 of the one after = (ao2 / wo2, kt2).
   auto ktile = [&](auto BUF, auto ISSUE1, auto ISSUE2, const unsigned (&ao1)[2][2], unsigned wo1, int kt1,
                    const unsigned (&ao2)[2][2], unsigned wo2, int kt2) {
@@ -1114,7 +804,7 @@ __global__ __launch_bounds__(512) void gemm256ps_bf16_kernel(GemmParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
-int gemm_force_tile = 0;  // 0: by tile count; 1: 128x128, 2: 256x128, 3: 256x256, 4: 256x256 phased, 5: 256x256 persistent stream (microbenchmarks)
+int gemm_force_tile = 0;  // 0: by tile count; 1: 128x128, 2: 256x128, 5: 256x256 stream per CU (tests and microbenchmarks)
 
 template <int EPI, bool SW>
 static void launch_one(GemmParams p, int n_begin, int n_end, hipStream_t s) {
@@ -1145,16 +835,6 @@ static void launch_one(GemmParams p, int n_begin, int n_end, hipStream_t s) {
       const int cus = n_cus.load(std::memory_order_relaxed);
       p.n_tiles = (n_end - n_begin) / BN3;
       hipLaunchKernelGGL((gemm256ps_bf16_kernel<EPI, SW>), dim3(tiles_sq < cus ? tiles_sq : cus), dim3(512), lds, s, p);
-      return;
-    }
-    if ((gemm_force_tile == 4 || (gemm_force_tile == 0 && sq_pays)) && nk >= 4 && nk % 2 == 0) {
-      p.n_tiles = (n_end - n_begin) / BN3;
-      hipLaunchKernelGGL((gemm256ph_bf16_kernel<EPI, SW>), dim3(tiles_sq), dim3(512), 2 * KT4_BYTES, s, p);
-      return;
-    }
-    if (gemm_force_tile == 3 || (gemm_force_tile == 0 && sq_pays)) {
-      p.n_tiles = (n_end - n_begin) / BN3;
-      hipLaunchKernelGGL((gemm256sq_bf16_kernel<EPI, SW>), dim3(tiles_sq), dim3(512), 2 * STAGE3_BYTES, s, p);
       return;
     }
   }

@@ -63,10 +63,11 @@ std::mutex& persistent_launch_mutex(int device);
 
 // Stream capture of a decoder step (hipStreamBeginCapture ... EndCapture) and the calls that may invalidate SOMEBODY ELSE's
 // capture on the same device (allocation, synchronous copies, device-wide synchronisation: engine construction, capacity
-// growth, StreamOpen, the stage-level entry points) take this mutex, one per device, whichever handle or build they belong
-// to: two handles on one GPU — whisper_srv --devices 0,0, or a bf16 and an fp16 model side by side — would otherwise break
-// each other's capture ("operation failed due to a previous error during capture"). Held for milliseconds, a few times
-// per handle lifetime. Defined once in api.cpp.
+// growth, StreamOpen, the stage-level entry points) take this mutex — ONE for the whole process (round 4; it was one per
+// device), whichever handle, device or build they belong to: two handles on one GPU — whisper_srv --devices 0,0, or a bf16
+// and an fp16 model side by side — would otherwise break each other's capture ("operation failed due to a previous error
+// during capture"), and whether handles on DIFFERENT GPUs can was never observable on a one-GPU box. Held for
+// milliseconds, a few times per handle lifetime (engine construction: for its whole duration). Defined once in api.cpp.
 std::recursive_mutex& device_capture_mutex(int device);
 
 IEngine* make_engine_bf16(const std::string& model_type, const std::string& model_path, const std::string& language, int device, int max_batch);

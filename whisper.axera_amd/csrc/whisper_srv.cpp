@@ -185,17 +185,27 @@ static void slot_scheduler(AX_WHISPER_HANDLE model, int n_slots, int wait_ms, in
       open = false;
       continue;
     }
-    for (int i = 0; i < nfin; ++i) {
+    bool collect_failed = false;
+    for (int i = 0; i < nfin && !collect_failed; ++i) {
       const int sl = fin[i];
       if (sl < 0 || sl >= n_slots || !owner[sl]) continue;
       int n = 0;
       char* text = nullptr;
-      const bool ok = AX_WHISPER_StreamCollect(model, sl, ids.data(), &n) == 0 && AX_WHISPER_Transcript(model, ids.data(), n, &text) == 0 && text;
+      if (AX_WHISPER_StreamCollect(model, sl, ids.data(), &n) != 0) { collect_failed = true; break; }
+      const bool ok = AX_WHISPER_Transcript(model, ids.data(), n, &text) == 0 && text;
       owner[sl]->done.set_value({ok, text ? std::string(text) : std::string()});
       free(text);
       owner[sl] = nullptr;
       --busy;
       ++g_served;
+    }
+    if (collect_failed) {
+      // the engine still holds that slot as finished-but-uncollected and would refuse every later admission into it: the
+      // stream is closed and reopened by the next requests, as after a failed step (the requests in flight fail)
+      for (int sl = 0; sl < n_slots; ++sl) if (owner[sl]) { fail(owner[sl]); owner[sl] = nullptr; }
+      busy = 0;
+      AX_WHISPER_StreamClose(model);
+      open = false;
     }
     report();
   }
