@@ -50,6 +50,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-batch64", action="store_true", help="N=1, batch 1 only: skip the batch-64 leg")
     ap.add_argument("--no-batch256", action="store_true", help="N=1, batch 1 only: skip the batch-256 leg (not a BASELINE config: what one GPU's HBM allows)")
     ap.add_argument("--no-turbo", action="store_true", help="N=1, batch 1 only: skip the turbo fp16 batch-16 leg (configs[3])")
+    ap.add_argument("--no-realistic", action="store_true",
+                    help="N=1, batch 1 only: skip the realistic-length legs (batch64_len100: 64 clips with budgets of 60-150 ids; stream64: 384 clips through 64 refilled slots)")
     ap.add_argument("--no-config0", action="store_true", help="N=1, batch 1 only: skip the tiny / demo.wav CPU-vs-GPU leg (configs[0])")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed region and its roofline: no host-PCM / forced-length / demo.wav / batch-64 / turbo / "
@@ -227,9 +229,17 @@ def ensure_model_dir(modelgen, model_dir, model, dims, dtype):
     return model_root, mdir
 
 
-def batch_leg(torch, dev, dev_index, sync, model, dtype, B, steps, max_new, model_dir, rooflines=True):
+def realistic_budgets(n, seed=20260104):
+    """Per-clip id budgets of the realistic-length legs: real 30 s utterances end after ~60-150 ids; synthetic weights never
+    emit eot, so every clip gets its own budget, drawn ONCE from U{60..150} (numpy PCG64, fixed seed: the same on every box)."""
+    import numpy as np
+
+    return [int(x) for x in np.random.Generator(np.random.PCG64(seed)).integers(60, 151, size=n)]
+
+
+def batch_leg(torch, dev, dev_index, sync, model, dtype, B, steps, max_new, model_dir, rooflines=True, budgets=None):
     """One more BASELINE config timed in the same run on the same GPU: B synthetic 30 s clips resident in HBM through
-    the whole hot path, `steps` timed passes after one warm-up pass."""
+    the whole hot path, `steps` timed passes after one warm-up pass. budgets: per-clip id budgets (a ragged batch)."""
     import numpy as np
 
     import modelgen
@@ -245,7 +255,7 @@ def batch_leg(torch, dev, dev_index, sync, model, dtype, B, steps, max_new, mode
     st = {"frontend_ms": 0.0, "encoder_ms": 0.0, "decode_ms": 0.0, "steps": 0}
 
     def step():
-        r = eng.run_device_tokens(d_pcm.data_ptr(), N_SAMP, [N_SAMP] * B, max_new=max_new)
+        r = eng.run_device_tokens(d_pcm.data_ptr(), N_SAMP, [N_SAMP] * B, max_new=max_new, max_new_clip=budgets)
         tm = eng.timings()
         for k in st:
             st[k] += tm[k]
@@ -255,6 +265,8 @@ def batch_leg(torch, dev, dev_index, sync, model, dtype, B, steps, max_new, mode
     for k in st:
         st[k] = 0
     dt, ids = timed_steps(step, steps, 0, sync, lambda: None)
+    if budgets is not None:
+        assert [len(r) for r in ids] == [min(b, max_new) if max_new > 0 else b for b in budgets]
     leg = {
         "value": round(B * steps / dt, 3), "unit": "clips/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2),
         "rtf": round(dt / steps / (B * 30.0), 7), "dtype": dtype,
@@ -267,6 +279,49 @@ def batch_leg(torch, dev, dev_index, sync, model, dtype, B, steps, max_new, mode
     eng.close()
     del d_pcm
     return leg, ids
+
+
+def stream_leg(torch, dev, dev_index, sync, model, dtype, n_slots, n_clips, model_dir):
+    """The serving path on the realistic-length workload: n_clips 30 s clips (host PCM, as requests arrive) through n_slots
+    utterance slots that are refilled while the others decode (AX_WHISPER_Stream*: one batched front-end + encoder pass per
+    group of freed slots, cross K/V scattered into the idle slots, per-slot decode offsets). Budgets as in the ragged batch
+    leg. Also: what an admission pass of k clips costs per clip (the encoder runs at a fraction of its batched rate on few
+    clips; at 60-150 ids per utterance it is 20-27 % of the GPU time of this workload)."""
+    import numpy as np
+
+    import modelgen
+    import whisper_axera_amd as wa
+
+    dims = modelgen.DIMS[model]
+    model_root, _ = ensure_model_dir(modelgen, model_dir, model, dims, dtype)
+    distinct = [modelgen.synth_clip(i, N_SAMP) for i in range(min(n_slots, 64))]
+    clips = [distinct[i % len(distinct)] for i in range(n_clips)]
+    budgets = realistic_budgets(n_clips, seed=20260105)
+    eng = wa.Whisper(model, model_root, "zh", device=dev_index, max_batch=n_slots)
+    res = {}
+    for min_admit in (1, 8):
+        eng.run_stream(clips[: 2 * n_slots], n_slots, max_new=budgets[: 2 * n_slots], min_admit=min_admit)  # warm: graphs, buffers
+        sync()
+        t0 = time.perf_counter()
+        got, calls = eng.run_stream(clips, n_slots, max_new=budgets, min_admit=min_admit)
+        dt = time.perf_counter() - t0
+        assert [len(g) for g in got] == budgets
+        res[f"min_admit_{min_admit}"] = {"clips_per_s": round(n_clips / dt, 2), "wall_s": round(dt, 4), "step_calls": calls}
+    enc_flop = {"tiny": 40.48e9, "small": 386.63e9, "turbo": 2313.09e9}.get(model)
+    groups = {}
+    for k in (1, 2, 4, 8, 16, 32, 64):
+        if k > n_slots:
+            break
+        ms = eng.bench("encoder", k, 0, 5) / 5
+        groups[str(k)] = {"ms": round(ms, 3), "ms_per_clip": round(ms / k, 4), "TFLOPs": round(enc_flop * k / (ms * 1e-3) / 1e12, 1) if enc_flop else None}
+    eng.close()
+    best = max(res.values(), key=lambda r: r["clips_per_s"])
+    return {"value": best["clips_per_s"], "unit": "clips/s", "dtype": dtype,
+            "config": {"workload": f"whisper-{model} {dtype}, {n_clips} 30 s synthetic clips (host PCM) through {n_slots} refilled slots, "
+                                   f"greedy decode, per-clip budgets U{{60..150}} ids (mean {float(np.mean(budgets)):.0f})"},
+            "by_admission_policy": res,
+            "what": "min_admit_k: an admission pass waits for k free slots while anything is still decoding (whisper_srv --min-admit)",
+            "encoder_pass_by_group_size": groups}
 
 
 def config0_leg(torch, dev, dev_index, sync, model_dir, n_ids=32):
@@ -631,6 +686,13 @@ def run_rank(args) -> int:
                 leg, ids2 = batch_leg(torch, dev, dev_index, sync, "small", dtype, 64, n2, args.max_new, args.model_dir)
                 leg["clip0_ids_equal_batch1"] = ids2[0] == ids[0]
                 out["batch64"] = leg
+            if not args.no_realistic and args.max_new == 0:
+                # realistic utterance lengths (SURVEY §8d asks for them beside the full context): every clip of the 64 leaves the
+                # loop at its own budget of 60-150 ids; then the same workload through the slot scheduler (384 clips, 64 slots)
+                leg, _ = batch_leg(torch, dev, dev_index, sync, "small", dtype, 64, n2, 0, args.model_dir, rooflines=False,
+                                   budgets=realistic_budgets(64))
+                out["batch64_len100"] = leg
+                out["stream64"] = stream_leg(torch, dev, dev_index, sync, "small", dtype, 64, 384, args.model_dir)
             if not args.no_batch256 and args.max_new == 0:
                 # not a BASELINE config: the same workload at the batch 288 GB of HBM invite (19 GB of K/V caches). A decoder
                 # step's chain of small GEMMs is paid once whatever the batch: 17.9 us per clip and step at 64, 13.1 at 256.
@@ -661,7 +723,7 @@ def run_rank(args) -> int:
 def main():
     args = parse_args()
     if args.no_extras:
-        args.no_batch64 = args.no_batch256 = args.no_turbo = args.no_config0 = args.no_cpu_baseline = True
+        args.no_batch64 = args.no_batch256 = args.no_turbo = args.no_config0 = args.no_cpu_baseline = args.no_realistic = True
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         return 2

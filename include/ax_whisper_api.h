@@ -88,6 +88,12 @@ AX_WHISPER_API int AX_WHISPER_RunPCMBatch(AX_WHISPER_HANDLE handle, const float*
 AX_WHISPER_API int AX_WHISPER_RunDeviceBatchTokens(AX_WHISPER_HANDLE handle, const float* d_pcm,
                                                    int stride, const int* num_samples, int batch,
                                                    int max_new, int32_t* ids, int* n_ids);
+/** The same with a per-clip id budget (host [batch], may be NULL; <= 0: none), each capped by max_new: a RAGGED batch in one
+ *  call — front-end, encoder and the loop — whose clips leave the loop at different steps the way real utterances reach eot
+ *  at different steps (bench.py's realistic-length leg: synthetic weights never emit eot by themselves). */
+AX_WHISPER_API int AX_WHISPER_RunDeviceBatchTokensRagged(AX_WHISPER_HANDLE handle, const float* d_pcm, int stride,
+                                                         const int* num_samples, int batch, int max_new,
+                                                         const int* max_new_clip, int32_t* ids, int* n_ids);
 /** ids -> bytes (base64 table of {type}-tokens.txt, Whisper.cpp:224-229); ids >= the table
  *  size are skipped. *result malloc'd. */
 AX_WHISPER_API int AX_WHISPER_Detokenize(AX_WHISPER_HANDLE handle, const int32_t* ids, int n, char** result);

@@ -48,11 +48,11 @@ def test_batched_teacher_forced_logits_vs_oracle(engine, micro_case, B):
     for b in check:
         err = np.abs(logits[b] - refs[b]).max(axis=1)
         print(f"B={B} clip {b}: logits err {err.max():.3e}")
-        assert err.max() < 2e-2
+        assert err.max() < 1e-3  # measured 1.1e-4 .. 2.3e-4 at every batch size
         srt = np.sort(refs[b], axis=1)
         margin = srt[:, -1] - srt[:, -2]
         for s in range(refs[b].shape[0]):
-            assert am[b, s] == int(refs[b][s].argmax()) or margin[s] < 2 * err[s]
+            assert am[b, s] == int(refs[b][s].argmax()) or margin[s] < 2 * err[s] + 1e-4
 
 
 def test_batched_and_single_paths_agree(engine):
@@ -142,15 +142,15 @@ def test_model_widths_batched_and_single_vs_oracle(built_lib, oracle_mod, tmp_pa
             for b in [c for c in check if c < batch]:
                 err = np.abs(logits[b] - refs[b]).max(axis=1)
                 print(f"{model_type} batch {batch} clip {b}: logits err {err.max():.3e}")
-                assert err.max() < 2e-2
+                assert err.max() < 4e-3  # measured: d = 512 6.3e-4, d = 1024 5.4e-4, d = 1280 1.0e-3
                 srt = np.sort(refs[b], axis=1)
                 for s in range(refs[b].shape[0]):
-                    assert am[b, s] == int(refs[b][s].argmax()) or srt[s, -1] - srt[s, -2] < 2 * err[s] + 1e-3
+                    assert am[b, s] == int(refs[b][s].argmax()) or srt[s, -1] - srt[s, -2] < 2 * err[s] + 1e-4
         e.encode_mel(mels[7])
         lg1, _ = e.decode_forced(1, forced[7:8])
         err1 = np.abs(lg1[0] - refs[7]).max()
         print(f"{model_type} single clip: logits err {err1:.3e}")
-        assert err1 < 2e-2
+        assert err1 < 3e-3  # measured 4.0e-4 .. 6.7e-4
     finally:
         e.close()
 

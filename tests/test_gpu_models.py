@@ -27,17 +27,21 @@ def test_model_vs_oracle_and_transformers(built_lib, oracle_mod, tmp_path, model
     k, v = e.get_cross_kv(0)
     kb, vb = case.oracle_bf16.encoder(mel)
     print(model_type, "cross kv err vs bf16 policy", np.abs(k - kb).max(), np.abs(v - vb).max())
-    assert np.abs(k - kb).max() < 4e-2 and np.abs(v - vb).max() < 4e-2
-    assert np.abs(k[:, ::53, ::7] - g["cross_k_sub"]).max() < 8e-2  # HF fp32 golden
+    assert np.abs(k - kb).max() < 2e-2 and np.abs(v - vb).max() < 2e-2  # measured: exactly one bf16 ulp at |x| ~ 2 (1.56e-2)
+    e_hf = np.abs(k[:, ::53, ::7] - g["cross_k_sub"]).max()
+    print(model_type, "cross k err vs transformers golden (fp32)", e_hf)
+    assert e_hf < 3e-2  # HF fp32 golden: half a bf16 ulp of storage (7.8e-3 at |x| ~ 2, 1.6e-2 at ~ 4) + the arithmetic
     n_new = int(g["n_new"])
     hf_ids = [int(x) for x in g["ids"][:n_new]]
     logits, am = e.decode_forced(1, np.array([hf_ids]))
     top = np.take_along_axis(logits[0], g["top_ids"][: n_new + 1], axis=1)
     err = np.abs(top - g["top_vals"][: n_new + 1]).max()
     print(model_type, "logits err vs transformers golden", err)
-    assert err < 6e-2
+    assert err < 5e-3  # measured 6.3e-4 (tiny) .. 1.1e-3 (small)
     ids_o, lg_o = case.oracle_bf16.greedy(kb, vb, lang, max_new=n_new, forced=hf_ids, want_logits=True)
-    assert np.abs(logits[0] - lg_o).max() < 2.5e-2
+    e_o = np.abs(logits[0] - lg_o).max()
+    print(model_type, "logits err vs bf16-policy oracle", e_o)
+    assert e_o < 6e-3  # measured 1.8e-3 at Whisper-small dims, less below
     e.close()
 
 
@@ -76,7 +80,7 @@ def test_turbo_shaped_model(built_lib, oracle_mod, tmp_path):
     logits, am = e.decode_forced(1, np.array([ids]))
     err = np.abs(logits[0] - lg).max()
     print("miniturbo logits err", err)
-    assert err < 2e-2
+    assert err < 1.2e-3  # measured 2.4e-4
     assert_ids_equal_or_tie(e, mel, got, ids, lg, "miniturbo")
     import modelgen
 

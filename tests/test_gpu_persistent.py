@@ -58,7 +58,7 @@ def test_persistent_equals_graph_path_and_oracle(built_lib, oracle_mod, tmp_path
             e_paths = float(np.abs(lp[0, :n] - lgp[0, :n]).max())
             e_ref = float(np.abs(lp[0, :n] - ref_lg).max())
             print(model_type, "logits: persistent vs graph", e_paths, "persistent vs oracle", e_ref)
-            assert e_paths < 2e-3 and e_ref < 2e-2
+            assert e_paths < 3e-4 and e_ref < 3e-3  # measured 4.3e-5 .. 5.6e-5 and 3.1e-4 .. 7.4e-4
             assert np.array_equal(ap, ag)
             top2 = np.sort(ref_lg, axis=1)[:, -2:]
             margin = float((top2[:, 1] - top2[:, 0]).min())

@@ -42,6 +42,7 @@ SYMBOLS = {
     "AX_WHISPER_RunPCMBatchTokens": (C.c_int, [C.c_void_p, C.POINTER(fp), C.POINTER(C.c_int), C.c_int, C.c_int, ip, C.POINTER(C.c_int)]),
     "AX_WHISPER_RunPCMBatch": (C.c_int, [C.c_void_p, C.POINTER(fp), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "AX_WHISPER_RunDeviceBatchTokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, ip, C.POINTER(C.c_int)]),
+    "AX_WHISPER_RunDeviceBatchTokensRagged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int), ip, C.POINTER(C.c_int)]),
     "AX_WHISPER_Detokenize": (C.c_int, [C.c_void_p, ip, C.c_int, C.POINTER(C.c_void_p)]),
     "AX_WHISPER_Transcript": (C.c_int, [C.c_void_p, ip, C.c_int, C.POINTER(C.c_void_p)]),
     "AX_WHISPER_ConvertT2S": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -178,12 +179,16 @@ class Whisper:
         self._check(self.L.AX_WHISPER_RunPCMBatch(self.h, ptrs, lens, B, outs), "RunPCMBatch")
         return [self._take(outs[b]) for b in range(B)]
 
-    def run_device_tokens(self, d_ptr: int, stride: int, n_samples, max_new: int = 0):
-        """d_ptr: device address of [B][stride] f32 PCM already resident in HBM."""
+    def run_device_tokens(self, d_ptr: int, stride: int, n_samples, max_new: int = 0, max_new_clip=None):
+        """d_ptr: device address of [B][stride] f32 PCM already resident in HBM; max_new_clip: per-clip id budgets."""
         B = len(n_samples)
         lens = (C.c_int * B)(*[int(x) for x in n_samples])
         ids = np.zeros((B, self.n_text_ctx), dtype=np.int32)
         n = (C.c_int * B)()
+        if max_new_clip is not None:
+            mc = (C.c_int * B)(*[int(x) for x in max_new_clip])
+            self._check(self.L.AX_WHISPER_RunDeviceBatchTokensRagged(self.h, C.c_void_p(d_ptr), stride, lens, B, max_new, mc, ids.ctypes.data_as(ip), n), "RunDeviceBatchTokensRagged")
+            return [ids[b, : n[b]].tolist() for b in range(B)]
         self._check(self.L.AX_WHISPER_RunDeviceBatchTokens(self.h, C.c_void_p(d_ptr), stride, lens, B, max_new, ids.ctypes.data_as(ip), n), "RunDeviceBatchTokens")
         return [ids[b, : n[b]].tolist() for b in range(B)]
 

@@ -244,6 +244,13 @@ AX_WHISPER_API int AX_WHISPER_RunDeviceBatchTokens(AX_WHISPER_HANDLE handle, con
   return guarded(handle, [&](Engine& e) { e.run_tokens(nullptr, d_pcm, stride, num_samples, batch, max_new, ids, n_ids); });
 }
 
+AX_WHISPER_API int AX_WHISPER_RunDeviceBatchTokensRagged(AX_WHISPER_HANDLE handle, const float* d_pcm, int stride,
+                                                         const int* num_samples, int batch, int max_new,
+                                                         const int* max_new_clip, int32_t* ids, int* n_ids) {
+  if (!handle || !d_pcm || !num_samples || !ids || !n_ids || batch < 1) return -1;
+  return guarded(handle, [&](Engine& e) { e.run_tokens(nullptr, d_pcm, stride, num_samples, batch, max_new, ids, n_ids, max_new_clip); });
+}
+
 AX_WHISPER_API int AX_WHISPER_RunPCMBatch(AX_WHISPER_HANDLE handle, const float* const* pcm, const int* num_samples, int batch,
                                           char** results) {
   if (!handle || !pcm || !num_samples || !results || batch < 1) return -1;

@@ -1285,7 +1285,7 @@ void Engine::fetch_ids(int batch, int32_t* ids, int* n_ids) {
 
 // ------------------------------------------------------------------------------ public entry points
 void Engine::run_tokens(const float* const* pcm, const float* d_pcm, int d_stride, const int* n_samples, int batch, int max_new,
-                        int32_t* ids, int* n_ids) {
+                        int32_t* ids, int* n_ids, const int* max_new_clip) {
   if (batch < 1) throw std::runtime_error("batch must be >= 1");
   require_no_stream("run_tokens");
   HIP_CHECK(hipSetDevice(device_));
@@ -1302,7 +1302,7 @@ void Engine::run_tokens(const float* const* pcm, const float* d_pcm, int d_strid
   HIP_CHECK(hipEventRecord(ev_[1], s));
   run_encoder(batch);
   HIP_CHECK(hipEventRecord(ev_[2], s));
-  const int steps = greedy_loop(batch, max_new);
+  const int steps = greedy_loop(batch, max_new, max_new_clip);
   fetch_ids(batch, ids, n_ids);
   // stage timings (events 3/4 are reused by the poll; bracket decode with a fresh record)
   HIP_CHECK(hipEventRecord(ev_[3], s));

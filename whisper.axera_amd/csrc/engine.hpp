@@ -27,7 +27,7 @@ class Engine final : public IEngine {
   Engine(const Engine&) = delete;
 
   void run_tokens(const float* const* pcm, const float* d_pcm, int d_stride, const int* n_samples, int batch, int max_new,
-                  int32_t* ids, int* n_ids) override;
+                  int32_t* ids, int* n_ids, const int* max_new_clip = nullptr) override;
   std::string detokenize(const int32_t* ids, int n) const override;
   std::string transcript(const int32_t* ids, int n) const override;
   bool has_t2s() const { return (bool)t2s_; }

@@ -26,8 +26,9 @@ class IEngine {
  public:
   virtual ~IEngine() {}
   // full path, host PCM or device PCM; ids [batch][n_text_ctx], n_ids [batch]
+  // max_new_clip: optional host [batch] per-clip id budgets (<= 0: none), each capped by max_new
   virtual void run_tokens(const float* const* pcm, const float* d_pcm, int d_stride, const int* n_samples, int batch, int max_new,
-                          int32_t* ids, int* n_ids) = 0;
+                          int32_t* ids, int* n_ids, const int* max_new_clip = nullptr) = 0;
   virtual std::string detokenize(const int32_t* ids, int n) const = 0;
   // detokenize + the reference's zh post-pass (Traditional -> Simplified, Whisper.cpp:231-236) when its OpenCC data files were found
   virtual std::string transcript(const int32_t* ids, int n) const = 0;
