@@ -65,16 +65,21 @@ __device__ __forceinline__ uint4 ld_kv(const h16* base, long off) {
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
-template <bool FUSE_Q>
+// STAMP (measurement builds of the kernel only): thread 0 of every workgroup folds its start and end time into the launch's
+// {min begin, max end} pair, so that a decoder step's attention launches can be placed on one time axis while two graph
+// branches run them side by side (a profiler serialises the branches; hipEvents see only whole replays).
+template <bool FUSE_Q, bool STAMP = false>
 __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, int cap_blocks) {
   __shared__ float s_part[4][kPartStride];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the block loop below is wave-uniform control flow
   const int split = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  if constexpr (STAMP) { if (tid == 0) atomicMin(p.stamp, (unsigned long long)wall_clock64()); }
+  auto stamp_end = [&] { if constexpr (STAMP) { if (tid == 0) atomicMax(p.stamp + 1, (unsigned long long)wall_clock64()); } };
   // A clip that has reached its eot keeps its slot in the batch but streams no K/V any more (the reference stops each
   // utterance at its own eot, Whisper.cpp:219-222). Its stale attention output feeds linear layers whose results
   // nobody reads: rows of different clips never mix, and advance_kernel re-seeds x[b] from the embedding every step.
-  if (p.done && p.done[b]) return;
+  if (p.done && p.done[b]) { stamp_end(); return; }
   const int bps = (cap_blocks + p.n_split - 1) / p.n_split;
   const int blk_begin = split * bps, blk_cap_end = min(cap_blocks, blk_begin + bps);
 
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
       }
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
       ticket = __builtin_amdgcn_readfirstlane(ticket);
-      if (ticket != (unsigned)p.n_split - 1u) return;  // (the whole wave; the other waves are past their last use of LDS)
+      if (ticket != (unsigned)p.n_split - 1u) { stamp_end(); return; }  // (the whole wave; the other waves are past their last use of LDS)
       float M = -INFINITY, Ls = 0.f, O = 0.f;
       for (int s2 = 0; s2 < p.n_split; ++s2) {
         float m2 = m, l2 = l, o2 = ov;
@@ -326,15 +331,18 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
       if (tid == 0) { out[0] = m; out[1] = l; }
       out[2 + tid] = ov;
     }
+    stamp_end();  // thread 0 sits in the wave that writes the output: the last thing a workgroup does
   }
 }
 
 void launch_decode_attention(const DecAttnParams& p, hipStream_t s) {
   if (p.wq) {
     if (p.d_model > 1024 || p.d_model % 32 != 0 || (p.n_split != 1 && !(p.out_hi && p.mpart && p.mcnt))) { fprintf(stderr, "[ax_whisper] fused query projection: d_model %d, n_split %d unsupported\n", p.d_model, p.n_split); abort(); }
-    hipLaunchKernelGGL(decode_attention_kernel<true>, dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);
+    if (p.stamp) hipLaunchKernelGGL((decode_attention_kernel<true, true>), dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);
+    else hipLaunchKernelGGL((decode_attention_kernel<true>), dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);
   } else {
-    hipLaunchKernelGGL(decode_attention_kernel<false>, dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);
+    if (p.stamp) hipLaunchKernelGGL((decode_attention_kernel<false, true>), dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);
+    else hipLaunchKernelGGL((decode_attention_kernel<false>), dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);
   }
 }
 

@@ -855,6 +855,14 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
   if (step_mask_ & 4) launch_advance(a, s);
 }
 
+// bench "attn_stamp" (step_mask_ bit 16): the next {min begin, max end} slot, with what the launch is
+unsigned long long* Engine::next_stamp(int layer, int cross, int b0, int nb) {
+  if (!(step_mask_ & 16) || !d_stamp_) return nullptr;
+  if (stamp_meta_.size() >= 512) return nullptr;
+  stamp_meta_.push_back({layer, cross, b0, nb});
+  return d_stamp_ + 2 * (stamp_meta_.size() - 1);
+}
+
 // Decoder layers of clips [b0, b0 + nb) as clip-block GEMMs (decode_cgemm_kernel): LayerNorm is the prologue of its
 // consumer and the residual add the epilogue of its producer, so a layer is 7 launches instead of 11
 // (AX_WHISPER_BATCHED_LN=0: the older sequence with a separate LayerNorm/h16-pair preparation launch and split-K
@@ -910,7 +918,7 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
     c.x = x; c.ln_w = w.attn_ln_w; c.ln_b = w.attn_ln_b;
     c.out = qd; c.k_cache = sk; c.v_cache = sv; c.kv_batch_stride = self_stride;
     cgo(c);
-    if (step_mask_ & 2) launch_decode_attention(attn(sk, sv, self_stride, -1, Tc / 64), s);
+    if (step_mask_ & 2) { DecAttnParams a = attn(sk, sv, self_stride, -1, Tc / 64); a.stamp = next_stamp(l, 0, b0, nb); launch_decode_attention(a, s); }
     c = cgemm(wq.w_o, w.b_o, d, d, GEPI_RESID, 1);
     c.a_hi = att_hi; c.a_lo = att_lo; c.out = x;
     cgo(c);
@@ -922,12 +930,13 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
       a.mcnt = d_attn_mcnt_ + (long)b0 * H;
       a.strict_ticket = strict_ticket();
       a.x = x; a.ln_w = w.cross_ln_w; a.ln_b = w.cross_ln_b; a.wq = w.w_cq; a.bq = w.b_cq;
+      a.stamp = next_stamp(l, 1, b0, nb);
       if (step_mask_ & 2) launch_decode_attention(a, s);
     } else {
       c = cgemm(wq.w_cq, w.b_cq, d, d, GEPI_STORE, 1);
       c.x = x; c.ln_w = w.cross_ln_w; c.ln_b = w.cross_ln_b; c.out = qd;
       cgo(c);
-      if (step_mask_ & 2) launch_decode_attention(attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64), s);
+      if (step_mask_ & 2) { DecAttnParams a = attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64); a.stamp = next_stamp(l, 1, b0, nb); launch_decode_attention(a, s); }
     }
     c = cgemm(wq.w_co, w.b_co, d, d, GEPI_RESID, 1);
     c.a_hi = att_hi; c.a_lo = att_lo; c.out = x;
@@ -1010,6 +1019,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     pend_n = p.ksplit;
     pend_bias = bias;
   };
+  int stamp_layer = 0;
   auto attn = [&](const h16* kc, const h16* vc, long stride, int n_keys, int cap_blocks) {
     DecAttnParams a{};
     a.q = d_qdec_; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = nullptr; a.n_split = 1;
@@ -1027,6 +1037,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
       a.mcnt = d_attn_mcnt_;
       a.strict_ticket = strict_ticket();
     }
+    a.stamp = next_stamp(stamp_layer, n_keys >= 0 ? 1 : 0, 0, batch);
     if (step_mask_ & 2) launch_decode_attention(a, s);
   };
   auto base = [&](const h16* W, const float* bias, int N, int K, const h16* ahi, const h16* alo, int epi) {
@@ -1061,6 +1072,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     }
   }
   for (int l = 0; l < L && !batched_ln_; ++l) {
+    stamp_layer = l;
     const DecLayerW& w = dec_[l];
     h16* sk = d_self_k_ + (size_t)l * cap_ * self_stride;
     h16* sv = d_self_v_ + (size_t)l * cap_ * self_stride;
@@ -1149,7 +1161,7 @@ void Engine::recover_streams() {
 }
 
 hipGraphExec_t Engine::step_graph(int batch, int max_new) {
-  const long key = ((long)batch * 1024 + max_new) * 16 + step_mask_;
+  const long key = ((long)batch * 1024 + max_new) * 32 + step_mask_;
   auto it = graphs_.find(key);
   if (it != graphs_.end()) return it->second;
   hipStream_t s = stream();
@@ -1631,6 +1643,75 @@ float Engine::bench(const std::string& what, int batch, int arg, int iters) {
     HIP_CHECK(hipEventRecord(a, s));
     for (int i = 0; i < iters; ++i) HIP_CHECK(hipGraphLaunch(g, s));
     HIP_CHECK(hipEventRecord(b, s));
+  } else if (what == "attn_stamp") {
+    // One replay of the production step graph (all launches, every branch) at decode offset `arg` whose decode_attention
+    // launches stamp their own {first workgroup start, last workgroup end}; the table goes to $AX_WHISPER_ATTN_STAMP
+    // (default attn_stamps.csv). Returns the length of the UNION of the attention intervals in ms: K/V bytes of the step
+    // over that time is the rate the attention launches achieve while the other branch's launches run beside them.
+    if (batch <= gemv_max_) throw std::runtime_error("bench attn_stamp: the batched decode sequences only (3+ clips)");
+    if (!d_stamp_) { d_stamp_ = (unsigned long long*)dalloc(2 * 512 * 8, true); allocs_.push_back(d_stamp_); }
+    step_mask_ = 15 | 16;
+    struct Restore { int& m; ~Restore() { m = 15; } } restore{step_mask_};
+    const int Tc = cfg_.n_text_ctx;
+    reset_decode_state(batch);
+    const long key = ((long)batch * 1024 + (Tc - 4)) * 32 + step_mask_;
+    auto old = graphs_.find(key);
+    if (old != graphs_.end()) { (void)hipGraphExecDestroy(old->second); graphs_.erase(old); }
+    stamp_meta_.clear();
+    hipGraphExec_t g = step_graph(batch, Tc - 4);
+    arg = std::max(0, std::min(arg, Tc - 3));
+    DecState st{arg, 0, 0, 0};
+    std::vector<int> offs(batch, arg);
+    std::vector<unsigned long long> init(2 * 512);
+    for (size_t i = 0; i < init.size(); ++i) init[i] = (i & 1) ? 0ull : ~0ull;
+    std::vector<unsigned long long> got(2 * 512);
+    std::vector<std::pair<double, double>> iv;
+    double best_union = 0.0;
+    std::string table;
+    for (int rep = 0; rep < std::max(2, iters); ++rep) {  // the first replay warms the caches; the last one is reported
+      HIP_CHECK(hipMemcpy(d_state_, &st, sizeof(st), hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(d_off_, offs.data(), (size_t)batch * 4, hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(d_stamp_, init.data(), init.size() * 8, hipMemcpyHostToDevice));
+      HIP_CHECK(hipEventRecord(a, s));
+      HIP_CHECK(hipGraphLaunch(g, s));
+      HIP_CHECK(hipEventRecord(b, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      HIP_CHECK(hipMemcpy(got.data(), d_stamp_, got.size() * 8, hipMemcpyDeviceToHost));
+    }
+    float step_ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&step_ms, a, b));
+    unsigned long long t0 = ~0ull;
+    for (size_t i = 0; i < stamp_meta_.size(); ++i) t0 = std::min(t0, got[2 * i]);
+    const double keys_self = arg + 1, d_ = cfg_.n_text_state;
+    char line[256];
+    snprintf(line, sizeof line, "# batch %d, decode offset %d, %zu attention launches, whole step %.3f us (hipEvents); times in us from the first start (100 MHz wall clock)\n",
+             batch, arg, stamp_meta_.size(), step_ms * 1e3);
+    table += line;
+    table += "launch,kind,layer,first_clip,clips,begin_us,end_us,duration_us,kv_bytes,GBs\n";
+    for (size_t i = 0; i < stamp_meta_.size(); ++i) {
+      const StampMeta& m = stamp_meta_[i];
+      const double bg = (double)(got[2 * i] - t0) * 0.01, en = (double)(got[2 * i + 1] - t0) * 0.01;
+      const double bytes = (double)m.nb * 2.0 * 2.0 * d_ * (m.cross ? (double)cfg_.n_audio_ctx : keys_self);
+      iv.push_back({bg, en});
+      snprintf(line, sizeof line, "%zu,%s,%d,%d,%d,%.2f,%.2f,%.2f,%.0f,%.1f\n", i, m.cross ? "cross" : "self", m.layer, m.b0, m.nb, bg, en, en - bg, bytes,
+               en > bg ? bytes / ((en - bg) * 1e-6) / 1e9 : 0.0);
+      table += line;
+    }
+    std::sort(iv.begin(), iv.end());
+    double cur_b = -1, cur_e = -1;
+    for (auto& x : iv) {
+      if (x.first > cur_e) { best_union += cur_e - cur_b; cur_b = x.first; cur_e = x.second; }
+      else cur_e = std::max(cur_e, x.second);
+    }
+    best_union += cur_e - cur_b;
+    snprintf(line, sizeof line, "# union of the attention intervals: %.2f us\n", best_union);
+    table += line;
+    const char* path = getenv("AX_WHISPER_ATTN_STAMP");
+    if (FILE* f = fopen(path ? path : "attn_stamps.csv", "w")) { fputs(table.c_str(), f); fclose(f); }
+    { auto it = graphs_.find(key); if (it != graphs_.end()) { (void)hipGraphExecDestroy(it->second); graphs_.erase(it); } }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return (float)(best_union * 1e-3);
   } else if (what == "encoder") {
     run_encoder(batch);
     HIP_CHECK(hipEventRecord(a, s));

@@ -168,7 +168,12 @@ class Engine final : public IEngine {
   DecState* d_state_ = nullptr;
   int* h_poll_ = nullptr;  // pinned
   int split_self_ = 2, split_cross_ = 6;
-  int step_mask_ = 15;  // bench only: 1 GEMV/GEMM launches, 2 attention launches, 4 advance, 8 act_prep
+  int step_mask_ = 15;  // bench only: 1 GEMV/GEMM launches, 2 attention launches, 4 advance, 8 act_prep, 16 attention launches stamp themselves
+  // bench "attn_stamp": every decode_attention launch of a captured step gets a {min begin, max end} slot (DecAttnParams::stamp)
+  struct StampMeta { int layer, cross, b0, nb; };
+  unsigned long long* d_stamp_ = nullptr;
+  std::vector<StampMeta> stamp_meta_;
+  unsigned long long* next_stamp(int layer, int cross, int b0, int nb);
   // persistent batch-1 decode
   bool batched_ln_ = false;         // batched decode: clip-block GEMM sequence (AX_WHISPER_BATCHED_LN=0 disables)
   bool persistent_ok_ = false;      // model shape supported and not disabled (AX_WHISPER_DECODE=graph)
