@@ -16,10 +16,12 @@ import modelgen  # noqa: E402
 import whisper_axera_amd as wa  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-mdir = os.environ.get("AXW_BENCH_MODEL_DIR", "/tmp/axw_bench_models")
-if not os.path.exists(os.path.join(mdir, "small", "small.safetensors")):
-    modelgen.write_model_dir(mdir, "small", seed=0)
-e = wa.Whisper("small", mdir, "zh", device=0, max_batch=B)
+model = sys.argv[2] if len(sys.argv) > 2 else "small"          # round 4: pmc_driver.py 16 turbo fp16 / 256 small
+fp16 = len(sys.argv) > 3 and sys.argv[3] == "fp16"
+mdir = os.environ.get("AXW_BENCH_MODEL_DIR", "/tmp/axw_bench_models") + ("_f16" if fp16 else "")
+if not os.path.exists(os.path.join(mdir, model, model + ".safetensors")):
+    modelgen.write_model_dir(mdir, model, seed=0, dtype="F16" if fp16 else "BF16")
+e = wa.Whisper(model, mdir, "zh", device=0, max_batch=B)
 e.bench("encoder", B, 0, 1)
 e.bench("decode_step", B, 224, 4)
 if B == 1:  # the persistent batch-1 decode launch: one whole utterance (448 steps) = one launch

@@ -329,8 +329,9 @@ struct DecAttnParams {
   // fused query projection (batched cross-attention): q = Wq[head rows] . LayerNorm(x[b]) + bq computed by the
   // (clip, head) workgroup itself while its first K/V block is in flight; wq == nullptr: q is read from `q`
   const float* x; const float* ln_w; const float* ln_b; const h16* wq; const float* bq;
-  // measurement only (Engine::bench "attn_stamp"): {min begin, max end} of this launch's workgroups in 100 MHz wall-clock
-  // ticks, written by the kernel itself (a separate template instantiation: the production kernel carries no stamp code)
+  // measurement only (Engine::bench "attn_stamp"): [workgroups][2] = {begin, end} of every workgroup of this launch in
+  // 100 MHz wall-clock ticks, written by the kernel itself (a separate template instantiation: the production kernel
+  // carries no stamp code)
   unsigned long long* stamp;
 };
 void launch_decode_attention(const DecAttnParams& p, hipStream_t s);

@@ -65,8 +65,7 @@ __device__ __forceinline__ uint4 ld_kv(const h16* base, long off) {
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
-// STAMP (measurement builds of the kernel only): thread 0 of every workgroup folds its start and end time into the launch's
-// {min begin, max end} pair, so that a decoder step's attention launches can be placed on one time axis while two graph
+// STAMP (measurement builds of the kernel only): thread 0 of every workgroup records its start and end time, so that a decoder step's attention launches can be placed on one time axis while two graph
 // branches run them side by side (a profiler serialises the branches; hipEvents see only whole replays).
 template <bool FUSE_Q, bool STAMP = false>
 __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, int cap_blocks) {
@@ -74,8 +73,14 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the block loop below is wave-uniform control flow
   const int split = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-  if constexpr (STAMP) { if (tid == 0) atomicMin(p.stamp, (unsigned long long)wall_clock64()); }
-  auto stamp_end = [&] { if constexpr (STAMP) { if (tid == 0) atomicMax(p.stamp + 1, (unsigned long long)wall_clock64()); } };
+  // (one {begin, end} pair per WORKGROUP, plain stores; the host takes the minimum and the maximum: 768 atomics on one
+  // address per launch cost ~6 us per launch and moved the branches apart)
+  unsigned long long* my_stamp = nullptr;
+  if constexpr (STAMP) {
+    my_stamp = p.stamp + 2 * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    if (tid == 0) my_stamp[0] = (unsigned long long)wall_clock64();
+  }
+  auto stamp_end = [&] { if constexpr (STAMP) { if (tid == 0) my_stamp[1] = (unsigned long long)wall_clock64(); } };
   // A clip that has reached its eot keeps its slot in the batch but streams no K/V any more (the reference stops each
   // utterance at its own eot, Whisper.cpp:219-222). Its stale attention output feeds linear layers whose results
   // nobody reads: rows of different clips never mix, and advance_kernel re-seeds x[b] from the embedding every step.

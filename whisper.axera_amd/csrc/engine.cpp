@@ -858,9 +858,9 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
 // bench "attn_stamp" (step_mask_ bit 16): the next {min begin, max end} slot, with what the launch is
 unsigned long long* Engine::next_stamp(int layer, int cross, int b0, int nb) {
   if (!(step_mask_ & 16) || !d_stamp_) return nullptr;
-  if (stamp_meta_.size() >= 512) return nullptr;
+  if (stamp_meta_.size() >= kStampLaunches) return nullptr;
   stamp_meta_.push_back({layer, cross, b0, nb});
-  return d_stamp_ + 2 * (stamp_meta_.size() - 1);
+  return d_stamp_ + 2 * kStampWgs * (stamp_meta_.size() - 1);  // room for kStampWgs workgroups per launch
 }
 
 // Decoder layers of clips [b0, b0 + nb) as clip-block GEMMs (decode_cgemm_kernel): LayerNorm is the prologue of its
@@ -1649,7 +1649,9 @@ float Engine::bench(const std::string& what, int batch, int arg, int iters) {
     // (default attn_stamps.csv). Returns the length of the UNION of the attention intervals in ms: K/V bytes of the step
     // over that time is the rate the attention launches achieve while the other branch's launches run beside them.
     if (batch <= gemv_max_) throw std::runtime_error("bench attn_stamp: the batched decode sequences only (3+ clips)");
-    if (!d_stamp_) { d_stamp_ = (unsigned long long*)dalloc(2 * 512 * 8, true); allocs_.push_back(d_stamp_); }
+    // (a launch has batch * heads workgroups, or up to 640 when few (clip, head) pairs are split along the keys)
+    if (std::max<long>((long)batch * cfg_.n_text_head, 640) > (long)kStampWgs) throw std::runtime_error("bench attn_stamp: too many workgroups per launch");
+    if (!d_stamp_) { d_stamp_ = (unsigned long long*)dalloc((size_t)2 * kStampWgs * kStampLaunches * 8, true); allocs_.push_back(d_stamp_); }
     step_mask_ = 15 | 16;
     struct Restore { int& m; ~Restore() { m = 15; } } restore{step_mask_};
     const int Tc = cfg_.n_text_ctx;
@@ -1659,24 +1661,39 @@ float Engine::bench(const std::string& what, int batch, int arg, int iters) {
     if (old != graphs_.end()) { (void)hipGraphExecDestroy(old->second); graphs_.erase(old); }
     stamp_meta_.clear();
     hipGraphExec_t g = step_graph(batch, Tc - 4);
-    arg = std::max(0, std::min(arg, Tc - 3));
+    const int warm_replays = iters >= 100 ? iters - 100 : 0;
+    arg = std::max(0, std::min(arg, Tc - 4 - warm_replays));  // every replay advances the clips by one position
     DecState st{arg, 0, 0, 0};
     std::vector<int> offs(batch, arg);
-    std::vector<unsigned long long> init(2 * 512);
-    for (size_t i = 0; i < init.size(); ++i) init[i] = (i & 1) ? 0ull : ~0ull;
-    std::vector<unsigned long long> got(2 * 512);
+    const size_t n_words = (size_t)2 * kStampWgs * kStampLaunches;
+    std::vector<unsigned long long> raw(n_words), got(2 * kStampLaunches);
     std::vector<std::pair<double, double>> iv;
     double best_union = 0.0;
     std::string table;
-    for (int rep = 0; rep < std::max(2, iters); ++rep) {  // the first replay warms the caches; the last one is reported
+    for (int rep = 0; rep < 3; ++rep) {  // the first repetitions warm the caches; the last one is reported
       HIP_CHECK(hipMemcpy(d_state_, &st, sizeof(st), hipMemcpyHostToDevice));
       HIP_CHECK(hipMemcpy(d_off_, offs.data(), (size_t)batch * 4, hipMemcpyHostToDevice));
-      HIP_CHECK(hipMemcpy(d_stamp_, init.data(), init.size() * 8, hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemset(d_stamp_, 0, n_words * 8));
+      HIP_CHECK(hipDeviceSynchronize());
       HIP_CHECK(hipEventRecord(a, s));
+      // arg2 (iters >= 100): `iters - 100` replays back to back BEFORE the stamped one, so that the stamped step starts the way
+      // a step of the loop does — behind its predecessor, both branches already queued (a lone replay's second branch starts
+      // ~250 us late: the host is still enqueuing its nodes)
+      for (int k = 0; k < warm_replays; ++k) HIP_CHECK(hipGraphLaunch(g, s));
       HIP_CHECK(hipGraphLaunch(g, s));
       HIP_CHECK(hipEventRecord(b, s));
       HIP_CHECK(hipStreamSynchronize(s));
-      HIP_CHECK(hipMemcpy(got.data(), d_stamp_, got.size() * 8, hipMemcpyDeviceToHost));
+      HIP_CHECK(hipMemcpy(raw.data(), d_stamp_, n_words * 8, hipMemcpyDeviceToHost));
+    }
+    for (size_t i = 0; i < stamp_meta_.size(); ++i) {  // a launch = the earliest start and the latest end of its workgroups
+      unsigned long long lo = ~0ull, hi = 0ull;
+      for (size_t w = 0; w < kStampWgs; ++w) {
+        const unsigned long long bg = raw[(i * kStampWgs + w) * 2], en = raw[(i * kStampWgs + w) * 2 + 1];
+        if (bg) lo = std::min(lo, bg);
+        hi = std::max(hi, en);
+      }
+      got[2 * i] = lo;
+      got[2 * i + 1] = hi;
     }
     float step_ms = 0.f;
     HIP_CHECK(hipEventElapsedTime(&step_ms, a, b));
@@ -1684,8 +1701,8 @@ float Engine::bench(const std::string& what, int batch, int arg, int iters) {
     for (size_t i = 0; i < stamp_meta_.size(); ++i) t0 = std::min(t0, got[2 * i]);
     const double keys_self = arg + 1, d_ = cfg_.n_text_state;
     char line[256];
-    snprintf(line, sizeof line, "# batch %d, decode offset %d, %zu attention launches, whole step %.3f us (hipEvents); times in us from the first start (100 MHz wall clock)\n",
-             batch, arg, stamp_meta_.size(), step_ms * 1e3);
+    snprintf(line, sizeof line, "# batch %d, decode offset %d, %zu attention launches, %d replays back to back before the stamped one (all %d: %.3f us, hipEvents); times in us from the stamped step's first attention start (100 MHz wall clock)\n",
+             batch, arg, stamp_meta_.size(), warm_replays, warm_replays + 1, step_ms * 1e3);
     table += line;
     table += "launch,kind,layer,first_clip,clips,begin_us,end_us,duration_us,kv_bytes,GBs\n";
     for (size_t i = 0; i < stamp_meta_.size(); ++i) {

@@ -171,6 +171,7 @@ class Engine final : public IEngine {
   int step_mask_ = 15;  // bench only: 1 GEMV/GEMM launches, 2 attention launches, 4 advance, 8 act_prep, 16 attention launches stamp themselves
   // bench "attn_stamp": every decode_attention launch of a captured step gets a {min begin, max end} slot (DecAttnParams::stamp)
   struct StampMeta { int layer, cross, b0, nb; };
+  static constexpr size_t kStampWgs = 4096, kStampLaunches = 128;
   unsigned long long* d_stamp_ = nullptr;
   std::vector<StampMeta> stamp_meta_;
   unsigned long long* next_stamp(int layer, int cross, int b0, int nb);

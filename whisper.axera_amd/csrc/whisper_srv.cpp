@@ -48,6 +48,7 @@
 struct Job {
   std::vector<float> pcm;
   std::promise<std::pair<bool, std::string>> done;
+  std::chrono::steady_clock::time_point arrived = std::chrono::steady_clock::now();
 };
 
 static std::mutex g_mu;
@@ -114,7 +115,12 @@ static void batcher(AX_WHISPER_HANDLE model, int max_batch, int wait_ms) {
 
 // Slots that are refilled as they finish (AX_WHISPER_Stream*). One request alone on an idle device takes the one-clip
 // path instead (the persistent launch is 2x faster than a step sequence with one live slot).
-static void slot_scheduler(AX_WHISPER_HANDLE model, int n_slots, int wait_ms, int steps_per_call) {
+// Admission policy (--min_admit N --admit_wait_ms T): while something is decoding, an admission pass is held back until N
+// requests can be admitted together or the oldest waiting request is T ms old — an encoder pass over 8 clips costs 0.72 ms
+// per clip against 1.74 ms alone (bench.py stream64.encoder_pass_by_group_size). Default N = 1 (admit as they come): on
+// MI355X at 64 slots and 60-150 ids per clip that measures FASTER than N = 8 (366 against 354 clips/s, bench.py stream64),
+// because a slot that waits for company idles for whole decoder steps; the knob is for models whose encoder dominates.
+static void slot_scheduler(AX_WHISPER_HANDLE model, int n_slots, int wait_ms, int steps_per_call, int min_admit, int admit_wait_ms) {
   const int Tc = std::max(1, AX_WHISPER_GetConfigInt(model, "n_text_ctx"));
   std::vector<Job*> owner(n_slots, nullptr);
   std::vector<int> fin(std::max(n_slots, 3));
@@ -141,7 +147,10 @@ static void slot_scheduler(AX_WHISPER_HANDLE model, int n_slots, int wait_ms, in
         if (g_stop) break;
         if (g_queue.size() == 1 && wait_ms > 0) g_cv.wait_for(lk, std::chrono::milliseconds(wait_ms), [] { return g_stop || g_queue.size() > 1; });
       }
-      while (!g_queue.empty() && busy + (int)take.size() < n_slots) { take.push_back(g_queue.front()); g_queue.pop_front(); }
+      const int room = n_slots - busy, can = std::min(room, (int)g_queue.size());
+      const bool hold = busy > 0 && can > 0 && can < std::min(min_admit, room) &&
+                        std::chrono::steady_clock::now() - g_queue.front()->arrived < std::chrono::milliseconds(admit_wait_ms);
+      while (!hold && !g_queue.empty() && busy + (int)take.size() < n_slots) { take.push_back(g_queue.front()); g_queue.pop_front(); }
     }
     if (busy == 0 && take.size() == 1) {  // alone on an idle device
       if (open) { AX_WHISPER_StreamClose(model); open = false; }
@@ -314,7 +323,7 @@ static void serve(int fd) {
 }
 
 int main(int argc, char** argv) {
-  int port = 8080, max_batch = 64, wait_ms = 5, steps_per_call = 8, max_body_mb = 16;
+  int port = 8080, max_batch = 64, wait_ms = 5, steps_per_call = 8, max_body_mb = 16, min_admit = 1, admit_wait_ms = 20;
   std::string model_type = "turbo", model_path = "../models-mi355x", language = "zh", devices, scheduler = "slots";
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -331,11 +340,13 @@ int main(int argc, char** argv) {
     if (val("model_type", "-t", model_type) || val("model_path", "-p", model_path) || val("language", "-l", language)) continue;
     if (val("devices", nullptr, devices) || val("scheduler", nullptr, scheduler)) continue;
     if (val("steps_per_call", nullptr, v)) { steps_per_call = std::max(1, atoi(v.c_str())); continue; }
+    if (val("min_admit", nullptr, v)) { min_admit = std::max(1, atoi(v.c_str())); continue; }
+    if (val("admit_wait_ms", nullptr, v)) { admit_wait_ms = std::max(0, atoi(v.c_str())); continue; }
     if (val("max_conns", nullptr, v)) { g_max_conns = std::max(1, atoi(v.c_str())); continue; }
     if (val("max_body_mb", nullptr, v)) { max_body_mb = std::max(1, atoi(v.c_str())); continue; }
     if (val("recv_timeout_s", nullptr, v)) { g_recv_timeout_s = std::max(1, atoi(v.c_str())); continue; }
     fprintf(stderr, "usage: %s [--port 8080] [-t model_type] [-p model_path] [-l language] [--max_batch 64] [--batch_wait_ms 5] [--devices all|0,1,..]\n"
-                    "          [--scheduler slots|batches] [--steps_per_call 8] [--max_conns 256] [--max_body_mb 16] [--recv_timeout_s 10]\n", argv[0]);
+                    "          [--scheduler slots|batches] [--steps_per_call 8] [--min_admit 1] [--admit_wait_ms 20] [--max_conns 256] [--max_body_mb 16] [--recv_timeout_s 10]\n", argv[0]);
     return a == "--help" || a == "-?" ? 0 : 1;
   }
   printf("port: %d\n", port);
@@ -389,7 +400,7 @@ int main(int argc, char** argv) {
 
   std::vector<std::thread> bts;
   for (AX_WHISPER_HANDLE m : models) {
-    if (scheduler == "slots" && max_batch >= 2) bts.emplace_back(slot_scheduler, m, max_batch, wait_ms, steps_per_call);
+    if (scheduler == "slots" && max_batch >= 2) bts.emplace_back(slot_scheduler, m, max_batch, wait_ms, steps_per_call, min_admit, admit_wait_ms);
     else bts.emplace_back(batcher, m, max_batch, wait_ms);
   }
   signal(SIGPIPE, SIG_IGN);
