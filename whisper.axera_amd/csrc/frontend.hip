@@ -7,10 +7,13 @@
 // "ALL frames" means all frames of the input however long it is (Whisper.cpp:158-172 takes the maximum before it
 // truncates to 3000 frames): the grid covers every frame of the longest clip, frames past 3000 only feed the maximum.
 //
-// Kernel 1 (stft_mel_kernel): one workgroup = 32 consecutive frames of one clip. The windowed
-// frames are staged in LDS ([32][400] f32, 51 KB), the 400-point DFT is evaluated directly with
-// a 400-entry twiddle table in LDS (each lane owns up to 4 bins x 8 frames = 64 accumulators),
-// the power spectrum goes back to LDS and the mel projection + log10 + clip maximum are fused in.
+// Kernel 1 (stft_mel_kernel): one workgroup = 32 consecutive frames of one clip. The windowed frames are staged in
+// LDS ([32][401] f32, 51 KB) and the 400-point DFT runs on the matrix cores as an exact-fp32 GEMM
+//   [32 frames x 400 samples] . [400 x (cos | sin) of 224 bins]     (v_mfma_f32_32x32x2_f32, fp32 in, fp32 accumulate:
+// the arithmetic class of the FMA loop it replaces — rounds 1-3 evaluated the DFT with 64 scalar accumulators per lane at
+// 0.18 of the fp32 vector peak); the twiddle operand is never materialised: a lane walks a 400-entry (cos, sin) table in
+// LDS with its own stride (k * bin mod 400). The power spectrum goes back to LDS and the mel projection + log10 + clip
+// maximum are fused in.
 // Kernel 2 (mel_normalize_kernel): clamp/scale/zero-fill and layout: time-major h16 rows for the
 // encoder's conv-as-GEMM (and the reference's [n_mels][3000] f32 layout when a caller asks for it).
 // HBM traffic per clip: 1.92 MB PCM in, 0.96 MB log-mel scratch out+in, 0.48 MB h16 out.
@@ -19,8 +22,10 @@
 namespace axw {
 inline namespace AXW_NS {
 
-constexpr int FR = 32;        // frames per workgroup
-constexpr int PW_LD = 208;    // power row stride in LDS
+constexpr int FR = 32;        // frames per workgroup = rows of one MFMA tile
+constexpr int PW_LD = 209;    // power row stride in LDS: odd (column reads of the mel GEMM), >= 202 (bins padded to an even count)
+constexpr int XS = kNFFT + 1; // row stride of the staged frames: odd, so a column read (32 frames, one sample) hits 32 banks
+constexpr int kBinGroups = (kBins + 31) / 32;  // 7 groups of 32 bins
 
 __device__ __forceinline__ unsigned float_to_ordered(float f) {
   unsigned u = __float_as_uint(f);
@@ -32,8 +37,8 @@ __device__ __forceinline__ float ordered_to_float(unsigned u) {
 
 __global__ __launch_bounds__(256) void stft_mel_kernel(FrontendParams p, const float* __restrict__ basis_t /*[201][n_mels]*/) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* xw = reinterpret_cast<float*>(smem);                 // [FR][400] windowed frames; later power [FR][PW_LD]
-  float2* tw = reinterpret_cast<float2*>(smem + FR * kNFFT * 4);  // [400] (cos, sin)
+  float* xw = reinterpret_cast<float*>(smem);                 // [FR][XS] windowed frames; later power [FR][PW_LD]
+  float2* tw = reinterpret_cast<float2*>(smem + FR * XS * 4);  // [400] (cos, sin)
   __shared__ float red[4];
 
   const int b = blockIdx.y;
@@ -48,68 +53,121 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(FrontendParams p, const f
   const int tid = threadIdx.x;
 
   for (int i = tid; i < kNFFT; i += 256) tw[i] = make_float2(p.twiddle[2 * i], p.twiddle[2 * i + 1]);
-  for (int i = tid; i < FR * kNFFT; i += 256) {
-    int f = i / kNFFT, k = i - f * kNFFT;
-    float v = 0.f;
-    if (f0 + f < n_frames) {
-      int j = (f0 + f) * kHop + k - kNFFT / 2;       // index into the un-padded signal
-      if (j < 0) j = -j;                              // librosa.h:51  x[left - i]
-      if (j >= n) j = 2 * n - 2 - j;                  // librosa.h:54  x[size - 2 - i + left]
-      j = min(max(j, 0), n - 1);                      // clips shorter than the pad: stay in bounds
-      float smp = 0.f;                                // librosa.h:92 (openai mode: zeros behind the clip's end)
-      if (j < n_real) smp = j < p.stride ? x[j] : p.overflow[p.over_off[b] + (j - p.stride)];  // clips beyond the staging row
-      v = smp * p.window[k];
+  // Stage the 32 windowed frames. Interior workgroups (no reflection at either end of the clip, every sample inside the
+  // staging row) take the plain path: k walks the frame, f the frames, no division and no per-sample tests, so the loads
+  // of an iteration are independent and go out together.
+  const int j_first = f0 * kHop - kNFFT / 2, j_last = (f0 + FR - 1) * kHop + kNFFT - 1 - kNFFT / 2;
+  if (j_first >= 0 && j_last < min(n_real, p.stride) && f0 + FR <= n_frames) {  // uniform per workgroup
+    const float* xs = x + j_first;
+    for (int k = tid; k < kNFFT; k += 256) {
+      const float wk = p.window[k];
+#pragma unroll 8
+      for (int f = 0; f < FR; ++f) xw[f * XS + k] = xs[f * kHop + k] * wk;
     }
-    xw[i] = v;
+  } else {
+    for (int i = tid; i < FR * kNFFT; i += 256) {
+      int f = i / kNFFT, k = i - f * kNFFT;
+      float v = 0.f;
+      if (f0 + f < n_frames) {
+        int j = (f0 + f) * kHop + k - kNFFT / 2;       // index into the un-padded signal
+        if (j < 0) j = -j;                              // librosa.h:51  x[left - i]
+        if (j >= n) j = 2 * n - 2 - j;                  // librosa.h:54  x[size - 2 - i + left]
+        j = min(max(j, 0), n - 1);                      // clips shorter than the pad: stay in bounds
+        float smp = 0.f;                                // librosa.h:92 (openai mode: zeros behind the clip's end)
+        if (j < n_real) smp = j < p.stride ? x[j] : p.overflow[p.over_off[b] + (j - p.stride)];  // clips beyond the staging row
+        v = smp * p.window[k];
+      }
+      xw[f * XS + k] = v;
+    }
   }
   __syncthreads();
 
-  // ---- DFT: lane -> bins {l, l+64, l+128, l+192}, wave -> frames [8w, 8w+8)
-  const int lane = tid & 63, w = tid >> 6;
-  float re[4][8], im[4][8];
+  // ---- DFT on the matrix cores. One v_mfma_f32_32x32x2_f32 multiplies A = 32 frames x 2 samples (lane: frame lane % 32,
+  // sample 2s + lane / 32) by B = 2 samples x 32 bins (lane: bin lane % 32) into a 32 x 32 fp32 tile whose lanes run along
+  // the bins and whose registers run along the frames; the cos and the sin tile of the same 32 bins share lane and
+  // register, so re^2 + im^2 is register-local. 201 bins = 7 groups of 32: wave w takes groups w and w + 4.
+  // B is read from the twiddle table: bin n at sample k needs entry (k * n) mod 400, and k advances by 2 per step.
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int n_groups = (w + 4 < kBinGroups) ? 2 : 1;  // wave-uniform
+  f32x16 acc[2][2];  // [group][cos | sin]
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int g = 0; g < 2; ++g)
 #pragma unroll
-    for (int f = 0; f < 8; ++f) { re[j][f] = 0.f; im[j][f] = 0.f; }
-  int idx[4] = {0, 0, 0, 0};
-  const int kk[4] = {lane, lane + 64, lane + 128, lane + 192};
-  const float* xf = xw + (w * 8) * kNFFT;
-  for (int t = 0; t < kNFFT; ++t) {
-    float xs[8];
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int f = 0; f < 8; ++f) xs[f] = xf[f * kNFFT + t];   // wave-uniform address: LDS broadcast
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float2 c = tw[idx[j]];
-#pragma unroll
-      for (int f = 0; f < 8; ++f) { re[j][f] = fmaf(xs[f], c.x, re[j][f]); im[j][f] = fmaf(-xs[f], c.y, im[j][f]); }
-      idx[j] += kk[j];
-      if (idx[j] >= kNFFT) idx[j] -= kNFFT;
+      for (int e = 0; e < 16; ++e) acc[g][c][e] = 0.f;
+  const int bin0 = w * 32 + r, bin1 = (w + 4) * 32 + r;
+  int idx0 = (h * bin0) % kNFFT, idx1 = (h * bin1) % kNFFT;
+  const int inc0 = (2 * bin0) % kNFFT, inc1 = (2 * bin1) % kNFFT;
+  const float* xa = xw + r * XS + h;
+  if (n_groups == 2) {
+#pragma unroll 4
+    for (int s2 = 0; s2 < kNFFT / 2; ++s2) {
+      const float a = xa[2 * s2];
+      const float2 t0 = tw[idx0], t1 = tw[idx1];
+      idx0 += inc0; idx0 -= idx0 >= kNFFT ? kNFFT : 0;
+      idx1 += inc1; idx1 -= idx1 >= kNFFT ? kNFFT : 0;
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, t0.x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, t0.y, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, t1.x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, t1.y, acc[1][1], 0, 0, 0);
+    }
+  } else {
+#pragma unroll 4
+    for (int s2 = 0; s2 < kNFFT / 2; ++s2) {
+      const float a = xa[2 * s2];
+      const float2 t0 = tw[idx0];
+      idx0 += inc0; idx0 -= idx0 >= kNFFT ? kNFFT : 0;
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, t0.x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, t0.y, acc[0][1], 0, 0, 0);
     }
   }
   __syncthreads();  // all waves are done reading xw
   float* pw = xw;   // power [FR][PW_LD]
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (kk[j] < kBins) {
+  for (int g = 0; g < 2; ++g) {
+    const int bin = g ? bin1 : bin0;
+    if (g < n_groups && bin <= kBins) {  // bin 201 (of the last group) is the zero that pads the bins to an even count
 #pragma unroll
-      for (int f = 0; f < 8; ++f) pw[(w * 8 + f) * PW_LD + kk[j]] = re[j][f] * re[j][f] + im[j][f] * im[j][f];  // librosa.h:98-100
+      for (int e = 0; e < 16; ++e) {
+        const int f = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const float pv = acc[g][0][e] * acc[g][0][e] + acc[g][1][e] * acc[g][1][e];  // librosa.h:98-100
+        pw[f * PW_LD + bin] = bin < kBins ? pv : 0.f;
+      }
     }
   }
   __syncthreads();
 
-  // ---- mel projection (librosa.h:153) + log10 (Whisper.cpp:160) + clip maximum (:162-164)
+  // ---- mel projection (librosa.h:153) + log10 (Whisper.cpp:160) + clip maximum (:162-164), also on the matrix cores:
+  // [32 frames x 202 bins] . [202 x 32 mels] per wave (wave w: mels 32w .. 32w + 31), the filterbank operand straight from
+  // global memory (64-103 KB shared by every workgroup: L1 / L2 hits), lanes along the mels = the contiguous axis of logmel.
   const int nm = p.n_mels;
   float lmax = -3.402823466e38f;
-  for (int o = tid; o < FR * nm; o += 256) {
-    int f = o / nm, m = o - f * nm;
-    if (f0 + f >= n_frames) continue;
-    const float* pr = pw + f * PW_LD;
-    float acc = 0.f;
-    for (int k = 0; k < kBins; ++k) acc = fmaf(basis_t[k * nm + m], pr[k], acc);
-    float v = log10f(fmaxf(acc, 1e-10f));
-    lmax = fmaxf(lmax, v);
-    if (f0 + f < kFramesOut) p.logmel[((long)b * kFramesOut + f0 + f) * nm + m] = v;
+  if (w * 32 < nm) {
+    const int m = w * 32 + r;
+    const bool m_ok = m < nm;
+    f32x16 macc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) macc[e] = 0.f;
+    const float* pa = pw + r * PW_LD + h;
+    const float* bb = basis_t + (long)h * nm + (m_ok ? m : 0);
+#pragma unroll 4
+    for (int s2 = 0; s2 < (kBins + 1) / 2; ++s2) {
+      const int k = 2 * s2 + h;
+      const float a = pa[2 * s2];                                  // bin 201 of every row is zero (written above)
+      const float bv = (m_ok && k < kBins) ? bb[(long)2 * s2 * nm] : 0.f;
+      macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, macc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int f = (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (!m_ok || f0 + f >= n_frames) continue;
+      const float v = log10f(fmaxf(macc[e], 1e-10f));
+      lmax = fmaxf(lmax, v);
+      if (f0 + f < kFramesOut) p.logmel[((long)b * kFramesOut + f0 + f) * nm + m] = v;
+    }
   }
   lmax = wave_max(lmax);
   if (lane == 0) red[w] = lmax;
@@ -151,7 +209,7 @@ __global__ void gmax_reset_kernel(unsigned* gmax, int batch) {
 
 void launch_frontend(const FrontendParams& p, hipStream_t s) {
   hipLaunchKernelGGL(gmax_reset_kernel, dim3((p.batch + 63) / 64), dim3(64), 0, s, p.gmax, p.batch);
-  const int lds = FR * kNFFT * 4 + kNFFT * 8;
+  const int lds = FR * XS * 4 + kNFFT * 8;
   dim3 grid((p.max_frames + FR - 1) / FR, p.batch);
   // basis is passed transposed ([201][n_mels]) by the engine in p.mel_basis
   hipLaunchKernelGGL(stft_mel_kernel, grid, dim3(256), lds, s, p, p.mel_basis);
