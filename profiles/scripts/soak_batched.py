@@ -27,7 +27,7 @@ clips = [modelgen.synth_clip(300 + i, int(rng.integers(16000, 480000)) if i % 3 
 
 
 def run(env):
-    for k in ("AX_WHISPER_BATCHED_LN", "AX_WHISPER_FUSE_CQ", "AX_WHISPER_LOGITS_RT"):
+    for k in ("AX_WHISPER_BATCHED_LN",):
         os.environ.pop(k, None)
     os.environ.update(env)
     e = wa.Whisper(model, mdir, "zh", device=0, max_batch=B)
@@ -39,8 +39,8 @@ def run(env):
 
 
 new, t_new = run({})
-old, t_old = run({"AX_WHISPER_BATCHED_LN": "0", "AX_WHISPER_FUSE_CQ": "0", "AX_WHISPER_LOGITS_RT": "2"})
-for k in ("AX_WHISPER_BATCHED_LN", "AX_WHISPER_FUSE_CQ", "AX_WHISPER_LOGITS_RT"):
+old, t_old = run({"AX_WHISPER_BATCHED_LN": "0"})
+for k in ("AX_WHISPER_BATCHED_LN",):
     os.environ.pop(k, None)
 e1 = wa.Whisper(model, mdir, "zh", device=0, max_batch=1)
 single = [e1.run_tokens(c) for c in clips]

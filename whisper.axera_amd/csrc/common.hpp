@@ -325,7 +325,6 @@ struct DecAttnParams {
   h16* out_hi; h16* out_lo; int nbs; // normalised output as a fragment-major h16 pair instead of partials; with n_split > 1
                                      // the splits of a (clip, head) meet through mpart / mcnt and the last one to arrive writes it
   float* mpart; unsigned* mcnt;      // [B][H][n_split][66] / [B][H] (zero between launches), same clip origin as q / out
-  int strict_ticket;                 // 1: the splits' ticket is an acq_rel agent-scope RMW (buffer_wbl2 + buffer_inv per workgroup)
   // fused query projection (batched cross-attention): q = Wq[head rows] . LayerNorm(x[b]) + bq computed by the
   // (clip, head) workgroup itself while its first K/V block is in flight; wq == nullptr: q is read from `q`
   const float* x; const float* ln_w; const float* ln_b; const h16* wq; const float* bq;

@@ -291,13 +291,11 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
       // workgroup whose add came last — told by the value its add returned — reads the others' records with sc1 loads
       // after that add has returned (the loads sit behind a branch on the returned value; the signal fences pin the
       // compiler's ordering on both sides). An acq_rel RMW instead (buffer_wbl2 + buffer_inv per workgroup, what the C++
-      // memory model would ask for) was measured at turbo dims, 16 clips, 2 splits: decode 151.5 -> 197.0 ms.
-      // AX_WHISPER_STRICT_TICKET=1 selects it.
+      // memory model would ask for) was measured at turbo dims, 16 clips, 2 splits: decode 151.5 -> 197.0 ms (round 3).
       unsigned ticket = 0;
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
       if (tid == 0) {
-        if (p.strict_ticket) ticket = __hip_atomic_fetch_add(p.mcnt + b * p.n_head + head, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        else ticket = __hip_atomic_fetch_add(p.mcnt + b * p.n_head + head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __hip_atomic_fetch_add(p.mcnt + b * p.n_head + head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
       ticket = __builtin_amdgcn_readfirstlane(ticket);

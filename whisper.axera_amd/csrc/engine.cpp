@@ -21,21 +21,9 @@ inline namespace AXW_NS {
       throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);       \
   } while (0)
 
-// Launch-per-row-block form of the batched vocabulary projection (used where the register-resident form does not
-// fit, and for A/B runs when AX_WHISPER_LOGITS_RT is set): weight-row tiles of 16 rows per workgroup, 1, 2 (default) or 4
-static int logits_rt() {
-  static const int v = [] {
-    const char* e = getenv("AX_WHISPER_LOGITS_RT");
-    const int r = e ? atoi(e) : 2;
-    return (r == 1 || r == 2 || r == 4) ? r : 2;
-  }();
-  return v;
-}
-
-static int strict_ticket() {
-  static const int v = [] { const char* e = getenv("AX_WHISPER_STRICT_TICKET"); return e && e[0] == '1' ? 1 : 0; }();
-  return v;
-}
+// Launch-per-row-block form of the batched vocabulary projection (used where the register-resident form does not fit:
+// d_model 1280 beyond 48 clips): weight-row tiles of 16 rows per workgroup, two per wave (1 / 2 / 4 measured alike).
+static int logits_rt() { return 2; }
 
 static int dtype_code(const std::string& d) { return d == "F32" ? 0 : d == "BF16" ? 1 : 2; }
 
@@ -132,8 +120,7 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
     cfg_.ints["batched_ln"] = batched_ln_ ? 1 : 0;
   }
   {
-    const char* e = getenv("AX_WHISPER_ENC_SPLITK");
-    enc_split_k_ = !(e && e[0] == '0');
+    enc_split_k_ = true;
     // A/B and test switches of the batched decode sequence (read per engine)
     if (const char* t = getenv("AX_WHISPER_GEMV_MAX")) gemv_max_ = std::max(1, std::min(4, atoi(t)));
     if (const char* t = getenv("AX_WHISPER_CROSS_SPLIT")) cross_split_env_ = atoi(t);
@@ -886,7 +873,7 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
     c.d_model = d; c.n_ctx_pad = Tc; c.state = d_state_; c.off = d_off_ + b0;
     return c;
   };
-  static const bool fuse_cq = [] { const char* e = getenv("AX_WHISPER_FUSE_CQ"); return !(e && e[0] == '0'); }();
+  const bool fuse_cq = true;  // the cross-attention workgroups project their own queries (d_model <= 1024)
   // Workgroups per (clip, head) of the cross-attention launch (its key blocks divided among them, at least four blocks
   // = one per wave each): at few clips one workgroup per (clip, head) leaves most CUs idle behind 24 sequential blocks
   // (3 clips: attention 0.245 -> 0.209 ms per step with 6 splits); from ~24 clips on there are enough (clip, head)
@@ -933,7 +920,6 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
       a.n_split = cross_split;
       a.mpart = d_attn_mpart_ + (long)b0 * H * kCrossSplitMax * 66;
       a.mcnt = d_attn_mcnt_ + (long)b0 * H;
-      a.strict_ticket = strict_ticket();
       a.x = x; a.ln_w = w.cross_ln_w; a.ln_b = w.cross_ln_b; a.wq = w.w_cq; a.bq = w.b_cq;
       a.stamp = next_stamp(l, 1, b0, nb);
       if (step_mask_ & 2) launch_decode_attention(a, s);
@@ -967,10 +953,10 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
 //   97 and more     2 branches (112 clips: 1.745 with two, 1.811 with three; 128: 1.907 / 1.969; 192, 256: within 1 %)
 // One step costs 17.9 us per clip at 64 clips, 14.9 at 128, 13.1 at 256 (the chain of small GEMMs is paid once per step): the
 // slot scheduler's rate grows with its slot count (profiles/r03_big_batches.txt).
-// AX_WHISPER_DECODE_BRANCHES overrides (1, 2, 3 or 4; AX_WHISPER_BRANCH_MIN: fewest clips per branch it may leave, default 6).
+// AX_WHISPER_DECODE_BRANCHES overrides (1, 2, 3 or 4).
 int Engine::decode_branches(int batch) const {
   static const int forced = [] { const char* e = getenv("AX_WHISPER_DECODE_BRANCHES"); return e ? atoi(e) : 0; }();
-  static const int min_per = [] { const char* e = getenv("AX_WHISPER_BRANCH_MIN"); return e ? std::max(1, atoi(e)) : 6; }();
+  const int min_per = 6;  // fewest clips the last branch may be left with
   int n = forced > 0 ? forced : (batch < 22 ? 1 : batch < 40 ? 2 : batch <= 48 ? 3 : batch <= 64 ? 2 : batch <= 96 ? 3 : 2);
   n = std::min(n, kMaxBranches);
   // every branch gets whole clip blocks; the last one at least min_per clips
@@ -1040,7 +1026,6 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
       a.n_split = c;
       a.mpart = d_attn_mpart_;
       a.mcnt = d_attn_mcnt_;
-      a.strict_ticket = strict_ticket();
     }
     a.stamp = next_stamp(stamp_layer, n_keys >= 0 ? 1 : 0, 0, batch);
     if (step_mask_ & 2) launch_decode_attention(a, s);
@@ -1104,8 +1089,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
   }
   ln(dec_ln_w_, dec_ln_b_);
   DecGemmParams p = base(tok_emb_packed_, nullptr, cfg_.n_vocab, d, d_act_[0], d_act_[1], GEPI_LOGITS);
-  static const bool resident_off = [] { const char* e = getenv("AX_WHISPER_LOGITS_RT"); return e != nullptr; }();
-  const int vocab_rt = (!resident_off && decode_logits_resident_ok(d, batch)) ? 0 : logits_rt();
+  const int vocab_rt = decode_logits_resident_ok(d, batch) ? 0 : logits_rt();
   p.rt = vocab_rt;
   p.amax_val = d_amax_val_; p.amax_idx = d_amax_idx_; p.amax_stride = n_amax_part_;
   p.skip_before_step = 3; p.logits_dump = d_logits; p.logits_dump_stride = logits_stride;
