@@ -68,16 +68,11 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
   std::lock_guard<std::recursive_mutex> capture_lock(device_capture_mutex(device_));  // allocations + synchronous copies (iengine.hpp)
   HIP_CHECK(hipSetDevice(device_));
   device_set_ = true;
-  // Creation order = hardware-queue order: the runtime deals streams onto its (four) hardware queues in turn, and streams that
-  // share one run their work one after the other. The four that work side by side in a slot stream — the step graph's main
-  // stream, its second branch, the admission passes (encoder) and the result copies — are created back to back, so they get
-  // four different queues whatever the process created before; the third and fourth graph branch (40-48 / 65-96 clips) wrap.
   HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
-  HIP_CHECK(hipStreamCreateWithFlags(&admit_stream_, hipStreamNonBlocking));
-  HIP_CHECK(hipStreamCreateWithFlags(&branch_stream_[0], hipStreamNonBlocking));
-  HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-  for (int i = 1; i < kMaxBranches - 1; ++i) HIP_CHECK(hipStreamCreateWithFlags(&branch_stream_[i], hipStreamNonBlocking));
   for (auto& e : ev_) HIP_CHECK(hipEventCreate(&e));
+  for (auto& b : branch_stream_) HIP_CHECK(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&admit_stream_, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
   for (auto& e : ev_ring_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : ev_step_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&ev_upload_, hipEventDisableTiming));
