@@ -70,7 +70,9 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
   device_set_ = true;
   HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   for (auto& e : ev_) HIP_CHECK(hipEventCreate(&e));
-  for (auto& b : branch_stream_) HIP_CHECK(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+  // (the second branch's stream; the third and fourth are created when a step graph first needs them: every stream takes a turn
+  // on the runtime's four hardware queues, and up to 64 clips only four of the engine's streams ever work side by side)
+  HIP_CHECK(hipStreamCreateWithFlags(&branch_stream_[0], hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&admit_stream_, hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
   for (auto& e : ev_ring_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1144,6 +1146,14 @@ void Engine::recover_streams() {
   (void)hipGetLastError();
 }
 
+// the streams the batched step of `batch` clips forks into (enqueue_decode_step_batched): branch i runs on branch_stream_[i - 1]
+void Engine::ensure_branch_streams(int batch) {
+  if (batch <= gemv_max_ || !batched_ln_) return;
+  const int nbr = decode_branches(batch);
+  for (int i = 1; i < nbr - 1 && i < kMaxBranches - 1; ++i)
+    if (!branch_stream_[i]) HIP_CHECK(hipStreamCreateWithFlags(&branch_stream_[i], hipStreamNonBlocking));
+}
+
 hipGraphExec_t Engine::step_graph(int batch, int max_new) {
   const long key = ((long)batch * 1024 + max_new) * 32 + step_mask_;
   auto it = graphs_.find(key);
@@ -1152,6 +1162,7 @@ hipGraphExec_t Engine::step_graph(int batch, int max_new) {
   hipGraph_t graph = nullptr;
   // nobody on this device allocates, copies synchronously or captures while this capture is open (iengine.hpp)
   std::lock_guard<std::recursive_mutex> capture_lock(device_capture_mutex(device_));
+  ensure_branch_streams(batch);  // before the capture opens
   HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   hipError_t cap_err = hipSuccess;
   try {
@@ -1412,6 +1423,7 @@ void Engine::decode_forced(int batch, const int32_t* forced, int n_forced, float
     else persistent_gave_up();
   }
   if (!done) reset_decode_state(batch);
+  if (!done) ensure_branch_streams(batch);
   for (int st = 0; !done && st < 4 + n_forced; ++st) {
     const int gi = st - 3;
     float* lrow = (d_logits && gi >= 0) ? d_logits + (size_t)gi * nv : nullptr;

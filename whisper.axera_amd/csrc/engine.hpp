@@ -75,6 +75,7 @@ class Engine final : public IEngine {
                                    long logits_stride, int* d_argmax);
   void enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced);
   int decode_branches(int batch) const;
+  void ensure_branch_streams(int batch);
   hipGraphExec_t step_graph(int batch, int max_new);
   void recover_streams();
   int greedy_loop(int batch, int max_new, const int* max_new_clip = nullptr);
