@@ -1647,7 +1647,11 @@ float Engine::bench(const std::string& what, int batch, int arg, int iters) {
     if (batch <= gemv_max_) throw std::runtime_error("bench attn_stamp: the batched decode sequences only (3+ clips)");
     // (a launch has batch * heads workgroups, or up to 640 when few (clip, head) pairs are split along the keys)
     if (std::max<long>((long)batch * cfg_.n_text_head, 640) > (long)kStampWgs) throw std::runtime_error("bench attn_stamp: too many workgroups per launch");
-    if (!d_stamp_) { d_stamp_ = (unsigned long long*)dalloc((size_t)2 * kStampWgs * kStampLaunches * 8, true); allocs_.push_back(d_stamp_); }
+    if (!d_stamp_) {
+      std::lock_guard<std::recursive_mutex> capture_lock(device_capture_mutex(device_));  // an allocation (iengine.hpp)
+      d_stamp_ = (unsigned long long*)dalloc((size_t)2 * kStampWgs * kStampLaunches * 8, true);
+      allocs_.push_back(d_stamp_);
+    }
     step_mask_ = 15 | 16;
     struct Restore { int& m; ~Restore() { m = 15; } } restore{step_mask_};
     const int Tc = cfg_.n_text_ctx;
