@@ -283,7 +283,7 @@ def batch_leg(torch, dev, dev_index, sync, model, dtype, B, steps, max_new, mode
     return leg, ids
 
 
-def stream_leg(torch, dev, dev_index, sync, model, dtype, n_slots, n_clips, model_dir):
+def stream_leg(torch, dev, dev_index, sync, model, dtype, n_slots, n_clips, model_dir, policies=(1, 8), group_sizes=True):
     """The serving path on the realistic-length workload: n_clips 30 s clips (host PCM, as requests arrive) through n_slots
     utterance slots that are refilled while the others decode (AX_WHISPER_Stream*: one batched front-end + encoder pass per
     group of freed slots, cross K/V scattered into the idle slots, per-slot decode offsets). Budgets as in the ragged batch
@@ -301,7 +301,7 @@ def stream_leg(torch, dev, dev_index, sync, model, dtype, n_slots, n_clips, mode
     budgets = realistic_budgets(n_clips, seed=20260105)
     eng = wa.Whisper(model, model_root, "zh", device=dev_index, max_batch=n_slots)
     res = {}
-    for min_admit in (1, 8):
+    for min_admit in policies:
         eng.run_stream(clips[: 2 * n_slots], n_slots, max_new=budgets[: 2 * n_slots], min_admit=min_admit)  # warm: graphs, buffers
         sync()
         t0 = time.perf_counter()
@@ -312,7 +312,7 @@ def stream_leg(torch, dev, dev_index, sync, model, dtype, n_slots, n_clips, mode
     enc_flop = {"tiny": 40.48e9, "small": 386.63e9, "turbo": 2313.09e9}.get(model)
     groups = {}
     for k in (1, 2, 4, 8, 16, 32, 64):
-        if k > n_slots:
+        if k > n_slots or not group_sizes:
             break
         ms = eng.bench("encoder", k, 0, 5) / 5
         groups[str(k)] = {"ms": round(ms, 3), "ms_per_clip": round(ms / k, 4), "TFLOPs": round(enc_flop * k / (ms * 1e-3) / 1e12, 1) if enc_flop else None}
@@ -681,6 +681,9 @@ def run_rank(args) -> int:
                                    budgets=realistic_budgets(64))
                 out["batch64_len100"] = leg
                 out["stream64"] = stream_leg(torch, dev, dev_index, sync, "small", dtype, 64, 384, args.model_dir)
+                # the slot count is a deployment knob (a slot costs 57 MB of cross K/V + 16.5 MB of self K/V): the step's chain of small
+                # GEMMs is paid once whatever the slot count, so twice the slots serve more clips per second
+                out["stream128"] = stream_leg(torch, dev, dev_index, sync, "small", dtype, 128, 768, args.model_dir, policies=(1,), group_sizes=False)
             if not args.no_batch256 and args.max_new == 0:
                 # not a BASELINE config: the same workload at the batch 288 GB of HBM invite (19 GB of K/V caches). A decoder
                 # step's chain of small GEMMs is paid once whatever the batch: 17.9 us per clip and step at 64, 13.1 at 256.
