@@ -11,7 +11,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "whisper.axera_amd", "csrc")
-FILES = ["frontend", "gemm", "encoder_attn", "decoder", "decode_gemv", "decode_gemm", "decode_persistent"]
+FILES = ["frontend", "gemm", "encoder_attn", "decoder", "decode_gemv", "decode_gemm", "decode_persistent", "decode_persistent2"]
 f16 = "1" if "--f16" in sys.argv else "0"
 print(f"# hipcc --offload-arch=gfx950 -O3 -DAXW_F16={f16}; kernel | vgpr | sgpr | vgpr spills | sgpr spills | scratch B | static LDS B")
 for name in FILES:

@@ -10,7 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "whisper.axera_amd", "csrc")
-KERNEL_FILES = ["frontend", "gemm", "encoder_attn", "decoder", "decode_gemv", "decode_gemm", "decode_persistent"]
+KERNEL_FILES = ["frontend", "gemm", "encoder_attn", "decoder", "decode_gemv", "decode_gemm", "decode_persistent", "decode_persistent2"]
 
 
 @pytest.mark.parametrize("f16", [0, 1], ids=["bf16", "fp16"])  # both builds of every kernel file (csrc/common.hpp AXW_F16)
@@ -27,9 +27,12 @@ def test_no_scratch_no_spills(name, f16, tmp_path):
     spills = [int(x) for x in re.findall(r"^\s+\.vgpr_spill_count:\s+(\d+)", text, re.M)]
     vgprs = [int(x) for x in re.findall(r"^\s+\.vgpr_count:\s+(\d+)", text, re.M)]
     assert names and len(priv) == len(names)
-    bad = [(n, p) for n, p in zip(names, priv) if p != 0]
+    # (the in-kernel timeline build of the two-clip launch — template arguments <..., PROF = true, 2> — is a measuring tool
+    #  run on request only, AX_WHISPER_PERSIST_PROF: its one spilled register is tolerated)
+    tool = [name == "decode_persistent2" and "Lb1ELi2E" in n for n in names]
+    bad = [(n, p) for n, p, t in zip(names, priv, tool) if p != 0 and not t]
     assert not bad, f"kernels using scratch memory: {bad}"
-    assert all(s == 0 for s in spills)
+    assert all(s == 0 or t for s, t in zip(spills, tool))
     assert max(vgprs) <= 512  # unified VGPR+AGPR file on gfx950
-    if name == "decode_persistent":
+    if name.startswith("decode_persistent"):
         assert max(vgprs) <= 128  # 1024-thread workgroups: 16 waves per CU

@@ -409,11 +409,24 @@ struct PersistParams {
   int* out_ids; int* n_out; DecState* state;
   int fault;                    // test hook (AX_WHISPER_PERSIST_FAULT=1): workgroup 0 leaves at once, so the launch must give up
   long long* prof;              // optional [grid][64]: per-phase 100 MHz tick sums + one layer's absolute timeline (AX_WHISPER_PERSIST_PROF), else nullptr
+  // Two clips in one launch (n_clip == 2; greedy decode only): every phase runs for clip 0 and then for clip 1 with the same
+  // weight rows in registers, so that one clip's hand-off is in flight while the other clip's rows are computed. Clip 0 keeps
+  // the LDS-resident K/V of the one-clip launch; clip 1 reads its K/V from global memory: its cross K/V in the next slot
+  // (cross_clip_stride elements on), its self-attention cache in self_k1 / self_v1 ([n_layer * n_head][8 blocks][4096], the
+  // per-owner layouts of the LDS cache). Granules, ids and counts of clip 1: gran + gran_clip_u64, out_ids1, n_out1.
+  int n_clip;
+  int prof_clip;  // two-clip timeline: whose absolute stamps are kept (decode_persistent2.hip)
+  long cross_clip_stride;
+  h16* self_k1; h16* self_v1;
+  long gran_clip_u64;
+  int* out_ids1; int* n_out1; int max_new1;
 };
 bool decode_persistent_supported(int d_model, int n_head, int n_layer, int n_cu);
 int decode_persistent_grid(int d_model, int n_cu);
 size_t decode_persistent_gran_bytes(int d_model, int grid);   // granule area; the error word sits in its last 8 bytes
 hipError_t launch_decode_persistent(const PersistParams& p, int d_model, int grid, hipStream_t s);
+hipError_t launch_decode_persistent2(const PersistParams& p, int d_model, int grid, hipStream_t s);  // n_clip == 2 (decode_persistent2.hip)
+bool decode_persistent_two_clips_supported(int d_model, int n_head, int n_layer, int grid);  // shapes whose every linear layer is ONE pass of rows per workgroup
 
 // weight preparation (device): raw file dtype -> h16 / fp32, with the layout changes the kernels want
 void launch_convert_to_h16(const void* src, int src_dtype /*0 f32,1 bf16,2 f16*/, h16* dst, long n, hipStream_t s);
