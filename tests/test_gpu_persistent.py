@@ -155,6 +155,24 @@ def test_two_clips_run_one_persistent_launch(built_lib, micro_case):
         e.close()
 
 
+def test_two_clip_launch_gives_up_and_falls_back(built_lib, micro_case, monkeypatch):
+    """A workgroup of the two-clip launch that never publishes (test hook): every other workgroup times out and drains, the
+    call falls back to the launch-per-phase path and returns the same ids."""
+    import modelgen
+
+    clips = [load_demo_pcm(), modelgen.synth_clip(9, 123456)]
+    e = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=2)
+    try:
+        want = e.run_tokens_batch(clips, max_new=16)
+        monkeypatch.setenv("AX_WHISPER_PERSIST_FAULT", "1")
+        assert e.run_tokens_batch(clips, max_new=16) == want
+        assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_giveups") == 1
+        monkeypatch.delenv("AX_WHISPER_PERSIST_FAULT")
+        assert e.run_tokens_batch(clips, max_new=16) == want
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("model_type,seed,max_new", [("mini", 31, 40), ("tiny", 32, 60), ("w512", 33, 40), ("small", 34, 100)])
 def test_two_clip_launch_equals_one_clip_launches(built_lib, tmp_path, monkeypatch, model_type, seed, max_new):
     """The two-clip launch runs the one-clip launch's arithmetic per clip (same rows, same summation order): ids of a

@@ -1199,11 +1199,11 @@ hipGraphExec_t Engine::step_graph(int batch, int max_new) {
 int Engine::greedy_loop(int batch, int max_new, const int* max_new_clip) {
   const int Tc = cfg_.n_text_ctx;
   if (max_new <= 0 || max_new > Tc - 4) max_new = Tc - 4;
-  // One clip: the persistent launch. Two clips: the persistent launch twice, one clip after the other — measured
-  // 2 x 118 ms against 316 ms for two clips through the launch-per-phase path (which wins from 3 clips on: 341 ms
-  // against 3 x 118), and each clip stops at its own eot.
+  // One clip: the persistent launch. Two clips: ONE two-clip persistent launch, phase by phase (one clip's rows are computed
+  // while the other's hand-off is in flight; decode_persistent2.hip) — Whisper-small, 444 ids per clip: 140 ms per pair
+  // against 2 x 116 ms for one launch per clip (shapes without a two-clip launch, AX_WHISPER_PERSIST2=0) and 316 ms through
+  // the launch-per-phase path, which wins from 3 clips on (244 ms). Each clip stops at its own eot / budget.
   if (batch == 2 && persistent2_ok_ && persistent_usable()) {
-    // two clips in ONE launch, phase by phase (one clip's rows are computed while the other's hand-off is in flight)
     const int mn0 = (max_new_clip && max_new_clip[0] > 0) ? std::min(max_new, max_new_clip[0]) : max_new;
     const int mn1 = (max_new_clip && max_new_clip[1] > 0) ? std::min(max_new, max_new_clip[1]) : max_new;
     const int st = run_persistent(mn0, nullptr, 0, nullptr, nullptr, 0, mn1);
