@@ -674,6 +674,11 @@ def run_rank(args) -> int:
                 leg, ids2 = batch_leg(torch, dev, dev_index, sync, "small", dtype, 64, n2, args.max_new, args.model_dir)
                 leg["clip0_ids_equal_batch1"] = ids2[0] == ids[0]
                 out["batch64"] = leg
+            if not args.no_batch64 and args.max_new == 0:
+                # two clips per call = both greedy loops in ONE persistent launch (decode_persistent2.hip): the low-load end of a server
+                leg, idsp = batch_leg(torch, dev, dev_index, sync, "small", dtype, 2, n2, 0, args.model_dir, rooflines=False)
+                leg["clip0_ids_equal_batch1"] = idsp[0] == ids[0]
+                out["batch2"] = leg
             if not args.no_realistic and args.max_new == 0:
                 # realistic utterance lengths (SURVEY §8d asks for them beside the full context): every clip of the 64 leaves the
                 # loop at its own budget of 60-150 ids; then the same workload through the slot scheduler (384 clips, 64 slots)

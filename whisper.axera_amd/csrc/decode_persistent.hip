@@ -81,7 +81,8 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   // attention outputs / cross-attention partials / mlp hidden vector; every other workgroup skips those three phases
   // altogether (no polls, no barriers): a hand-off is the faster the fewer workgroups poll it (-5 % decode time)
   constexpr int NP_D = (D + CT / LD - 1) / (CT / LD), NP_F2 = (D + CT / LF - 1) / (CT / LF);
-  const bool in_o = wg < NP_D, in_f2 = wg < NP_F2;
+  const int rwg = (wg - NS + P) % P;  // row roles by a rotated workgroup index: rwg 0 = the first self-attention owner
+  const bool in_o = rwg < NP_D, in_f2 = rwg < NP_F2;
 
   if (p.fault && wg == 0) return;  // test hook: a workgroup that never publishes; everybody else must give up and drain
   for (int i = tid; i < kKvBytes / 16; i += PT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};  // masked keys must be finite
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     // the busiest: their mlp.0 rows could only be requested after their cross-attention-output publish, ~2 us before
     // use, and arrived late — every consumer of the hidden vector waited for them: 1.2 us of skew per layer).
     const int pk_f = (NP_D + NP_F <= P && NP_Q <= P && NP_D + NP_F + NP_Q >= P) ? NP_D : ((NP_F <= P && NP_Q <= P && NP_F + NP_Q >= P) ? 0 : -1);
-    const bool is_fc1 = pk_f < 0 || (wg >= pk_f && wg < pk_f + NP_F);
+    const bool is_fc1 = pk_f < 0 || (rwg >= pk_f && rwg < pk_f + NP_F);
     // its mlp.2 rows can be requested a phase earlier (no mlp.0 rows in the way); not for wide models: 10 chunks per lane
     // held across the mlp.0 phase do not fit the register budget (the d=1280 instantiation went to scratch)
     constexpr bool kEarlyFc2 = CF <= 6;
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     // in the other (qkv A, o B, cq A, co B, mlp.0 A, [mlp.2 F], next qkv / vocabulary A)
     RowSet<LD, CD> ra, rb;
     RowSet<LF, CF> rs_fc2;
-    ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid, pk_qkv);
+    ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, rwg, P, ctid, pk_qkv);
     {  // the first layer's cross-attention unit has no previous layer to hide behind
       const int cu0 = ca_unit_of(0);
       if (cu0 >= 0) {
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         float res[2];
         ra.run(w_qkv, b_qkv, D, act, ctid, res);
         ra.publish(ctid, res, pk, ctl + 2, G + O_QKV, tag, [](float v) { return v; });
-        rb.prefetch(w_o, b_o, D, D, wg, P, ctid, pk_d);
+        rb.prefetch(w_o, b_o, D, D, rwg, P, ctid, pk_d);
         kv_piece(0, 2);
         AXW_STAMP(17)
         AXW_TL(10)
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           rb.run(w_o, b_o, D, act, ctid, res);
           rb.publish(ctid, res, pk, ctl + 2, G + O_Y1, tag, [](float v) { return v; });
         }
-        ra.prefetch(w_cq, b_cq, D, D, wg, P, ctid, pk_d);
+        ra.prefetch(w_cq, b_cq, D, D, rwg, P, ctid, pk_d);
         kv_piece(2, 5);
         AXW_STAMP(20)
         AXW_TL(12)
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_TL(20)
         ra.run(w_cq, b_cq, D, act, ctid, res);
         ra.publish(ctid, res, pk, ctl + 2, G + O_CQ, tag, [](float v) { return v; });
-        rb.prefetch(w_co, b_co, D, D, wg, P, ctid, pk_d);
+        rb.prefetch(w_co, b_co, D, D, rwg, P, ctid, pk_d);
         kv_piece(5, 8);
         AXW_STAMP(22)
         AXW_TL(13)
@@ -546,9 +547,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           rb.run(w_co, b_co, D, act, ctid, res);
           rb.publish(ctid, res, pk, ctl + 2, G + O_Y2, tag, [](float v) { return v; });
         }
-        ra.prefetch(w_fc1, b_fc1, D, F, wg, P, ctid, pk_f);
+        ra.prefetch(w_fc1, b_fc1, D, F, rwg, P, ctid, pk_f);
         if constexpr (kEarlyFc2) {
-          if (early_fc2) rs_fc2.prefetch(w_fc2, b_fc2, F, D, wg, P, ctid, pk_d);
+          if (early_fc2) rs_fc2.prefetch(w_fc2, b_fc2, F, D, rwg, P, ctid, pk_d);
         }
         kv_piece(8, 11);
         AXW_STAMP(25)
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_TL(22)
         ra.run(w_fc1, b_fc1, D, act, ctid, res);
         ra.publish(ctid, res, pk, ctl + 2, G + O_HID, tag, [](float v) { return gelu_erf(v); });
-        if (!early_fc2) rs_fc2.prefetch(w_fc2, b_fc2, F, D, wg, P, ctid, pk_d);
+        if (!early_fc2) rs_fc2.prefetch(w_fc2, b_fc2, F, D, rwg, P, ctid, pk_d);
         kv_piece(11, 13);
         AXW_STAMP(27)
         AXW_TL(16)
@@ -585,9 +586,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_STAMP(31)
         }
         // next consumer of the residual stream: the next layer's QKV rows, the vocabulary projection, or the next step
-        if (l + 1 < L) ra.prefetch(w_qkv + DecArena::w_stride(D), b_qkv + DecArena::f_stride(D), D, 3 * D, wg, P, ctid, pk_qkv);
-        else if (step >= 3) ra.prefetch(AXW_COLD(tok_emb), nullptr, D, AXW_COLD(n_vocab), wg, P, ctid);
-        else ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid, pk_qkv);
+        if (l + 1 < L) ra.prefetch(w_qkv + DecArena::w_stride(D), b_qkv + DecArena::f_stride(D), D, 3 * D, rwg, P, ctid, pk_qkv);
+        else if (step >= 3) ra.prefetch(AXW_COLD(tok_emb), nullptr, D, AXW_COLD(n_vocab), rwg, P, ctid);
+        else ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, rwg, P, ctid, pk_qkv);
         kv_piece(13, 16);
         AXW_STAMP(29)
         AXW_TL(17)
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           }
         }
         // the next step's first rows: requested before the token is even known
-        ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid, pk_qkv);
+        ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, rwg, P, ctid, pk_qkv);
         // workgroup argmax: lanes with j == 0 hold candidates; the lower index wins ties
         if (j != 0) { bv = -INFINITY; bi = 0x7fffffff; }
         wave_argmax(bv, bi);

@@ -84,7 +84,15 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   // attention outputs / cross-attention partials / mlp hidden vector; every other workgroup skips those three phases
   // altogether (no polls, no barriers): a hand-off is the faster the fewer workgroups poll it (-5 % decode time)
   constexpr int NP_D = (D + CT / LD - 1) / (CT / LD), NP_F2 = (D + CT / LF - 1) / (CT / LF);
-  const bool in_o = wg < NP_D, in_f2 = wg < NP_F2;
+  // Row roles go by a ROTATED workgroup index (rwg 0 = the first self-attention owner): the d-wide layers' producers are then
+  // workgroups that own a head (busy with attention in one layer of twelve), not the ones that run a cross-attention unit in
+  // most layers — with two clips interleaved, a producer that is also a unit holder puts one clip's rows behind the other
+  // clip's attention block.
+  const int rwg = (wg - NS + P) % P;
+  const bool in_o = rwg < NP_D, in_f2 = rwg < NP_F2;
+  // (Measured and switched off: a head's owner that produces no QKV rows running clip 0's self-attention block BEFORE clip 1's
+  //  QKV LayerNorm — its query is on its way already — 134.0 -> 143.8 ms per pair: the owners' later phases slip behind.)
+  constexpr bool sa_first = false;
 
   if (p.fault && wg == 0) return;  // test hook: a workgroup that never publishes; everybody else must give up and drain
   for (int i = tid; i < kKvBytes / 16; i += PT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};  // masked keys must be finite
@@ -204,6 +212,35 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         const bool tl_on = step == p.total_steps / 2 && l == L / 2;
         const float* FL = p.fl + (long)l * DecArena::f_stride(D);
         const unsigned tag = (unsigned)(step * L + l + 1);
+        // lanes 0-31: q, 32-63: k, 64-95: v of the head, two adjacent dims each
+        auto qkv_pair = [&](int c) { return [&, c](int) { return tid < 96 ? c * gco + O_QKV + (tid >> 5) * D + sa_head * 64 + 2 * (tid & 31) : -1; }; };
+        auto stage_q = [&](const unsigned (&v)[2], unsigned* q) {  // dims 2 tid, 2 tid + 1 as one packed (hi, lo) pair
+          unsigned hi, lo;
+          h16split2(__uint_as_float(v[0]), __uint_as_float(v[1]), hi, lo);
+          q[tid] = hi;
+          q[32 + tid] = lo;
+        };
+        // self-attention owner, clip 0: collect q, k, v of the head; append k, v to the LDS cache; its blocks are the compute waves'
+#define AXW_SA0_POLL                                                                                                   \
+  {                                                                                                                    \
+    unsigned v[2];                                                                                                     \
+    const bool fail = gather2<1>(GR, tag, v, p.err, ctl, qkv_pair(0));                                                 \
+    if (tid < 32) stage_q(v, qs);                                                                                      \
+    else if (tid < 96) {                                                                                               \
+      _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                                  \
+        const int dd = 2 * (tid & 31) + e;                                                                             \
+        const float val = __uint_as_float(v[e]);                                                                       \
+        if (tid < 64) /* K row `step`, blocked [blk][d/8][key%64][8] */                                                \
+          sK[(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (h16)val;                            \
+        else          /* V row `step`, TRANSPOSED per block: [blk][key%64 / 8][dim][8 keys] */                         \
+          sV[(step >> 6) * 4096 + ((step >> 3) & 7) * 512 + dd * 8 + (step & 7)] = (h16)val;                           \
+      }                                                                                                                \
+    }                                                                                                                  \
+    if (fail) ctl[0] = 1;                                                                                              \
+    AXW_STAMP(2)                                                                                                       \
+    AXW_BARRIER_CHECK(0x200 + l)                                                                                       \
+    AXW_STAMP(3)                                                                                                       \
+  }
         // ---- QKV
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -215,38 +252,12 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_LN_STAGE(y, l > 0, fail, 0x100 + l, c)
           AXW_STAMP(1)
           AXW_TL(1)
+          if (c == 0 && l == sa_layer && sa_first) AXW_SA0_POLL
         }
         ln_prefetch(FL + DecArena::F_CROSS_LN_W * D, FL + DecArena::F_CROSS_LN_B * D);
-        // ---- self-attention owner: collect q, k, v of the head; append k, v to the cache (clip 0: LDS, clip 1: global memory)
+        // ---- self-attention owner (clip 0: LDS cache, clip 1: global memory)
         if (l == sa_layer) {
-          // lanes 0-31: q, 32-63: k, 64-95: v of the head, two adjacent dims each
-          auto qkv_pair = [&](int c) { return [&, c](int) { return tid < 96 ? c * gco + O_QKV + (tid >> 5) * D + sa_head * 64 + 2 * (tid & 31) : -1; }; };
-          auto stage_q = [&](const unsigned (&v)[2], unsigned* q) {  // dims 2 tid, 2 tid + 1 as one packed (hi, lo) pair
-            unsigned hi, lo;
-            h16split2(__uint_as_float(v[0]), __uint_as_float(v[1]), hi, lo);
-            q[tid] = hi;
-            q[32 + tid] = lo;
-          };
-          {  // clip 0: its cache is the LDS region, its blocks are the compute waves'
-            unsigned v[2];
-            const bool fail = gather2<1>(GR, tag, v, p.err, ctl, qkv_pair(0));
-            if (tid < 32) stage_q(v, qs);
-            else if (tid < 96) {
-#pragma unroll
-              for (int e = 0; e < 2; ++e) {
-                const int dd = 2 * (tid & 31) + e;
-                const float val = __uint_as_float(v[e]);
-                if (tid < 64)  // K row `step`, blocked [blk][d/8][key%64][8]
-                  sK[(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (h16)val;
-                else           // V row `step`, TRANSPOSED per block: [blk][key%64 / 8][dim][8 keys]
-                  sV[(step >> 6) * 4096 + ((step >> 3) & 7) * 512 + dd * 8 + (step & 7)] = (h16)val;
-              }
-            }
-            if (fail) ctl[0] = 1;
-            AXW_STAMP(2)
-            AXW_BARRIER_CHECK(0x200 + l)
-            AXW_STAMP(3)
-          }
+          if (!sa_first) AXW_SA0_POLL
           if constexpr (NC == 2) {
             // Clip 1's cache lives in global memory (there is one LDS region, and it is clip 0's). Its blocks are run by the POLLER
             // waves — eight of them, with registers to spare, idle while the compute waves run clip 0's blocks: each requests its
@@ -328,6 +339,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
             AXW_BARRIER_CHECK(0x300 + l)
           }
         }
+        const int cu = ca_unit_of(step * L + l);
         // ---- cross-attention query
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -338,25 +350,25 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_LN_STAGE(y, true, fail, 0x400 + l, c)
           AXW_STAMP(6)
           AXW_TL(4)
+          // ---- cross-attention unit of THIS clip: collect the head's query (a unit of clip 0 runs before clip 1's query rows:
+          //      its query is already on its way, and nothing it needs waits behind the other clip's LayerNorm)
+          if (cu >= 0 && cu / NU == c) {
+            const int ca_clip = cu / NU, ca_head = (cu % NU) / kCrossSplit;
+            unsigned v[2];
+            const bool fail = gather2<1>(GR, tag, v, p.err, ctl, [&](int) { return tid < 32 ? ca_clip * gco + O_CQ + ca_head * 64 + 2 * tid : -1; });
+            if (tid < 32) {
+              unsigned hi, lo;
+              h16split2(__uint_as_float(v[0]), __uint_as_float(v[1]), hi, lo);
+              qs[tid] = hi;
+              qs[32 + tid] = lo;
+            }
+            if (fail) ctl[0] = 1;
+            AXW_STAMP(7)
+            AXW_BARRIER_CHECK(0x500 + l)
+            AXW_STAMP(8)
+          }
         }
         ln_prefetch(FL + DecArena::F_MLP_LN_W * D, FL + DecArena::F_MLP_LN_B * D);
-        // ---- cross-attention unit: collect the head's query
-        const int cu = ca_unit_of(step * L + l);
-        if (cu >= 0) {
-          const int ca_clip = cu / NU, ca_head = (cu % NU) / kCrossSplit;
-          unsigned v[2];
-          const bool fail = gather2<1>(GR, tag, v, p.err, ctl, [&](int) { return tid < 32 ? ca_clip * gco + O_CQ + ca_head * 64 + 2 * tid : -1; });
-          if (tid < 32) {
-            unsigned hi, lo;
-            h16split2(__uint_as_float(v[0]), __uint_as_float(v[1]), hi, lo);
-            qs[tid] = hi;
-            qs[32 + tid] = lo;
-          }
-          if (fail) ctl[0] = 1;
-          AXW_STAMP(7)
-          AXW_BARRIER_CHECK(0x500 + l)
-          AXW_STAMP(8)
-        }
         // ---- cross-attention output projection: merge the partials of every head
         if (in_o) {
 #pragma unroll
@@ -502,6 +514,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
       }
     }
 #undef AXW_LN_STAGE
+#undef AXW_SA0_POLL
 #undef AXW_PAIRS_D
   } else {
     // ======================================================================================= compute waves
@@ -521,7 +534,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     // the busiest: their mlp.0 rows could only be requested after their cross-attention-output publish, ~2 us before
     // use, and arrived late — every consumer of the hidden vector waited for them: 1.2 us of skew per layer).
     const int pk_f = (NP_D + NP_F <= P && NP_Q <= P && NP_D + NP_F + NP_Q >= P) ? NP_D : ((NP_F <= P && NP_Q <= P && NP_F + NP_Q >= P) ? 0 : -1);
-    const bool is_fc1 = pk_f < 0 || (wg >= pk_f && wg < pk_f + NP_F);
+    const bool is_fc1 = pk_f < 0 || (rwg >= pk_f && rwg < pk_f + NP_F);
     // its mlp.2 rows can be requested a phase earlier (no mlp.0 rows in the way); not for wide models: 10 chunks per lane
     // held across the mlp.0 phase do not fit the register budget (the d=1280 instantiation went to scratch)
     constexpr bool kEarlyFc2 = NC == 1 && CF <= 6;
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     // in the other (qkv A, o B, cq A, co B, mlp.0 A, [mlp.2 F], next qkv / vocabulary A)
     RowSet<LD, CD> ra, rb;
     RowSet<LF, CF> rs_fc2;
-    ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid, pk_qkv);
+    ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, rwg, P, ctid, pk_qkv);
     {  // the first layer's cross-attention unit has no previous layer to hide behind
       const int cu0 = ca_unit_of(0);
       if (cu0 >= 0) {  // its K tiles; the V tiles are layer 0's own pieces
@@ -576,6 +589,26 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)dst, 16, 0, kKvAux);
           }
         };
+        // self-attention of one head over keys 0..step (export_onnx.py:103-147: the -60000 mask + the separate current-token
+        // column of the reference equal causal attention), clip 0: the LDS cache. No second workgroup barrier: the compute wave
+        // that arrives last merges the block partials and publishes.
+#define AXW_SA0_COMP                                                                                                   \
+  {                                                                                                                    \
+    AXW_BARRIER_CHECK(0x200 + l)                                                                                       \
+    const int nblk = (step >> 6) + 1;                                                                                  \
+    if (cw < nblk) attn_block<true>(sK + cw * 4096, sV + cw * 4096, qs, cw * 64 + lane <= step, pscr + cw * 64, wpart + cw * kPS, lane); \
+    __builtin_amdgcn_wave_barrier();                                                                                   \
+    int old = 0;                                                                                                       \
+    if (lane == 0) old = __hip_atomic_fetch_add(ctl + 3, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);           \
+    old = __builtin_amdgcn_readfirstlane(old);                                                                         \
+    if ((old + 1) % NCW == 0) {                                                                                        \
+      float m, lt, ov;                                                                                                 \
+      merge_partials(wpart, nblk, lane, &m, &lt, &ov);                                                                 \
+      gput(G + O_ATT + sa_head * 64 + lane, tag, ov / lt);                                                             \
+    }                                                                                                                  \
+    AXW_STAMP(18)                                                                                                      \
+    AXW_TL(11)                                                                                                         \
+  }
         // ---- QKV rows (export_onnx.py:245-247)
         float res[2];
 #pragma unroll
@@ -587,38 +620,17 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           ra.run(w_qkv, b_qkv, D, actc[c], ctid, res);
           ra.publish(ctid, res, pk, ctl + 2, G + c * gco + O_QKV, tag, [](float v) { return v; });
           if (c == 0) {  // the next phase's rows are requested behind the FIRST clip's publish: they land under the second clip's rows
-            rb.prefetch(w_o, b_o, D, D, wg, P, ctid, pk_d);
-            kv_piece(8, 10);
+            rb.prefetch(w_o, b_o, D, D, rwg, P, ctid, pk_d);
+            kv_piece(8, 11);
           }
           AXW_STAMP(17)
           AXW_TL(10)
+          if (c == 0 && l == sa_layer && sa_first) AXW_SA0_COMP
         }
-        // ---- self-attention of one head over keys 0..step (export_onnx.py:103-147: the -60000 mask + the separate
-        //      current-token column of the reference equal causal attention)
+        // ---- self-attention (clip 1's blocks are the poller waves' — see there: only the hand-over of its query is shared)
         if (l == sa_layer) {
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const int nblk = (step >> 6) + 1;
-            if (c == 0) {
-              AXW_BARRIER_CHECK(0x200 + l)
-              if (cw < nblk) attn_block<true>(sK + cw * 4096, sV + cw * 4096, qs, cw * 64 + lane <= step, pscr + cw * 64, wpart + cw * kPS, lane);
-            } else {  // clip 1's blocks are the poller waves' (see there): only the hand-over of its query is shared
-              AXW_BARRIER_CHECK(0x200 + l)
-              continue;
-            }
-            // no second workgroup barrier: the compute wave that arrives last merges the block partials and publishes
-            __builtin_amdgcn_wave_barrier();
-            int old = 0;
-            if (lane == 0) old = __hip_atomic_fetch_add(ctl + 3, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            old = __builtin_amdgcn_readfirstlane(old);
-            if ((old + 1) % NCW == 0) {
-              float m, lt, ov;
-              merge_partials(wpart, nblk, lane, &m, &lt, &ov);
-              gput(G + c * gco + O_ATT + sa_head * 64 + lane, tag, ov / lt);
-            }
-            AXW_STAMP(18)
-            AXW_TL(11)
-          }
+          if (!sa_first) AXW_SA0_COMP
+          if constexpr (NC == 2) AXW_BARRIER_CHECK(0x200 + l)
         }
         // ---- attention output projection
         if (in_o) {
@@ -631,8 +643,8 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
             rb.publish(ctid, res, pk, ctl + 2, G + c * gco + O_Y1, tag, [](float v) { return v; });
           }
         }
-        ra.prefetch(w_cq, b_cq, D, D, wg, P, ctid, pk_d);
-        kv_piece(10, 13);
+        ra.prefetch(w_cq, b_cq, D, D, rwg, P, ctid, pk_d);
+        kv_piece(11, 16);
         AXW_STAMP(20)
         AXW_TL(12)
         // ---- cross-attention query (export_onnx.py:221-230)
@@ -644,38 +656,35 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_TL(20)
           ra.run(w_cq, b_cq, D, actc[c], ctid, res);
           ra.publish(ctid, res, pk, ctl + 2, G + c * gco + O_CQ, tag, [](float v) { return v; });
-          if (c == 0) {
-            rb.prefetch(w_co, b_co, D, D, wg, P, ctid, pk_d);
-            kv_piece(13, 16);
-          }
+          if (c == 0) rb.prefetch(w_co, b_co, D, D, rwg, P, ctid, pk_d);
           AXW_STAMP(22)
           AXW_TL(13)
-        }
-        // ---- cross-attention over one third of the 1536 padded keys
-        if (cu >= 0) {
-          const int ca_clip = cu / NU, ca_head = (cu % NU) / kCrossSplit, ca_split = cu % kCrossSplit;
-          AXW_BARRIER_CHECK(0x500 + l)
-          // this wave's own K/V tiles have landed. The builtin, not inline asm: behind an asm that may touch the counters the
-          // compiler drains vmcnt at every following join (measured: +18 ms on Whisper-small for one such asm in a cold path)
-          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-          asm volatile("" ::: "memory");
-          const int key = (ca_split * NCW + cw) * 64 + lane;
-          attn_block<false>(sK + cw * 4096, sV + cw * 4096, qs, key < p.n_audio_ctx, pscr + cw * 64, wpart + cw * kPS, lane);
-          __builtin_amdgcn_wave_barrier();
-          int old = 0;
-          if (lane == 0) old = __hip_atomic_fetch_add(ctl + 3, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-          old = __builtin_amdgcn_readfirstlane(old);
-          if ((old + 1) % NCW == 0) {  // the wave that arrives last merges and publishes
-            const int ctid = lane;
-            float m, lt, ov;
-            merge_partials(wpart, NCW, ctid, &m, &lt, &ov);
-            // one 64-lane store of o (four full lines) + one 2-lane store of (m, l)
-            u64* out = G + ca_clip * gco + O_PART + (ca_head * kCrossSplit + ca_split) * kRec;
-            gput(out + ctid, tag, ov);
-            if (ctid < 2) gput(out + 64 + ctid, tag, ctid == 0 ? m : lt);
+          // ---- cross-attention over one third of the 1536 padded keys: the unit of THIS clip, if this workgroup holds one
+          if (cu >= 0 && cu / NU == c) {
+            const int ca_clip = cu / NU, ca_head = (cu % NU) / kCrossSplit, ca_split = cu % kCrossSplit;
+            AXW_BARRIER_CHECK(0x500 + l)
+            // this wave's own K/V tiles have landed. The builtin, not inline asm: behind an asm that may touch the counters the
+            // compiler drains vmcnt at every following join (measured: +18 ms on Whisper-small for one such asm in a cold path)
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            asm volatile("" ::: "memory");
+            const int key = (ca_split * NCW + cw) * 64 + lane;
+            attn_block<false>(sK + cw * 4096, sV + cw * 4096, qs, key < p.n_audio_ctx, pscr + cw * 64, wpart + cw * kPS, lane);
+            __builtin_amdgcn_wave_barrier();
+            int old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(ctl + 3, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if ((old + 1) % NCW == 0) {  // the wave that arrives last merges and publishes
+              const int ctid = lane;
+              float m, lt, ov;
+              merge_partials(wpart, NCW, ctid, &m, &lt, &ov);
+              // one 64-lane store of o (four full lines) + one 2-lane store of (m, l)
+              u64* out = G + ca_clip * gco + O_PART + (ca_head * kCrossSplit + ca_split) * kRec;
+              gput(out + ctid, tag, ov);
+              if (ctid < 2) gput(out + 64 + ctid, tag, ctid == 0 ? m : lt);
+            }
+            AXW_STAMP(23)
+            AXW_TL(14)
           }
-          AXW_STAMP(23)
-          AXW_TL(14)
         }
         // ---- cross-attention output projection
         if (in_o) {
@@ -700,9 +709,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
             rb.publish(ctid, res, pk, ctl + 2, G + c * gco + O_Y2, tag, [](float v) { return v; });
           }
         }
-        ra.prefetch(w_fc1, b_fc1, D, F, wg, P, ctid, pk_f);
+        ra.prefetch(w_fc1, b_fc1, D, F, rwg, P, ctid, pk_f);
         if constexpr (kEarlyFc2) {
-          if (early_fc2) rs_fc2.prefetch(w_fc2, b_fc2, F, D, wg, P, ctid, pk_d);
+          if (early_fc2) rs_fc2.prefetch(w_fc2, b_fc2, F, D, rwg, P, ctid, pk_d);
         }
         kv_piece(0, 3);
         AXW_STAMP(25)
@@ -719,7 +728,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           if (c == 0) kv_piece(3, 5);
           // (behind the LAST clip's publish: next to the mlp.0 rows, which the second clip still needs, the 6 chunks per lane of
           //  the mlp.2 rows do not fit the register budget — as loads followed by vmcnt(0) + a scratch store they cost 2 us per layer)
-          if (c == NC - 1 && !early_fc2) rs_fc2.prefetch(w_fc2, b_fc2, F, D, wg, P, ctid, pk_d);
+          if (c == NC - 1 && !early_fc2) rs_fc2.prefetch(w_fc2, b_fc2, F, D, rwg, P, ctid, pk_d);
           AXW_STAMP(27)
           AXW_TL(16)
         }
@@ -748,9 +757,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           }
         }
         // next consumer of the residual stream: the next layer's QKV rows, the vocabulary projection, or the next step
-        if (l + 1 < L) ra.prefetch(w_qkv + DecArena::w_stride(D), b_qkv + DecArena::f_stride(D), D, 3 * D, wg, P, ctid, pk_qkv);
-        else if (step >= 3) ra.prefetch(AXW_COLD(tok_emb), nullptr, D, AXW_COLD(n_vocab), wg, P, ctid);
-        else ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid, pk_qkv);
+        if (l + 1 < L) ra.prefetch(w_qkv + DecArena::w_stride(D), b_qkv + DecArena::f_stride(D), D, 3 * D, rwg, P, ctid, pk_qkv);
+        else if (step >= 3) ra.prefetch(AXW_COLD(tok_emb), nullptr, D, AXW_COLD(n_vocab), rwg, P, ctid);
+        else ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, rwg, P, ctid, pk_qkv);
         kv_piece(5, 8);
         AXW_STAMP(29)
         AXW_TL(17)
@@ -828,7 +837,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           }
         }
         // the next step's first rows: requested before the token is even known
-        ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, wg, P, ctid, pk_qkv);
+        ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, rwg, P, ctid, pk_qkv);
         // workgroup argmax: lanes with j == 0 hold candidates; the lower index wins ties
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -893,6 +902,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     AXW_COLD(state)->step = steps_run;
     AXW_COLD(state)->n_done = n_done;
   }
+#undef AXW_SA0_COMP
 #undef AXW_COLD
 #undef AXW_BARRIER_CHECK
 #undef AXW_STAMP

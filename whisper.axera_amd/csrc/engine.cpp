@@ -1200,7 +1200,7 @@ int Engine::greedy_loop(int batch, int max_new, const int* max_new_clip) {
   const int Tc = cfg_.n_text_ctx;
   if (max_new <= 0 || max_new > Tc - 4) max_new = Tc - 4;
   // One clip: the persistent launch. Two clips: ONE two-clip persistent launch, phase by phase (one clip's rows are computed
-  // while the other's hand-off is in flight; decode_persistent2.hip) — Whisper-small, 444 ids per clip: 140 ms per pair
+  // while the other's hand-off is in flight; decode_persistent2.hip) — Whisper-small, 444 ids per clip: 134 ms per pair
   // against 2 x 116 ms for one launch per clip (shapes without a two-clip launch, AX_WHISPER_PERSIST2=0) and 316 ms through
   // the launch-per-phase path, which wins from 3 clips on (244 ms). Each clip stops at its own eot / budget.
   if (batch == 2 && persistent2_ok_ && persistent_usable()) {
