@@ -675,25 +675,26 @@ def run_rank(args) -> int:
                 leg["clip0_ids_equal_batch1"] = ids2[0] == ids[0]
                 out["batch64"] = leg
             if not args.no_batch64 and args.max_new == 0:
-                # two clips per call = both greedy loops in ONE persistent launch (decode_persistent2.hip): the low-load end of a server
-                leg, idsp = batch_leg(torch, dev, dev_index, sync, "small", dtype, 2, n2, 0, args.model_dir, rooflines=False)
-                leg["clip0_ids_equal_batch1"] = idsp[0] == ids[0]
-                # algorithmic bytes of the pair's ONE launch: the decoder-layer weights and the vocabulary projection stream once
-                # per step for BOTH clips, cross K/V once per clip; clip 1's self-attention cache is read from global memory
-                # (clip 0's lives in LDS). Duration: the engine's hipEvents around the launch (stage "decode").
-                d_, L_, nv_, s_ = dims["d"], dims["dec_layers"], dims["n_vocab"], 2
-                n_st = int(round(len(idsp[0]) + 4))
-                b2 = n_st * (s_ * L_ * 14 * d_ * d_ + 2 * s_ * 2 * L_ * 1500 * d_) + max(n_st - 3, 0) * s_ * nv_ * d_ \
-                    + sum(s_ * 2 * L_ * (t + 1) * d_ for t in range(n_st))
-                l_s = leg["stage_ms"]["decode_ms"] * 1e-3
-                pmc2, src2 = load_pmc("small", 2)
-                leg["roofline"] = {"kernel": "decode_persistent_kernel<..., 2> (both greedy loops of a pair of clips: %d decoder steps in one launch)" % n_st,
-                                   "bound": "hbm", "achieved": round(b2 / l_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(b2 / l_s / 1e9 / HBM_PEAK_GBS, 4),
-                                   "traffic": (pmc2.get("decode_persistent_kernel") or {}).get("hbm_bytes_per_launch"),
-                                   "launch_ms": round(l_s * 1e3, 3), "bytes_per_launch": int(b2),
-                                   "us_per_decode_step": round(l_s * 1e6 / n_st, 2)}
-                out["batch2"] = leg
+                # two / three clips per call = their greedy loops in ONE persistent launch (decode_persistent2.hip): the low-load end
+                # of a server. Algorithmic bytes of that launch: the decoder-layer weights and the vocabulary projection stream once
+                # per step for ALL its clips, cross K/V once per clip; the later clips' self-attention caches are read from global
+                # memory (clip 0's lives in LDS). Duration: the engine's hipEvents around the launch (stage "decode").
+                for nb in (2, 3):
+                    leg, idsp = batch_leg(torch, dev, dev_index, sync, "small", dtype, nb, n2, 0, args.model_dir, rooflines=False)
+                    leg["clip0_ids_equal_batch1"] = idsp[0] == ids[0]
+                    d_, L_, nv_, s_ = dims["d"], dims["dec_layers"], dims["n_vocab"], 2
+                    n_st = int(round(len(idsp[0]) + 4))
+                    bts = n_st * (s_ * L_ * 14 * d_ * d_ + nb * s_ * 2 * L_ * 1500 * d_) + max(n_st - 3, 0) * s_ * nv_ * d_ \
+                        + (nb - 1) * sum(s_ * 2 * L_ * (t + 1) * d_ for t in range(n_st))
+                    l_s = leg["stage_ms"]["decode_ms"] * 1e-3
+                    pmcn, _ = load_pmc("small", nb)
+                    leg["roofline"] = {"kernel": "decode_persistent_kernel<..., %d> (the greedy loops of %d clips: %d decoder steps in one launch)" % (nb, nb, n_st),
+                                       "bound": "hbm", "achieved": round(bts / l_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(bts / l_s / 1e9 / HBM_PEAK_GBS, 4),
+                                       "traffic": (pmcn.get("decode_persistent_kernel") or {}).get("hbm_bytes_per_launch"),
+                                       "launch_ms": round(l_s * 1e3, 3), "bytes_per_launch": int(bts),
+                                       "us_per_decode_step": round(l_s * 1e6 / n_st, 2)}
+                    out["batch%d" % nb] = leg
             if not args.no_realistic and args.max_new == 0:
                 # realistic utterance lengths (SURVEY §8d asks for them beside the full context): every clip of the 64 leaves the
                 # loop at its own budget of 60-150 ids; then the same workload through the slot scheduler (384 clips, 64 slots)

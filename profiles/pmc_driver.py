@@ -28,6 +28,6 @@ if B == 1:  # the persistent batch-1 decode launch: one whole utterance (448 ste
     import numpy as np
 
     e.run_tokens(modelgen.synth_clip(0, 480000))
-if B == 2:  # the two-clip persistent launch: a pair of whole utterances = one launch
-    e.run_tokens_batch([modelgen.synth_clip(0, 480000), modelgen.synth_clip(1, 480000)])
+if B in (2, 3):  # the multi-clip persistent launch: two or three whole utterances = one launch
+    e.run_tokens_batch([modelgen.synth_clip(i, 480000) for i in range(B)])
 e.close()

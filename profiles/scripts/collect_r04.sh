@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 4's evidence on the MI355X box (profiles/README.md). usage: collect_r04.sh b1 | b2 | b64 | extra   (one gpurun call each)
+# Round 4's evidence on the MI355X box (profiles/README.md). usage: collect_r04.sh b1 | b2 | b3 | b64 | extra   (one gpurun call each)
 # Results land in gpurun_out/prof4/; what is to be judged is copied into profiles/ as r04_* (profiles/scripts/install_r04.sh).
 set -o pipefail
 OUT=$PWD/gpurun_out/prof4
@@ -40,6 +40,13 @@ b2)
   python profiles/persist_prof.py $OUT/pp2_c1.txt > $OUT/persist2_phases_summary_clip1.txt || exit 1
   python bench.py --batch 2 --steps 5 --warmup 2 --no-extras --no-cpu-baseline > $OUT/bench_b2.json 2> $OUT/bench_b2.err || exit 1
   ;;
+b3)
+  # three clips per call = one three-clip persistent launch: kernel stats, PMC traffic, the line bench.py prints, a soak of ragged triples
+  stats b3 "AXW_NOP=1" --batch 3 --steps 4 --warmup 2 --no-extras || exit 1
+  pmc small_b3 3 || exit 1
+  python bench.py --batch 3 --steps 5 --warmup 2 --no-extras --no-cpu-baseline > $OUT/bench_b3.json 2> $OUT/bench_b3.err || exit 1
+  python profiles/scripts/soak_persistent2.py 40 small 3 > $OUT/soak_persistent3.txt 2>&1 || exit 1
+  ;;
 b64)
   stats b64 "AXW_NOP=1" --batch 64 --steps 1 --warmup 1 --no-extras || exit 1
   stats b64_1branch "AX_WHISPER_DECODE_BRANCHES=1" --batch 64 --steps 1 --warmup 1 --no-extras || exit 1
@@ -57,7 +64,7 @@ extra)
   python bench.py --model turbo --batch 16 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_turbo_fp16_b16.json 2> $OUT/bench_turbo_b16.err || exit 1
   python bench.py --model turbo --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_turbo_fp16_b1.json 2> $OUT/bench_turbo_b1.err || exit 1
   ;;
-*) echo "usage: collect_r04.sh b1|b2|b64|extra"; exit 2;;
+*) echo "usage: collect_r04.sh b1|b2|b3|b64|extra"; exit 2;;
 esac
 cp profiles/r04_pmc_traffic.json $OUT/r04_pmc_traffic.json
 ls -la $OUT

@@ -6,7 +6,7 @@ tests/eot_case.py shapes a seeded model until the oracle's greedy run emits eot 
 Checked per path: the number of ids, every id, that eot itself is not among them (Whisper.cpp:220 pushes the token before
 the step that produces eot), and — slot stream — that the slot is reported finished, handed back and refilled.
 
-  persistent launch (1 clip, and 2 clips = two launches)          decode_persistent.hip:758,1075
+  persistent launches (1 clip; 2 and 3 clips = one multi-clip launch)   decode_persistent.hip, decode_persistent2.hip
   launch-per-phase path / GEMV family (AX_WHISPER_DECODE=graph)   advance_kernel, decode_gemv.hip
   clip-block sequence, 3 / 6 / 20 / 64 clips (1 and 2 graph branches, 1-4 clip blocks)
   split-K sequence (AX_WHISPER_BATCHED_LN=0; the d_model > 1024 path) at 6 clips, and at d = 1280 in fp16
@@ -41,7 +41,7 @@ def _check(case, got, want, what):
         assert case.eot not in g
 
 
-@pytest.mark.parametrize("mode,batch", [("persistent", 1), ("persistent", 2), ("graph", 1), ("graph", 2), ("cblock", 3), ("cblock", 6),
+@pytest.mark.parametrize("mode,batch", [("persistent", 1), ("persistent", 2), ("persistent", 3), ("graph", 1), ("graph", 2), ("cblock", 3), ("cblock", 6),
                                         ("cblock", 20), ("cblock", 64), ("splitk", 6)])
 def test_loop_ends_on_eot(built_lib, micro_eot, monkeypatch, mode, batch):
     case = micro_eot
@@ -49,14 +49,16 @@ def test_loop_ends_on_eot(built_lib, micro_eot, monkeypatch, mode, batch):
         monkeypatch.setenv("AX_WHISPER_DECODE", "graph")
     if mode == "splitk":
         monkeypatch.setenv("AX_WHISPER_BATCHED_LN", "0")
+    if mode == "cblock" and batch == 3:
+        monkeypatch.setenv("AX_WHISPER_PERSIST2", "2")   # three clips through the clip-block sequence (default: one three-clip launch)
     _, clips, want = case.sel
     e = built_lib.Whisper("micro", case.root, "zh", device=0, max_batch=batch)
     try:
         g = lambda k: e.L.AX_WHISPER_GetConfigInt(e.h, k.encode())
         assert g("persistent_decode") == (0 if mode == "graph" else 1)
         assert g("batched_ln") == (0 if mode == "splitk" else 1)
-        if batch <= 2:  # one clip after the other through the same slot(s), so a second run starts from a used state
-            for b0 in range(0, 8, batch):
+        if mode == "persistent" or batch <= 2:  # one group after the other through the same slot(s), so a second run starts from a used state
+            for b0 in range(0, 9 - batch, batch):
                 mels = np.stack([e.compute_mel(c) for c in clips[b0:b0 + batch]])
                 e.encode_mel(mels)
                 _check(case, e.decode_greedy(batch, max_new=case.budget), want[b0:b0 + batch], f"{mode} clips {b0}..")

@@ -208,3 +208,45 @@ def test_two_clip_launch_equals_one_clip_launches(built_lib, tmp_path, monkeypat
         assert e.decode_greedy(2, max_new=max_new) == single[:2]
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("model_type,seed,max_new", [("micro", 41, 30), ("tiny", 42, 70), ("small", 43, 100)])
+def test_three_clip_launch_equals_one_clip_launches(built_lib, tmp_path, monkeypatch, model_type, seed, max_new):
+    """Three clips per call: ONE three-clip persistent launch (3 x 36 one-clip cross-attention units per layer on the 112
+    workgroups without a head; the caches of clips 1 and 2 in global memory, their blocks run by the poller waves one clip
+    after the other). ids of a triple EQUAL the ids of its clips decoded alone, in every order, with per-clip budgets;
+    AX_WHISPER_PERSIST2=2 sends three clips through the clip-block sequence as before."""
+    import itertools
+
+    import modelgen
+
+    case = ModelCase(tmp_path, model_type, seed)
+    clips = [load_demo_pcm(), modelgen.synth_clip(seed, 200000), modelgen.synth_clip(seed + 1, 90000)]
+    e = built_lib.Whisper(model_type, case.root, "zh", device=0, max_batch=3)
+    try:
+        assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_max_clips") == 3
+        mels = np.stack([e.compute_mel(c) for c in clips])
+        single = []
+        for m in mels:
+            e.encode_mel(m)
+            single.append(e.decode_greedy(1, max_new=max_new)[0])
+        for order in list(itertools.permutations(range(3)))[:4] + [(1, 1, 2)]:
+            e.encode_mel(np.stack([mels[i] for i in order]))
+            for _ in range(2):
+                assert e.decode_greedy(3, max_new=max_new) == [single[i] for i in order], order
+        cut = [max_new // 3, max_new - 1, 2]
+        e.encode_mel(mels)
+        assert e.decode_greedy(3, max_new=max_new, max_new_clip=cut) == [single[i][:cut[i]] for i in range(3)]
+        assert e.run_tokens_batch(clips, max_new=12) == [s[:12] for s in single]
+        assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_giveups") == 0
+    finally:
+        e.close()
+    monkeypatch.setenv("AX_WHISPER_PERSIST2", "2")
+    e = built_lib.Whisper(model_type, case.root, "zh", device=0, max_batch=3)
+    try:
+        assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_max_clips") == 2
+        e.encode_mel(mels)
+        got = e.decode_greedy(3, max_new=max_new)   # clip-block sequence: same ids up to numerical ties
+        assert [len(g) for g in got] == [len(s) for s in single]
+    finally:
+        e.close()

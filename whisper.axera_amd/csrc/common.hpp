@@ -420,13 +420,15 @@ struct PersistParams {
   h16* self_k1; h16* self_v1;
   long gran_clip_u64;
   int* out_ids1; int* n_out1; int max_new1;
+  // three clips (n_clip == 3): clip 2's ids at out_ids1 + n_ctx, its count at n_out1 + 1, its self cache self_clip_stride elements on
+  int max_new2; long self_clip_stride;
 };
 bool decode_persistent_supported(int d_model, int n_head, int n_layer, int n_cu);
 int decode_persistent_grid(int d_model, int n_cu);
 size_t decode_persistent_gran_bytes(int d_model, int grid);   // granule area; the error word sits in its last 8 bytes
 hipError_t launch_decode_persistent(const PersistParams& p, int d_model, int grid, hipStream_t s);
 hipError_t launch_decode_persistent2(const PersistParams& p, int d_model, int grid, hipStream_t s);  // n_clip == 2 (decode_persistent2.hip)
-bool decode_persistent_two_clips_supported(int d_model, int n_head, int n_layer, int grid);  // shapes whose every linear layer is ONE pass of rows per workgroup
+int decode_persistent_max_clips(int d_model, int n_head, int n_layer, int grid);  // clips per persistent launch: 1, 2 or 3  // shapes whose every linear layer is ONE pass of rows per workgroup
 
 // weight preparation (device): raw file dtype -> h16 / fp32, with the layout changes the kernels want
 void launch_convert_to_h16(const void* src, int src_dtype /*0 f32,1 bf16,2 f16*/, h16* dst, long n, hipStream_t s);

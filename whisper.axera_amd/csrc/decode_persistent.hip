@@ -743,7 +743,7 @@ static hipError_t launch_one(const PersistParams& p, int grid, hipStream_t s) {
 }
 
 hipError_t launch_decode_persistent(const PersistParams& p, int d_model, int grid, hipStream_t s) {
-  if (p.n_clip == 2) return launch_decode_persistent2(p, d_model, grid, s);  // decode_persistent2.hip
+  if (p.n_clip >= 2) return launch_decode_persistent2(p, d_model, grid, s);  // two or three clips: decode_persistent2.hip
   switch (d_model) {
     case 128: return launch_one<16, 1, 32, 2>(p, grid, s);
     case 256: return launch_one<32, 1, 64, 2>(p, grid, s);

@@ -28,7 +28,7 @@ inline namespace AXW_NS {
 // LDS vectors (mlp hidden, cross-attention partial records) are shared and handed over with one more barrier.
 template <int LD, int CD, int LF, int CF, bool PROF, int NC>
 __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) {
-  static_assert(NC == 1 || NC == 2, "one or two clips per launch");
+  static_assert(NC == 2 || NC == 3, "two or three clips per launch");
   constexpr int D = 8 * LD * CD, F = 8 * LF * CF, H = D / 64;
   static_assert(F == 4 * D, "mlp width");
   // a poller lane owns PAIRS of adjacent vector elements: pair tid + j*PL (j < GPD) = elements 2*pair, 2*pair + 1
@@ -56,14 +56,26 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   float* pk = reinterpret_cast<float*>(ctl + 16);            // [64] this workgroup's rows of the phase, assembled for the one-instruction publish
   float* pscr = pk + 64;                                     // [NCW][64] probability transpose scratch
   long long* prof_acc = reinterpret_cast<long long*>(pscr + NCW * 64);  // [64] per-phase time sums + one layer's absolute timeline (profiling runs only)
-  // clip 1's copies of the d-wide input vector and of the attention query (NC == 2 only: persist_lds_bytes)
-  float* act1 = reinterpret_cast<float*>(prof_acc + 64);
-  unsigned* qs1 = reinterpret_cast<unsigned*>(act1 + D);
-  float* const actc[2] = {act, NC == 2 ? act1 : act};
-  unsigned* const qsc[2] = {qs, NC == 2 ? qs1 : qs};
-  h16* kvt = reinterpret_cast<h16*>(qs1 + 64 + 32);  // [128] clip 1's k (64 dims) and v (64 dims) of the CURRENT step (behind its argmax scratch)
-  float* wpart1 = reinterpret_cast<float*>(qs1 + 64 + 32 + 64);  // [NPW][kPS] + [NPW][64]: the poller waves' own attention scratch (they run
-  float* pscr1 = wpart1 + NPW * kPS;                             //  clip 1's self-attention blocks while the compute waves run clip 0's)
+  // every clip after the first: its own d-wide input vector [D], attention query [64], argmax scratch [32] and the self-attention
+  // k, v rows of its CURRENT step [64 words = 128 h16] (persist2_lds_bytes)
+  constexpr int XW = D + 64 + 32 + 64;
+  float* const xbase = reinterpret_cast<float*>(prof_acc + 64);
+  float* actc[NC];
+  unsigned* qsc[NC];
+  float* am_vc[NC];
+  int* am_ic[NC];
+  h16* kvtc[NC];
+  actc[0] = act; qsc[0] = qs; am_vc[0] = am_v; am_ic[0] = am_i; kvtc[0] = nullptr;
+#pragma unroll
+  for (int c = 1; c < NC; ++c) {
+    actc[c] = xbase + (c - 1) * XW;
+    qsc[c] = reinterpret_cast<unsigned*>(actc[c] + D);
+    am_vc[c] = reinterpret_cast<float*>(qsc[c] + 64);
+    am_ic[c] = reinterpret_cast<int*>(qsc[c] + 64) + 16;
+    kvtc[c] = reinterpret_cast<h16*>(qsc[c] + 64 + 32);
+  }
+  float* wpart1 = xbase + (NC - 1) * XW;  // [NPW][kPS] + [NPW][64]: the poller waves' own attention scratch (they run the later clips'
+  float* pscr1 = wpart1 + NPW * kPS;      //  self-attention blocks while the compute waves run clip 0's)
 
   // tid is re-derived behind an opaque asm at the top of every layer: without it the compiler hoists every
   // per-thread address of every phase out of the step loop and keeps >100 registers of loop invariants alive
@@ -72,8 +84,8 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   const int P = gridDim.x, wg = blockIdx.x;
   const int L = p.n_layer;
   u64* const G = p.gran;
-  const __amdgpu_buffer_rsrc_t GR = __builtin_amdgcn_make_buffer_rsrc((void*)p.gran, 0, NC == 2 ? (int)(p.gran_clip_u64 * 8) + p.gran_bytes : p.gran_bytes, 0x27000);
-  const int gco = NC == 2 ? (int)p.gran_clip_u64 : 0;  // granule index of clip 1's area
+  const __amdgpu_buffer_rsrc_t GR = __builtin_amdgcn_make_buffer_rsrc((void*)p.gran, 0, (NC - 1) * (int)(p.gran_clip_u64 * 8) + p.gran_bytes, 0x27000);
+  const int gco = (int)p.gran_clip_u64;  // granule index of clip c's area: c * gco
 
   // self-attention ownership: unit (l, h) -> workgroup P-1-(l*H+h). The other NS workgroups take the cross-attention
   // units: unit u of layer l -> workgroup (l*NU + u) % NS.
@@ -147,8 +159,6 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   };
 
   // per-clip argmax scratch (clip 1's sits behind its query)
-  float* const am_vc[2] = {am_v, NC == 2 ? reinterpret_cast<float*>(qs1 + 64) : am_v};
-  int* const am_ic[2] = {am_i, NC == 2 ? reinterpret_cast<int*>(qs1 + 64) + 16 : am_i};
 
   if (poller) {
     // ======================================================================================= pollers
@@ -258,8 +268,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         // ---- self-attention owner (clip 0: LDS cache, clip 1: global memory)
         if (l == sa_layer) {
           if (!sa_first) AXW_SA0_POLL
-          if constexpr (NC == 2) {
-            // Clip 1's cache lives in global memory (there is one LDS region, and it is clip 0's). Its blocks are run by the POLLER
+#pragma unroll
+          for (int c = 1; c < NC; ++c) {
+            // The later clips' caches live in global memory (there is one LDS region, and it is clip 0's). Their blocks are run by the POLLER
             // waves — eight of them, with registers to spare, idle while the compute waves run clip 0's blocks: each requests its
             // block (the rows of the EARLIER steps; nothing of this step is needed from memory) before clip 1's query has been
             // polled for, holds it in registers, and puts this step's row (LDS) into its place. Straight-line code with selects:
@@ -269,8 +280,8 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
             u32x4 kr[8], vr[8];
             {
               const bool on = pw < nblk;  // a block without a single key of this clip yet: all zeros, every key masked
-              const h16* kc = p.self_k1 + (long)sa_unit * (NCW * 4096) + (on ? pw : 0) * 4096;
-              const h16* vc = p.self_v1 + (long)sa_unit * (NCW * 4096) + (on ? pw : 0) * 4096;
+              const h16* kc = p.self_k1 + (c - 1) * p.self_clip_stride + (long)sa_unit * (NCW * 4096) + (on ? pw : 0) * 4096;
+              const h16* vc = p.self_v1 + (c - 1) * p.self_clip_stride + (long)sa_unit * (NCW * 4096) + (on ? pw : 0) * 4096;
               const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kc, 0, on ? 8192 : 0, 0x27000);  // (0 bytes: loads return 0, no traffic)
               const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vc, 0, on ? 8192 : 0, 0x27000);
 #pragma unroll
@@ -279,11 +290,11 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
               for (int i = 0; i < 8; ++i) vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, (i * 512 + lane * 8) * 2, 0, 1);
             }
             unsigned v[2];
-            const bool fail = gather2<1>(GR, tag, v, p.err, ctl, qkv_pair(1));
-            if (tid < 32) stage_q(v, qs1);
+            const bool fail = gather2<1>(GR, tag, v, p.err, ctl, qkv_pair(c));
+            if (tid < 32) stage_q(v, qsc[c]);
             else if (tid < 96) {
-              h16* kd = p.self_k1 + (long)sa_unit * (NCW * 4096);
-              h16* vd = p.self_v1 + (long)sa_unit * (NCW * 4096);
+              h16* kd = p.self_k1 + (c - 1) * p.self_clip_stride + (long)sa_unit * (NCW * 4096);
+              h16* vd = p.self_v1 + (c - 1) * p.self_clip_stride + (long)sa_unit * (NCW * 4096);
 #pragma unroll
               for (int e = 0; e < 2; ++e) {
                 const int dd = 2 * (tid & 31) + e;
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
                 // the global stores are for the LATER steps (nobody waits for them); this step's row travels through LDS
                 if (tid < 64) kd[(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (h16)val;
                 else vd[(step >> 6) * 4096 + ((step >> 3) & 7) * 512 + dd * 8 + (step & 7)] = (h16)val;
-                kvt[(tid < 64 ? 0 : 64) + dd] = (h16)val;
+                kvtc[c][(tid < 64 ? 0 : 64) + dd] = (h16)val;
               }
             }
             if (fail) ctl[0] = 1;
@@ -299,11 +310,11 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
             {
               const bool mine = pw == (step >> 6);  // this step's key is in this wave's block: key step % 64
               const int i_s = (step >> 3) & 7, w_s = (step & 7) >> 1;
-              const unsigned nv = reinterpret_cast<const unsigned short*>(kvt)[64 + lane];
+              const unsigned nv = reinterpret_cast<const unsigned short*>(kvtc[c])[64 + lane];
               const bool klane = mine && lane == (step & 63);
 #pragma unroll
               for (int i = 0; i < 8; ++i) {
-                const u32x4 kn = *reinterpret_cast<const u32x4*>(kvt + i * 8);
+                const u32x4 kn = *reinterpret_cast<const u32x4*>(kvtc[c] + i * 8);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   kr[i][e] = klane ? kn[e] : kr[i][e];
@@ -312,7 +323,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
                 }
               }
             }
-            attn_block_regs(kr, vr, qs1, pw * 64 + lane <= step, pscr1 + pw * 64, wpart1 + pw * kPS, lane);
+            attn_block_regs(kr, vr, qsc[c], pw * 64 + lane <= step, pscr1 + pw * 64, wpart1 + pw * kPS, lane);
             // the poller wave that arrives last merges the block partials and publishes
             __builtin_amdgcn_wave_barrier();
             int old = 0;
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
             if ((old + 1) % NPW == 0) {
               float m, lt, ov;
               merge_partials(wpart1, nblk, lane, &m, &lt, &ov);
-              gput(G + gco + O_ATT + sa_head * 64 + lane, tag, ov / lt);
+              gput(G + c * gco + O_ATT + sa_head * 64 + lane, tag, ov / lt);
             }
           }
         }
@@ -432,7 +443,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
             constexpr int GH = (F / 4 + PL - 1) / PL;  // pairs per lane of the first half
             unsigned y[2 * GH];
             const bool fail = gather2<GH>(GR, tag, y, p.err, ctl, [&](int j) { const int pi = tid + j * PL; return pi < F / 4 ? c * gco + O_HID + 2 * pi : -1; });
-            if (c == 1) wg_barrier();  // the compute waves have read clip 0's hidden vector
+            if (c >= 1) wg_barrier();  // the compute waves have read the previous clip's hidden vector
 #pragma unroll
             for (int j = 0; j < GH; ++j) {
               const int pi = tid + j * PL;
@@ -501,10 +512,10 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         bool all_fin = true;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          const int mn = c == 0 ? AXW_COLD(max_new) : AXW_COLD(max_new1);
+          const int mn = c == 0 ? AXW_COLD(max_new) : (c == 1 ? AXW_COLD(max_new1) : AXW_COLD(max_new2));
           if (!fin[c] && (best[c] == AXW_COLD(eot) || step + 1 >= AXW_COLD(n_ctx) || n_out[c] >= mn)) fin[c] = true;
           if (!fin[c]) {
-            if (wg == 0 && tid == 0) (c == 0 ? AXW_COLD(out_ids) : AXW_COLD(out_ids1))[n_out[c]] = best[c];
+            if (wg == 0 && tid == 0) (c == 0 ? AXW_COLD(out_ids) : AXW_COLD(out_ids1) + (long)(c - 1) * AXW_COLD(n_ctx))[n_out[c]] = best[c];
             ++n_out[c];
             tok[c] = best[c];
           }
@@ -630,7 +641,8 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         // ---- self-attention (clip 1's blocks are the poller waves' — see there: only the hand-over of its query is shared)
         if (l == sa_layer) {
           if (!sa_first) AXW_SA0_COMP
-          if constexpr (NC == 2) AXW_BARRIER_CHECK(0x200 + l)
+#pragma unroll
+          for (int c = 1; c < NC; ++c) AXW_BARRIER_CHECK(0x200 + l)
         }
         // ---- attention output projection
         if (in_o) {
@@ -740,7 +752,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
               constexpr int GH = (F / 4 + CT - 1) / CT;
               unsigned y[2 * GH];
               const bool fail = gather2<GH>(GR, tag, y, p.err, ctl, [&](int j) { const int pi = ctid + j * CT; return pi < F / 4 ? c * gco + O_HID + F / 2 + 2 * pi : -1; });
-              if (c == 1) wg_barrier();  // (with the pollers: everybody is done with clip 0's hidden vector; this wave's own reads of it are behind it)
+              if (c >= 1) wg_barrier();  // (with the pollers: everybody is done with the previous clip's hidden vector; this wave's own reads of it are behind it)
 #pragma unroll
               for (int j = 0; j < GH; ++j) {
                 const int pi = ctid + j * CT;
@@ -804,12 +816,14 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           float acc;
           if constexpr (kActInRegs) acc = rows_dot_reg<LD, CD>(wr, a);
           else acc = rows_dot<LD, CD>(wr, act, ctid);
-          float acc1 = 0.f;
-          if constexpr (NC == 2) acc1 = rows_dot<LD, CD>(wr, actc[1], ctid);
+          float accx[NC];  // the later clips' activations come from LDS (their own vectors)
+#pragma unroll
+          for (int c = 1; c < NC; ++c) accx[c] = rows_dot<LD, CD>(wr, actc[c], ctid);
           if (j == 0) {
             if (dump) dump[row] = acc;
             if (acc > bv[0]) { bv[0] = acc; bi[0] = row; }
-            if constexpr (NC == 2) { if (acc1 > bv[1]) { bv[1] = acc1; bi[1] = row; } }
+#pragma unroll
+            for (int c = 1; c < NC; ++c) if (accx[c] > bv[c]) { bv[c] = accx[c]; bi[c] = row; }
           }
         };
         if constexpr (CD <= 3) {  // two passes ahead: ra.w holds pass 0, wn pass 1
@@ -881,7 +895,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         bool all_fin = true;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          const int mn = c == 0 ? AXW_COLD(max_new) : AXW_COLD(max_new1);
+          const int mn = c == 0 ? AXW_COLD(max_new) : (c == 1 ? AXW_COLD(max_new1) : AXW_COLD(max_new2));
           if (!fin[c] && (best[c] == AXW_COLD(eot) || step + 1 >= AXW_COLD(n_ctx) || n_out[c] >= mn)) fin[c] = true;
           if (!fin[c]) { ++n_out[c]; tok[c] = best[c]; }
           all_fin &= fin[c];
@@ -898,7 +912,8 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   }
   if (wg == 0 && tid == 0) {
     AXW_COLD(n_out)[0] = n_out[0];
-    if constexpr (NC == 2) AXW_COLD(n_out1)[0] = n_out[1];
+#pragma unroll
+    for (int c = 1; c < NC; ++c) AXW_COLD(n_out1)[c - 1] = n_out[c];
     AXW_COLD(state)->step = steps_run;
     AXW_COLD(state)->n_done = n_done;
   }
@@ -910,40 +925,48 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
 }
 
 // ---------------------------------------------------------------------------------------- host side
-static size_t persist2_lds_bytes(int d) {
-  // the one-clip launch's LDS + clip 1's d-wide input vector, its query (64 words), its argmax scratch (32 words) and the
-  // self-attention k, v rows of its current step (64 words) + the poller waves' attention scratch
-  return (size_t)kKvBytes + ((size_t)4 * d + d / 8 + NCW * kPS + 2 * NPW + 64 + 16 + 16 + 16 + 64 + NCW * 64) * 4 + 64 * 8 + 64 + ((size_t)d + 64 + 32 + 64 + NPW * kPS + NPW * 64) * 4;
+static size_t persist2_lds_bytes(int d, int nc) {
+  // the one-clip launch's LDS + per later clip its d-wide input vector, query (64 words), argmax scratch (32) and the
+  // self-attention k, v rows of its current step (64) + the poller waves' attention scratch
+  return (size_t)kKvBytes + ((size_t)4 * d + d / 8 + NCW * kPS + 2 * NPW + 64 + 16 + 16 + 16 + 64 + NCW * 64) * 4 + 64 * 8 + 64 +
+         ((size_t)(nc - 1) * (d + 64 + 32 + 64) + NPW * kPS + NPW * 64) * 4;
 }
-bool decode_persistent_two_clips_supported(int d_model, int n_head, int n_layer, int grid) {
-  // every workgroup that owns no self-attention head takes at most ONE cross-attention unit (a clip's head and key range) per layer
-  if (grid - n_layer * n_head < 2 * kCrossSplit * n_head) return false;
-  // every linear layer must be ONE pass of rows per workgroup (a second pass overwrites the rows the second clip still
+int decode_persistent_max_clips(int d_model, int n_head, int n_layer, int grid) {
+  // every linear layer must be ONE pass of rows per workgroup (a second pass overwrites the rows the next clip still
   // needs): true up to d_model 768, not for 1280 (mlp.0: 20 rows per workgroup in passes of 16)
-  switch (d_model) { case 128: case 256: case 384: case 512: case 768: return true; default: return false; }
+  switch (d_model) { case 128: case 256: case 384: case 512: case 768: break; default: return 1; }
+  int nc = 1;
+  // every workgroup that owns no self-attention head takes at most ONE cross-attention unit (a clip's head and key range) per
+  // layer, and the later clips' vectors must fit what the K/V region leaves of the CU's 160 KB of LDS
+  while (nc < 3 && grid - n_layer * n_head >= (nc + 1) * kCrossSplit * n_head && persist2_lds_bytes(d_model, nc + 1) <= 160 * 1024) ++nc;
+  return nc;
 }
 
-template <int LD, int CD, int LF, int CF, bool PROF = false>
-static hipError_t launch_two(const PersistParams& p, int grid, hipStream_t s) {
-  const size_t lds = persist2_lds_bytes(8 * LD * CD);
-  auto kfn = decode_persistent_kernel<LD, CD, LF, CF, PROF, 2>;
+template <int LD, int CD, int LF, int CF, int NC, bool PROF = false>
+static hipError_t launch_multi(const PersistParams& p, int grid, hipStream_t s) {
+  const size_t lds = persist2_lds_bytes(8 * LD * CD, NC);
+  auto kfn = decode_persistent_kernel<LD, CD, LF, CF, PROF, NC>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(PT), lds, s, p);
   return hipGetLastError();
 }
+template <int LD, int CD, int LF, int CF>
+static hipError_t launch_nc(const PersistParams& p, int grid, hipStream_t s) {
+  return p.n_clip == 2 ? launch_multi<LD, CD, LF, CF, 2>(p, grid, s) : launch_multi<LD, CD, LF, CF, 3>(p, grid, s);
+}
 
 hipError_t launch_decode_persistent2(const PersistParams& p, int d_model, int grid, hipStream_t s) {
-  if (p.n_clip != 2 || p.forced || p.logits_dump || p.argmax_dump) return hipErrorInvalidValue;
-  // the in-kernel timeline (AX_WHISPER_PERSIST_PROF): Whisper-small's shape only. Phase sums cover both clips; the absolute
-  // stamps of one layer are clip 0's (first writer) or clip 1's (last writer, AX_WHISPER_PERSIST_PROF_CLIP=1)
-  if (p.prof) return d_model == 768 ? launch_two<32, 3, 64, 6, true>(p, grid, s) : hipErrorInvalidValue;
+  if ((p.n_clip != 2 && p.n_clip != 3) || p.forced || p.logits_dump || p.argmax_dump) return hipErrorInvalidValue;
+  // the in-kernel timeline (AX_WHISPER_PERSIST_PROF): Whisper-small's shape, two clips only. Phase sums cover both clips; the
+  // absolute stamps of one layer are clip 0's (first writer) or clip 1's (last writer, AX_WHISPER_PERSIST_PROF_CLIP=1)
+  if (p.prof) return d_model == 768 && p.n_clip == 2 ? launch_multi<32, 3, 64, 6, 2, true>(p, grid, s) : hipErrorInvalidValue;
   switch (d_model) {
-    case 128: return launch_two<16, 1, 32, 2>(p, grid, s);
-    case 256: return launch_two<32, 1, 64, 2>(p, grid, s);
-    case 384: return launch_two<16, 3, 64, 3>(p, grid, s);
-    case 512: return launch_two<32, 2, 64, 4>(p, grid, s);
-    case 768: return launch_two<32, 3, 64, 6>(p, grid, s);
+    case 128: return launch_nc<16, 1, 32, 2>(p, grid, s);
+    case 256: return launch_nc<32, 1, 64, 2>(p, grid, s);
+    case 384: return launch_nc<16, 3, 64, 3>(p, grid, s);
+    case 512: return launch_nc<32, 2, 64, 4>(p, grid, s);
+    case 768: return launch_nc<32, 3, 64, 6>(p, grid, s);
     default: return hipErrorInvalidValue;
   }
 }

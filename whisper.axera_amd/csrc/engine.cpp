@@ -102,21 +102,24 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
     if (persistent_ok_) {
       persist_grid_ = decode_persistent_grid(cfg_.n_text_state, prop.multiProcessorCount);
       gran_bytes_ = decode_persistent_gran_bytes(cfg_.n_text_state, persist_grid_);
-      d_gran_ = (u64*)dalloc(2 * gran_bytes_, true);  // two areas: the two-clip launch keeps one per clip
+      d_gran_ = (u64*)dalloc(3 * gran_bytes_, true);  // one area per clip of a multi-clip launch
       allocs_.push_back(d_gran_);
-      // two clips per launch (decode_persistent2.hip): clip 1's self-attention cache lives in global memory
-      const char* e2 = getenv("AX_WHISPER_PERSIST2");  // "0": two clips = two one-clip launches, as before round 4 (A/B, tests)
-      persistent2_ok_ = !(e2 && e2[0] == '0') && decode_persistent_two_clips_supported(cfg_.n_text_state, cfg_.n_text_head, cfg_.n_text_layer, persist_grid_);
-      if (persistent2_ok_) {
-        self1_bytes_ = (size_t)cfg_.n_text_layer * cfg_.n_text_head * 8 * 4096 * 2;
-        d_self_k1_ = (h16*)dalloc(self1_bytes_, true);
-        d_self_v1_ = (h16*)dalloc(self1_bytes_, true);
+      // two or three clips per launch (decode_persistent2.hip): the later clips' self-attention caches live in global memory
+      // "0" / "1": one launch per clip, as before round 4; "2": at most two clips per launch (A/B, tests); default: up to three
+      const char* e2 = getenv("AX_WHISPER_PERSIST2");
+      persist_max_clips_ = decode_persistent_max_clips(cfg_.n_text_state, cfg_.n_text_head, cfg_.n_text_layer, persist_grid_);
+      if (e2 && e2[0] >= '0' && e2[0] <= '9') persist_max_clips_ = std::max(1, std::min(persist_max_clips_, atoi(e2)));
+      if (persist_max_clips_ >= 2) {
+        self1_bytes_ = (size_t)cfg_.n_text_layer * cfg_.n_text_head * 8 * 4096 * 2;  // one later clip's cache (K; V alike)
+        d_self_k1_ = (h16*)dalloc((persist_max_clips_ - 1) * self1_bytes_, true);
+        d_self_v1_ = (h16*)dalloc((persist_max_clips_ - 1) * self1_bytes_, true);
         allocs_.push_back(d_self_k1_);
         allocs_.push_back(d_self_v1_);
       }
     }
   }
-  cfg_.ints["persistent_two_clips"] = persistent2_ok_ ? 1 : 0;
+  cfg_.ints["persistent_two_clips"] = persist_max_clips_ >= 2 ? 1 : 0;
+  cfg_.ints["persistent_max_clips"] = persist_max_clips_;
   cfg_.ints["persistent_decode"] = persistent_ok_ ? 1 : 0;  // visible through AX_WHISPER_GetConfigInt
   cfg_.ints["persistent_giveups"] = 0;
   {  // batched decode as clip-block GEMMs with LayerNorm prologue / residual epilogue (enqueue_decode_step_batched)
@@ -1199,14 +1202,14 @@ hipGraphExec_t Engine::step_graph(int batch, int max_new) {
 int Engine::greedy_loop(int batch, int max_new, const int* max_new_clip) {
   const int Tc = cfg_.n_text_ctx;
   if (max_new <= 0 || max_new > Tc - 4) max_new = Tc - 4;
-  // One clip: the persistent launch. Two clips: ONE two-clip persistent launch, phase by phase (one clip's rows are computed
-  // while the other's hand-off is in flight; decode_persistent2.hip) — Whisper-small, 444 ids per clip: 134 ms per pair
-  // against 2 x 116 ms for one launch per clip (shapes without a two-clip launch, AX_WHISPER_PERSIST2=0) and 316 ms through
-  // the launch-per-phase path, which wins from 3 clips on (244 ms). Each clip stops at its own eot / budget.
-  if (batch == 2 && persistent2_ok_ && persistent_usable()) {
-    const int mn0 = (max_new_clip && max_new_clip[0] > 0) ? std::min(max_new, max_new_clip[0]) : max_new;
-    const int mn1 = (max_new_clip && max_new_clip[1] > 0) ? std::min(max_new, max_new_clip[1]) : max_new;
-    const int st = run_persistent(mn0, nullptr, 0, nullptr, nullptr, 0, mn1);
+  // One clip: the persistent launch. Two or three clips: ONE multi-clip persistent launch, phase by phase (one clip's rows are
+  // computed while the others' hand-offs are in flight; decode_persistent2.hip) — Whisper-small, 444 ids per clip: 134 ms per
+  // pair against 2 x 116 ms for one launch per clip (shapes without a multi-clip launch, AX_WHISPER_PERSIST2=0) and 316 ms through
+  // the launch-per-phase path. Each clip stops at its own eot / budget.
+  if (batch >= 2 && batch <= persist_max_clips_ && persistent_usable()) {
+    int mn[3] = {max_new, -1, -1};
+    for (int b = 0; b < batch; ++b) mn[b] = (max_new_clip && max_new_clip[b] > 0) ? std::min(max_new, max_new_clip[b]) : max_new;
+    const int st = run_persistent(mn[0], nullptr, 0, nullptr, nullptr, 0, mn[1], mn[2]);
     if (st >= 0) { persistent_succeeded(); return st; }
     persistent_gave_up();
   } else if (batch <= 2 && persistent_usable()) {
@@ -1244,8 +1247,9 @@ int Engine::greedy_loop(int batch, int max_new, const int* max_new_clip) {
   return steps;
 }
 
-// max_new1 >= 0: TWO clips in this launch — slots `slot` and `slot + 1`, budgets max_new / max_new1 (greedy decode only)
-int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float* d_logits, int* d_argmax, int slot, int max_new1) {
+// max_new1 >= 0 (max_new2 >= 0): TWO (THREE) clips in this launch — slots `slot`, `slot + 1` (, `slot + 2`), budgets max_new / max_new1
+// (/ max_new2) (greedy decode only)
+int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float* d_logits, int* d_argmax, int slot, int max_new1, int max_new2) {
   // The launch needs every workgroup resident at once (one per CU): two of them in flight on one GPU could each hold
   // part of the CUs and starve the other until both give up. Handles of one process on one device take turns.
   // (one mutex per device, shared by the bfloat16 and the half build of this file: iengine.hpp)
@@ -1260,15 +1264,16 @@ int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float
   p.cross_layer_stride = (long)cap_ * H * t_pad_ * 64;
   p.n_layer = cfg_.n_text_layer; p.n_vocab = cfg_.n_vocab; p.n_ctx = Tc; p.n_audio_ctx = cfg_.n_audio_ctx;
   p.eot = cfg_.eot; p.max_new = max_new;
-  p.total_steps = d_forced || d_logits || d_argmax ? 4 + n_forced : std::min(Tc, 4 + std::max(max_new, max_new1));
+  p.total_steps = d_forced || d_logits || d_argmax ? 4 + n_forced : std::min(Tc, 4 + std::max(max_new, std::max(max_new1, max_new2)));
   p.n_clip = 1;
   if (max_new1 >= 0) {
-    if (!persistent2_ok_ || d_forced || d_logits || d_argmax || slot + 1 >= cap_) throw std::runtime_error("run_persistent: two clips unsupported here");
-    p.n_clip = 2;
+    p.n_clip = max_new2 >= 0 ? 3 : 2;
+    if (persist_max_clips_ < p.n_clip || d_forced || d_logits || d_argmax || slot + p.n_clip > cap_) throw std::runtime_error("run_persistent: that many clips are unsupported here");
     p.cross_clip_stride = (long)H * t_pad_ * 64;
     p.self_k1 = d_self_k1_; p.self_v1 = d_self_v1_;
     p.gran_clip_u64 = (long)(gran_bytes_ / 8);
     p.out_ids1 = d_out_ids_ + (size_t)(slot + 1) * Tc; p.n_out1 = d_nout_ + slot + 1; p.max_new1 = max_new1;
+    p.max_new2 = max_new2; p.self_clip_stride = (long)(self1_bytes_ / 2);
   }
   p.sot = d_sot_;
   p.forced = d_forced; p.n_forced = n_forced; p.logits_dump = d_logits; p.argmax_dump = d_argmax;
@@ -1288,9 +1293,9 @@ int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float
   HIP_CHECK(hipMemsetAsync(d_gran_, 0, p.n_clip * gran_bytes_, s));
   HIP_CHECK(hipMemsetAsync(d_state_, 0, sizeof(DecState), s));
   HIP_CHECK(hipMemsetAsync(d_nout_ + slot, 0, 4 * p.n_clip, s));
-  if (p.n_clip == 2) {  // keys beyond a clip's position are masked, but their values must be finite
-    HIP_CHECK(hipMemsetAsync(d_self_k1_, 0, self1_bytes_, s));
-    HIP_CHECK(hipMemsetAsync(d_self_v1_, 0, self1_bytes_, s));
+  if (p.n_clip >= 2) {  // keys beyond a clip's position are masked, but their values must be finite
+    HIP_CHECK(hipMemsetAsync(d_self_k1_, 0, (p.n_clip - 1) * self1_bytes_, s));
+    HIP_CHECK(hipMemsetAsync(d_self_v1_, 0, (p.n_clip - 1) * self1_bytes_, s));
   }
   HIP_CHECK(launch_decode_persistent(p, cfg_.n_text_state, persist_grid_, s));
   HIP_CHECK(hipMemcpyAsync(&h_poll_[8], p.err, 4, hipMemcpyDeviceToHost, s));

@@ -80,7 +80,7 @@ class Engine final : public IEngine {
   void recover_streams();
   int greedy_loop(int batch, int max_new, const int* max_new_clip = nullptr);
   // batch 1: the whole loop as one persistent launch (decode_persistent.hip); returns steps run, -1 if it gave up
-  int run_persistent(int max_new, const int* d_forced, int n_forced, float* d_logits, int* d_argmax, int slot = 0, int max_new1 = -1);
+  int run_persistent(int max_new, const int* d_forced, int n_forced, float* d_logits, int* d_argmax, int slot = 0, int max_new1 = -1, int max_new2 = -1);
   void fetch_ids(int batch, int32_t* ids, int* n_ids);
 
   ModelConfig cfg_;
@@ -179,8 +179,8 @@ class Engine final : public IEngine {
   // persistent batch-1 decode
   bool batched_ln_ = false;         // batched decode: clip-block GEMM sequence (AX_WHISPER_BATCHED_LN=0 disables)
   bool persistent_ok_ = false;      // model shape supported and not disabled (AX_WHISPER_DECODE=graph)
-  bool persistent2_ok_ = false;     // two clips per persistent launch (d_model <= 768; AX_WHISPER_PERSIST2=0 disables)
-  h16 *d_self_k1_ = nullptr, *d_self_v1_ = nullptr; size_t self1_bytes_ = 0;  // clip 1's self-attention cache of that launch
+  int persist_max_clips_ = 1;       // clips per persistent launch: up to 3 for d_model <= 768 (AX_WHISPER_PERSIST2=<n> caps it, 0 = 1)
+  h16 *d_self_k1_ = nullptr, *d_self_v1_ = nullptr; size_t self1_bytes_ = 0;  // the later clips' self-attention caches of that launch
   int persist_skip_ = 0, persist_backoff_ = 0, persist_giveups_ = 0;  // re-arming after a give-up (engine.cpp)
   bool persistent_usable();
   void persistent_gave_up();

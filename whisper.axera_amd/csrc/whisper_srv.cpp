@@ -113,8 +113,8 @@ static void batcher(AX_WHISPER_HANDLE model, int max_batch, int wait_ms) {
   }
 }
 
-// Slots that are refilled as they finish (AX_WHISPER_Stream*). One request alone on an idle device — or two, where the model
-// has a two-clip launch — takes the batch entry point instead (the persistent launch is 2x faster than a step sequence with one
+// Slots that are refilled as they finish (AX_WHISPER_Stream*). One request alone on an idle device — or two or three, where the
+// model has a multi-clip launch — takes the batch entry point instead (the persistent launch is 2x faster than a step sequence with one
 // or two live slots).
 // Admission policy (--min_admit N --admit_wait_ms T): while something is decoding, an admission pass is held back until N
 // requests can be admitted together or the oldest waiting request is T ms old — an encoder pass over 8 clips costs 0.72 ms
@@ -128,7 +128,7 @@ static void slot_scheduler(AX_WHISPER_HANDLE model, int n_slots, int wait_ms, in
   std::vector<int32_t> ids(Tc);
   int busy = 0, reported = 0;
   bool open = false;
-  const bool pair_launch = AX_WHISPER_GetConfigInt(model, "persistent_two_clips") == 1;
+  const int launch_clips = AX_WHISPER_GetConfigInt(model, "persistent_max_clips");  // clips one persistent launch decodes (1-3)
   auto report = [&] { g_busy_slots += busy - reported; reported = busy; };  // /health sums the devices
   auto fail = [](Job* j) { j->done.set_value({false, std::string()}); };
   auto run_alone = [&](Job* j) {
@@ -159,19 +159,23 @@ static void slot_scheduler(AX_WHISPER_HANDLE model, int n_slots, int wait_ms, in
       run_alone(take[0]);
       continue;
     }
-    if (busy == 0 && take.size() == 2 && pair_launch) {
-      // two requests on an idle device: both greedy loops in ONE persistent launch (134 ms for a pair of Whisper-small clips of
-      // 444 ids against ~240 ms for two live slots of the step sequence); a refused pair (one bad request) is served one by one
+    if (busy == 0 && take.size() >= 2 && (int)take.size() <= launch_clips) {
+      // two or three requests on an idle device: their greedy loops in ONE persistent launch (134 ms for a pair of Whisper-small
+      // clips of 444 ids against ~240 ms for two live slots of the step sequence); a refused group (one bad request) is served one by one
       if (open) { AX_WHISPER_StreamClose(model); open = false; }
-      const float* ptrs[2] = {take[0]->pcm.data(), take[1]->pcm.data()};
-      int lens[2] = {(int)take[0]->pcm.size(), (int)take[1]->pcm.size()};
-      char* texts[2] = {nullptr, nullptr};
-      if (AX_WHISPER_RunPCMBatch(model, ptrs, lens, 2, texts) == 0 && texts[0] && texts[1]) {
-        for (int i = 0; i < 2; ++i) { take[i]->done.set_value({true, std::string(texts[i])}); ++g_served; }
+      const int n = (int)take.size();
+      const float* ptrs[3];
+      int lens[3];
+      char* texts[3] = {nullptr, nullptr, nullptr};
+      for (int i = 0; i < n; ++i) { ptrs[i] = take[i]->pcm.data(); lens[i] = (int)take[i]->pcm.size(); }
+      bool ok = AX_WHISPER_RunPCMBatch(model, ptrs, lens, n, texts) == 0;
+      for (int i = 0; i < n; ++i) ok = ok && texts[i];
+      if (ok) {
+        for (int i = 0; i < n; ++i) { take[i]->done.set_value({true, std::string(texts[i])}); ++g_served; }
       } else {
-        for (int i = 0; i < 2; ++i) run_alone(take[i]);
+        for (int i = 0; i < n; ++i) run_alone(take[i]);
       }
-      for (int i = 0; i < 2; ++i) free(texts[i]);
+      for (int i = 0; i < n; ++i) free(texts[i]);
       continue;
     }
     if (!take.empty() && !open) {
