@@ -91,7 +91,7 @@ def test_slots_refill_while_others_decode(built_lib, micro_case):
 
 def test_stream_beyond_64_slots(built_lib, micro_case):
     """72 slots (three graph branches: 32 + 32 + 8 clips; the vocabulary projection as two launches) fed 150 clips: the slot
-    count is a deployment knob (one step costs 17.9 us per clip at 64 clips and 13.1 at 256, engine.cpp decode_branches), so
+    count is a deployment knob (one step costs 17.9 us per clip at 64 clips and 13.1 at 256, engine_decode.cpp decode_branches), so
     the stream has to be right on both sides of the 64-clip launch boundary. Every clip against its stand-alone run."""
     n_slots, n_clips = 72, 150
     clips8, _ = _clips_and_budgets(8)

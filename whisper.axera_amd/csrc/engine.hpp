@@ -181,7 +181,7 @@ class Engine final : public IEngine {
   bool persistent_ok_ = false;      // model shape supported and not disabled (AX_WHISPER_DECODE=graph)
   int persist_max_clips_ = 1;       // clips per persistent launch: up to 3 for d_model <= 768 (AX_WHISPER_PERSIST2=<n> caps it, 0 = 1)
   h16 *d_self_k1_ = nullptr, *d_self_v1_ = nullptr; size_t self1_bytes_ = 0;  // the later clips' self-attention caches of that launch
-  int persist_skip_ = 0, persist_backoff_ = 0, persist_giveups_ = 0;  // re-arming after a give-up (engine.cpp)
+  int persist_skip_ = 0, persist_backoff_ = 0, persist_giveups_ = 0;  // re-arming after a give-up (engine_decode.cpp)
   bool persistent_usable();
   void persistent_gave_up();
   void persistent_succeeded();

@@ -59,7 +59,7 @@ class IEngine {
 
 // One persistent decode launch at a time per GPU, whichever build (bfloat16 / half) the launching handle belongs to:
 // the launch needs every CU, and two of them co-resident would each hold part of the chip until both give up. Defined
-// once in api.cpp (engine.cpp is compiled twice).
+// once in api.cpp (the engine's translation units are compiled twice).
 std::mutex& persistent_launch_mutex(int device);
 
 // Stream capture of a decoder step (hipStreamBeginCapture ... EndCapture) and the calls that may invalidate SOMEBODY ELSE's
