@@ -210,8 +210,9 @@ def test_two_clip_launch_equals_one_clip_launches(built_lib, tmp_path, monkeypat
         e.close()
 
 
-@pytest.mark.parametrize("model_type,seed,max_new", [("micro", 41, 30), ("tiny", 42, 70), ("small", 43, 100)])
-def test_three_clip_launch_equals_one_clip_launches(built_lib, tmp_path, monkeypatch, model_type, seed, max_new):
+@pytest.mark.parametrize("model_type,seed,max_new,dtype", [("micro", 41, 30, "BF16"), ("tiny", 42, 70, "BF16"), ("small", 43, 100, "BF16"),
+                                                        ("tiny", 44, 70, "F16"), ("small", 45, 80, "F16")])
+def test_three_clip_launch_equals_one_clip_launches(built_lib, tmp_path, monkeypatch, model_type, seed, max_new, dtype):
     """Three clips per call: ONE three-clip persistent launch (3 x 36 one-clip cross-attention units per layer on the 112
     workgroups without a head; the caches of clips 1 and 2 in global memory, their blocks run by the poller waves one clip
     after the other). ids of a triple EQUAL the ids of its clips decoded alone, in every order, with per-clip budgets;
@@ -220,11 +221,12 @@ def test_three_clip_launch_equals_one_clip_launches(built_lib, tmp_path, monkeyp
 
     import modelgen
 
-    case = ModelCase(tmp_path, model_type, seed)
+    case = ModelCase(tmp_path, model_type, seed, dtype=dtype)   # both builds of the kernel: bfloat16 and IEEE half
     clips = [load_demo_pcm(), modelgen.synth_clip(seed, 200000), modelgen.synth_clip(seed + 1, 90000)]
     e = built_lib.Whisper(model_type, case.root, "zh", device=0, max_batch=3)
     try:
         assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_max_clips") == 3
+        assert e.L.AX_WHISPER_GetConfigInt(e.h, b"fp16") == (1 if dtype == "F16" else 0)
         mels = np.stack([e.compute_mel(c) for c in clips])
         single = []
         for m in mels:
