@@ -154,6 +154,28 @@ def test_server_asr_round_trip(built_lib, micro_case, scheduler):
         [t.start() for t in th]
         [t.join() for t in th]
         assert out[2][0] == 400 and all(o[0] == 200 and o[1]["text"] == js["text"] for i, o in enumerate(out) if i != 2)
+        # low load: two, then three DIFFERENT clips at once on an idle device share one multi-clip persistent launch
+        # (slots scheduler: the idle-device path; micro-batches: AX_WHISPER_RunPCMBatch of 2 / 3) — every reply its own clip's text;
+        # and a poisoned request in such a group fails alone
+        import modelgen
+
+        e = built_lib.Whisper("micro", micro_case.root, "zh", device=0)
+        assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_max_clips") == 3
+        others = [modelgen.synth_clip(70 + i, 50000 + 30000 * i) for i in range(3)]
+        texts = [e.run(c) for c in others]
+        e.close()
+        for n in (2, 3, 2):
+            out = [None] * n
+            th = [threading.Thread(target=lambda i=i: out.__setitem__(i, post(others[i].tobytes()))) for i in range(n)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert [o[0] for o in out] == [200] * n and [o[1]["text"] for o in out] == texts[:n]
+            time.sleep(0.05)
+        out = [None] * 2
+        th = [threading.Thread(target=lambda i=i: out.__setitem__(i, post((bad if i == 0 else others[1]).tobytes()))) for i in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert out[0][0] == 400 and out[1][0] == 200 and out[1][1]["text"] == texts[1]
         # nine requests at once on four slots: five of them wait in the queue and take slots as they free up
         out = [None] * 9
         th = [threading.Thread(target=lambda i=i: out.__setitem__(i, post(pcm.tobytes()))) for i in range(9)]
