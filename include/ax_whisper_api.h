@@ -113,6 +113,12 @@ AX_WHISPER_API int AX_WHISPER_ComputeMel(AX_WHISPER_HANDLE handle, const float* 
 AX_WHISPER_API int AX_WHISPER_EncodeMel(AX_WHISPER_HANDLE handle, const float* mel, int batch);
 /** Copy slot's cross K/V back as fp32 [n_text_layer][1500][n_text_state] (reference layout). */
 AX_WHISPER_API int AX_WHISPER_GetCrossKV(AX_WHISPER_HANDLE handle, int slot, float* k_out, float* v_out);
+/** Parity aid: scan every 16-bit tensor the engine keeps between kernels (encoder activations of clips 0..batch-1, cross and
+ *  self K/V caches, the decoder's activation pairs) after EncodeMel / Decode*: names [n_max][32] chars, nonfinite [n_max]
+ *  (NaN or Inf elements), maxabs [n_max] (largest finite |x|), *n_out buffers reported. A trained model's outlier channels
+ *  and FFN peaks must stay inside the storage type's range (65504 for the fp16 build). */
+AX_WHISPER_API int AX_WHISPER_ScanStored16(AX_WHISPER_HANDLE handle, int batch, int n_max, char* names, int64_t* nonfinite,
+                                           float* maxabs, int* n_out);
 /** Teacher-forced decode over the slots filled by EncodeMel: after the 4 SOT steps feed
  *  forced[b][0..n_forced-1]; logits: host [batch][n_forced+1][n_vocab] f32 (may be NULL);
  *  argmax_ids: host [batch][n_forced+1] (may be NULL). */

@@ -52,16 +52,19 @@ def oracle_mod():
 class ModelCase:
     """A seeded synthetic model on disk + the matching oracle objects."""
 
-    def __init__(self, tmpdir, model_type, seed, dtype="BF16"):
+    def __init__(self, tmpdir, model_type, seed, dtype="BF16", kind="benign"):
         """dtype "BF16": weights representable in bfloat16, engine in its bf16 build; "F16": weights representable in
         IEEE half, stored as F16, engine in its fp16 build. Either way both sides hold identical weight values and
-        `oracle_bf16` is the oracle that narrows at the engine's 16-bit storage points (in that engine's type)."""
+        `oracle_bf16` is the oracle that narrows at the engine's 16-bit storage points (in that engine's type).
+        kind "realistic": modelgen.realistic_weights (trained-model activation statistics) instead of N(0, 0.02)."""
         import modelgen
         import oracle
 
-        self.model_type, self.seed, self.root, self.dtype = model_type, seed, str(tmpdir), dtype
+        self.model_type, self.seed, self.root, self.dtype, self.kind = model_type, seed, str(tmpdir), dtype, kind
         self.dims = modelgen.DIMS[model_type]
-        if dtype == "F16":
+        if kind == "realistic":
+            self.weights = modelgen.realistic_weights(self.dims, seed, dtype=dtype)
+        elif dtype == "F16":
             w = modelgen.synth_weights(self.dims, seed, bf16=False)
             self.weights = {k: v.astype(np.float16).astype(np.float32) for k, v in w.items()}
         else:

@@ -70,9 +70,11 @@ from make_model_goldens_inputs import synth_mel, demo_mel  # noqa: E402
 
 
 @torch.no_grad()
-def run_case(name, model_type, seed, mel, n_new, language_idx=1):
+def run_case(name, model_type, seed, mel, n_new, language_idx=1, kind="benign"):
+    """kind "realistic": modelgen.realistic_weights (outlier channels, saturated / flat attention, FFN hidden values in the
+    thousands, logit std ~10, near-duplicate vocabulary rows) — the oracle is pinned under those statistics too."""
     dims = modelgen.DIMS[model_type]
-    w = modelgen.synth_weights(dims, seed, bf16=True)
+    w = modelgen.realistic_weights(dims, seed) if kind == "realistic" else modelgen.synth_weights(dims, seed, bf16=True)
     cfg = modelgen.make_config(model_type, dims)
     m = hf_from_weights(dims, w)
     enc = m.model.encoder(input_features=torch.from_numpy(mel)[None]).last_hidden_state  # [1,1500,d]
@@ -92,7 +94,7 @@ def run_case(name, model_type, seed, mel, n_new, language_idx=1):
     top = np.argsort(-step_logits, axis=1)[:, :8]
     probe = np.arange(0, dims["n_vocab"], 997)
     np.savez_compressed(
-        os.path.join(HERE, f"model_{name}.npz"), model_type=model_type, seed=seed, n_new=n_new,
+        os.path.join(HERE, f"model_{name}.npz"), model_type=model_type, seed=seed, n_new=n_new, kind=kind,
         sot_seq=np.array(toks[:4]), ids=np.array(ids), top_ids=top,
         top_vals=np.take_along_axis(step_logits, top, axis=1), probe_idx=probe,
         probe_vals=step_logits[:, probe], cross_k_sub=ck[:, ::53, ::7], cross_v_sub=cv[:, ::53, ::7],
@@ -105,6 +107,13 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     mel_demo = demo_mel(80)
+    if len(sys.argv) > 1 and sys.argv[1] == "round5":  # realistic activation statistics (modelgen.realistic_weights)
+        run_case("real_micro_demo", "micro", 41, mel_demo, 16, kind="realistic")
+        run_case("real_mini_synth", "mini", 42, synth_mel(6, 80, 1777), 12, kind="realistic")
+        run_case("real_miniturbo_synth", "miniturbo", 43, synth_mel(9, 128, 2500), 10, language_idx=99, kind="realistic")
+        run_case("real_tiny_demo", "tiny", 44, mel_demo, 8, kind="realistic")
+        run_case("real_small_demo", "small", 45, mel_demo, 6, kind="realistic")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "round2":  # only the cases added in round 2 (the others are unchanged)
         run_case("small_demo", "small", 0, mel_demo, 6)
         run_case("miniturbo_synth", "miniturbo", 21, synth_mel(9, 128, 2500), 8, language_idx=99)

@@ -24,4 +24,7 @@ def demo_mel(n_mels=80):
 def golden_mel(name):
     return {"micro_demo": lambda: demo_mel(80), "micro_synth": lambda: synth_mel(5, 80, 3000),
             "mini_synth": lambda: synth_mel(6, 80, 1777), "tiny_demo": lambda: demo_mel(80),
-            "small_demo": lambda: demo_mel(80), "miniturbo_synth": lambda: synth_mel(9, 128, 2500)}[name]()
+            "small_demo": lambda: demo_mel(80), "miniturbo_synth": lambda: synth_mel(9, 128, 2500),
+            "real_micro_demo": lambda: demo_mel(80), "real_mini_synth": lambda: synth_mel(6, 80, 1777),
+            "real_miniturbo_synth": lambda: synth_mel(9, 128, 2500), "real_tiny_demo": lambda: demo_mel(80),
+            "real_small_demo": lambda: demo_mel(80)}[name]()

@@ -17,21 +17,27 @@ def _mel_for(name):
 
 # small_demo: Whisper-small dims with the seed-0 weights bench.py runs (BASELINE configs[1], [2]); miniturbo_synth: the turbo
 # layout (128 mels, 100 languages incl. yue, n_vocab 51866, 3 encoder / 2 decoder layers) at reduced width
-@pytest.mark.parametrize("name", ["micro_demo", "micro_synth", "mini_synth", "tiny_demo", "small_demo", "miniturbo_synth"])
+# real_*: the same graph under trained-model activation statistics (modelgen.realistic_weights: outlier channels of
+# |x| ~ 150-400, LayerNorm gains 0.02-30, saturated and flat attention heads, FFN hidden values ~5000, logit std ~10 with
+# near-duplicate vocabulary rows) — fp32 vs fp32 tolerances scale with the magnitudes: 1e-5 of the largest golden value + 2e-5
+@pytest.mark.parametrize("name", ["micro_demo", "micro_synth", "mini_synth", "tiny_demo", "small_demo", "miniturbo_synth",
+                                  "real_micro_demo", "real_mini_synth", "real_miniturbo_synth", "real_tiny_demo", "real_small_demo"])
 def test_oracle_matches_transformers(oracle_mod, name):
     import modelgen
 
     g = np.load(os.path.join(GOLDEN, f"model_{name}.npz"))
     mt = str(g["model_type"])
     dims = modelgen.DIMS[mt]
-    w = modelgen.synth_weights(dims, int(g["seed"]))
+    real = name.startswith("real_")
+    w = modelgen.realistic_weights(dims, int(g["seed"])) if real else modelgen.synth_weights(dims, int(g["seed"]))
     cfg = modelgen.make_config(mt, dims)
     o = oracle_mod.Oracle(cfg, w)
     ck, cv = o.encoder(_mel_for(name))
-    assert np.abs(ck[:, ::53, ::7] - g["cross_k_sub"]).max() < 2e-5
-    assert np.abs(cv[:, ::53, ::7] - g["cross_v_sub"]).max() < 2e-5
-    assert abs(ck.astype(np.float64).sum() - float(g["cross_k_sum"])) < 1e-2
-    assert abs(np.abs(ck).astype(np.float64).sum() - float(g["cross_k_abs"])) < 1e-1
+    tol_k = 2e-5 + 1e-5 * float(np.abs(g["cross_k_sub"]).max()) * real
+    assert np.abs(ck[:, ::53, ::7] - g["cross_k_sub"]).max() < tol_k
+    assert np.abs(cv[:, ::53, ::7] - g["cross_v_sub"]).max() < tol_k
+    assert abs(ck.astype(np.float64).sum() - float(g["cross_k_sum"])) < (1.0 if real else 1e-2)
+    assert abs(np.abs(ck).astype(np.float64).sum() - float(g["cross_k_abs"])) < (2.0 if real else 1e-1)
     sot = [int(x) for x in g["sot_seq"]]
     codes = cfg["all_language_codes"].split(",")
     toks = [int(t) for t in cfg["all_language_tokens"].split(",")]
@@ -41,8 +47,11 @@ def test_oracle_matches_transformers(oracle_mod, name):
     ids, lg = o.greedy(ck, cv, language=lang, max_new=n_new, want_logits=True)
     assert ids == [int(x) for x in g["ids"][:n_new]]
     top = np.take_along_axis(lg, g["top_ids"][: len(lg)], axis=1)
-    assert np.abs(top - g["top_vals"][: len(lg)]).max() < 2e-5
-    assert np.abs(lg[:, g["probe_idx"]] - g["probe_vals"][: len(lg)]).max() < 2e-5
+    tol = 2e-5 + 1e-5 * float(np.abs(g["top_vals"]).max()) * real
+    assert np.abs(top - g["top_vals"][: len(lg)]).max() < tol
+    assert np.abs(lg[:, g["probe_idx"]] - g["probe_vals"][: len(lg)]).max() < tol
+    if real:  # the statistics the battery is about are really there
+        assert lg.std() > 5.0 and np.abs(ck).max() > 5.0, (lg.std(), np.abs(ck).max())
 
 
 def test_teacher_forcing_equals_free_running(oracle_mod, micro_case):

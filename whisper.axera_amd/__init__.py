@@ -49,6 +49,7 @@ SYMBOLS = {
     "AX_WHISPER_ComputeMel": (C.c_int, [C.c_void_p, fp, C.c_int, fp]),
     "AX_WHISPER_EncodeMel": (C.c_int, [C.c_void_p, fp, C.c_int]),
     "AX_WHISPER_GetCrossKV": (C.c_int, [C.c_void_p, C.c_int, fp, fp]),
+    "AX_WHISPER_ScanStored16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int64), fp, C.POINTER(C.c_int)]),
     "AX_WHISPER_DecodeForced": (C.c_int, [C.c_void_p, C.c_int, ip, C.c_int, fp, ip]),
     "AX_WHISPER_DecodeGreedy": (C.c_int, [C.c_void_p, C.c_int, C.c_int, ip, C.POINTER(C.c_int)]),
     "AX_WHISPER_DecodeGreedyRagged": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), ip, C.POINTER(C.c_int)]),
@@ -228,6 +229,16 @@ class Whisper:
         k, v = np.empty(shape, dtype=np.float32), np.empty(shape, dtype=np.float32)
         self._check(self.L.AX_WHISPER_GetCrossKV(self.h, slot, k.ctypes.data_as(fp), v.ctypes.data_as(fp)), "GetCrossKV")
         return k, v
+
+    def scan_stored16(self, batch: int = 1):
+        """{buffer name: (non-finite elements, max finite |x|)} over every 16-bit tensor the engine stores between kernels."""
+        n_max = 32
+        names = C.create_string_buffer(32 * n_max)
+        bad = (C.c_int64 * n_max)()
+        mx = (C.c_float * n_max)()
+        n = C.c_int()
+        self._check(self.L.AX_WHISPER_ScanStored16(self.h, batch, n_max, names, bad, mx, C.byref(n)), "ScanStored16")
+        return {names.raw[32 * i:32 * i + 32].split(b"\0")[0].decode(): (int(bad[i]), float(mx[i])) for i in range(n.value)}
 
     def decode_forced(self, batch: int, forced, want_logits: bool = True):
         f = np.ascontiguousarray(forced, dtype=np.int32).reshape(batch, -1)

@@ -346,6 +346,15 @@ AX_WHISPER_API int AX_WHISPER_GetCrossKV(AX_WHISPER_HANDLE handle, int slot, flo
   return guarded(handle, [&](Engine& e) { e.get_cross_kv(slot, k_out, v_out); });
 }
 
+AX_WHISPER_API int AX_WHISPER_ScanStored16(AX_WHISPER_HANDLE handle, int batch, int n_max, char* names, int64_t* nonfinite,
+                                           float* maxabs, int* n_out) {
+  if (!handle || !names || !nonfinite || !maxabs || !n_out || n_max < 1) return -1;
+  return guarded(handle, [&](Engine& e) {
+    static_assert(sizeof(long long) == sizeof(int64_t), "int64_t");
+    *n_out = e.scan_stored16(batch, n_max, reinterpret_cast<char(*)[32]>(names), reinterpret_cast<long long*>(nonfinite), maxabs);
+  });
+}
+
 AX_WHISPER_API int AX_WHISPER_DecodeForced(AX_WHISPER_HANDLE handle, int batch, const int32_t* forced, int n_forced,
                                            float* logits, int32_t* argmax_ids) {
   if (!handle || (n_forced > 0 && !forced)) return -1;

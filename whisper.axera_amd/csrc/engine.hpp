@@ -41,6 +41,7 @@ class Engine final : public IEngine {
   int stream_step(int n_steps, int* finished_slots) override;
   void stream_collect(int slot, int32_t* ids, int* n_ids) override;
   void stream_close() override;
+  int scan_stored16(int batch, int n_max, char (*names)[32], long long* nonfinite, float* maxabs) override;
   float bench(const std::string& what, int batch, int arg, int iters) override;
   void set_stream(void* s) override { user_stream_ = static_cast<hipStream_t>(s); }
   const ModelConfig& config() const override { return cfg_; }

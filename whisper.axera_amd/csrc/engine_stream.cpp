@@ -164,6 +164,61 @@ void Engine::stream_collect(int slot, int32_t* ids, int* n_ids) {
   slot_state_[slot] = kIdle;
 }
 
+// ------------------------------------------------------------------------------ stored 16-bit tensors: non-finite scan
+// (parity battery under trained-model statistics: outlier channels, FFN hidden values in the thousands — a half tensor
+// that overflowed would show here even where the logits still look plausible)
+__global__ static void scan16_kernel(const h16* __restrict__ p, size_t n, unsigned long long* bad, unsigned* maxbits) {
+  unsigned long long nb = 0;
+  float mx = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = (float)p[i];
+    if (v != v || fabsf(v) > 3.0e38f) ++nb; else mx = fmaxf(mx, fabsf(v));
+  }
+  if (nb) atomicAdd(bad, nb);
+  atomicMax(maxbits, __float_as_uint(mx));  // non-negative floats order like their bit patterns
+}
+
+int Engine::scan_stored16(int batch, int n_max, char (*names)[32], long long* nonfinite, float* maxabs) {
+  require_no_stream("scan_stored16");
+  std::lock_guard<std::recursive_mutex> capture_lock(device_capture_mutex(device_));
+  HIP_CHECK(hipSetDevice(device_));
+  if (batch < 1 || batch > cap_) throw std::runtime_error("scan_stored16: batch outside the allocated slots");
+  const size_t B = batch, d = cfg_.n_text_state, T = cfg_.n_audio_ctx, L = cfg_.n_text_layer, H = cfg_.n_text_head, Tc = cfg_.n_text_ctx;
+  struct Buf { const char* name; const h16* p; size_t n; };
+  std::vector<Buf> bufs = {
+      {"enc.mel", d_mel_tm_, B * mel_rows_ * cfg_.n_mels}, {"enc.conv1", d_h1_, B * h1_rows_ * d}, {"enc.ln", d_ln_, B * T * d},
+      {"enc.q", d_q_, B * T * d}, {"enc.k", d_k_, B * T * d}, {"enc.vt", d_vt_, B * d * t_pad_}, {"enc.attn", d_attn_, B * T * d},
+      {"enc.ffn_hidden", d_ffn_, B * T * 4 * d},
+      {"cross_k", d_cross_k_, L * (size_t)cap_ * H * t_pad_ * 64}, {"cross_v", d_cross_v_, L * (size_t)cap_ * H * t_pad_ * 64},
+      {"self_k", d_self_k_, L * (size_t)cap_ * H * Tc * 64}, {"self_v", d_self_v_, L * (size_t)cap_ * H * Tc * 64},
+      {"dec.act_hi", d_act_[0], (size_t)nbs_ * 16 * d}, {"dec.act_lo", d_act_[1], (size_t)nbs_ * 16 * d},
+      {"dec.att_hi", d_att_[0], (size_t)nbs_ * 16 * d}, {"dec.att_lo", d_att_[1], (size_t)nbs_ * 16 * d},
+      {"dec.hid_hi", d_hidp_[0], (size_t)nbs_ * 16 * 4 * d}, {"dec.hid_lo", d_hidp_[1], (size_t)nbs_ * 16 * 4 * d},
+  };
+  if (d_self_k1_) {
+    bufs.push_back({"persist.self_k1", d_self_k1_, self1_bytes_ / 2 * (size_t)std::max(persist_max_clips_ - 1, 1)});
+    bufs.push_back({"persist.self_v1", d_self_v1_, self1_bytes_ / 2 * (size_t)std::max(persist_max_clips_ - 1, 1)});
+  }
+  const int n = std::min<int>(n_max, (int)bufs.size());
+  unsigned long long* d_res = nullptr;
+  HIP_CHECK(hipMalloc((void**)&d_res, (size_t)n * 16));
+  HIP_CHECK(hipMemset(d_res, 0, (size_t)n * 16));
+  hipStream_t s = stream();
+  for (int i = 0; i < n; ++i)
+    scan16_kernel<<<1024, 256, 0, s>>>(bufs[i].p, bufs[i].n, d_res + 2 * i, reinterpret_cast<unsigned*>(d_res + 2 * i + 1));
+  std::vector<unsigned long long> h((size_t)n * 2);
+  HIP_CHECK(hipMemcpyAsync(h.data(), d_res, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  (void)hipFree(d_res);
+  for (int i = 0; i < n; ++i) {
+    snprintf(names[i], 32, "%s", bufs[i].name);
+    nonfinite[i] = (long long)h[2 * i];
+    const unsigned bits = (unsigned)(h[2 * i + 1] & 0xffffffffu);
+    memcpy(&maxabs[i], &bits, 4);
+  }
+  return n;
+}
+
 float Engine::bench(const std::string& what, int batch, int arg, int iters) {
   require_no_stream("bench");
   HIP_CHECK(hipSetDevice(device_));

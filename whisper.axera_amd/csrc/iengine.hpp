@@ -45,6 +45,9 @@ class IEngine {
   virtual int stream_step(int n_steps, int* finished_slots) = 0;  // returns the number of finished slots written
   virtual void stream_collect(int slot, int32_t* ids, int* n_ids) = 0;
   virtual void stream_close() = 0;
+  // every 16-bit tensor the engine STORES between kernels (encoder activations of `batch` clips, cross / self K/V caches, the
+  // decoder's activation pairs): non-finite count and max |x| per buffer; returns the number of buffers reported (<= n_max)
+  virtual int scan_stored16(int batch, int n_max, char (*names)[32], long long* nonfinite, float* maxabs) = 0;
   virtual float bench(const std::string& what, int batch, int arg, int iters) = 0;
   virtual void set_stream(void* hip_stream) = 0;
   virtual const ModelConfig& config() const = 0;

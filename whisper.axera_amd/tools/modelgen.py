@@ -172,6 +172,147 @@ def synth_weights(dims: dict, seed: int = 0, bf16: bool = True) -> Dict[str, np.
     return out
 
 
+def _round16(x: np.ndarray, dtype: str) -> np.ndarray:
+    if dtype == "F16":
+        return x.astype(np.float16).astype(np.float32)
+    if dtype == "BF16":
+        return bf16_round(x)
+    return x.astype(np.float32)
+
+
+def realistic_weights(dims: dict, seed: int = 0, dtype: str = "BF16", outlier_rel: float = 14.0, hidden_peak: float = 6000.0,
+                      logit_gain: float = 1.0, temps=(0.2, 2.0, 4.0, 8.0), out_scale: float = 1.0,
+                      gain_centre: float = 4.0, v_damp: float = 2.0) -> Dict[str, np.ndarray]:
+    """Seeded weights whose ACTIVATIONS look like a trained Whisper's instead of N(0, 0.02) everywhere (no checkpoint exists
+    in the reference or this image; tests/golden/probe_realistic_stats.py prints what these produce):
+
+      * a few residual channels carry |x| of 10^2..10^3 in both stacks (a bias and a scaled row of an early mlp.2, the decoder's
+        positional embedding), so every later LayerNorm sees one channel that owns most of the variance;
+      * LayerNorm gains spread over 0.2..30 (log-normal, re-amplifying what the outlier channel shrank; tiny on the outlier
+        channels themselves, as trained models do), biases up to +-2;
+      * attention heads cycle through four temperatures: flat over all keys (scores ~1e-2), ordinary, peaked, and saturated
+        (one key >> the rest) — query and key rows of a head scaled together (export_onnx.py:116-126 scales both);
+      * a few FFN hidden units run at `hidden_peak` (thousands: a third of the half range when it is 6000; GELU is the
+        identity there) and feed back through small mlp.2 columns;
+      * token-embedding rows with log-normal norms and a final LayerNorm gain that put the logit std at >= 5, top-2 margins
+        from ~1e-3 to ~10.
+    Coordinate 0 of the residual stream is left ordinary (tests/eot_case.py reserves it). Values are rounded to `dtype`
+    (both sides of a parity test then hold identical numbers)."""
+    w = dict(synth_weights(dims, seed, bf16=False))
+    rng = np.random.Generator(np.random.PCG64(seed * 1000003 + 7919))
+    d, H = dims["d"], dims["heads"]
+    f32 = np.float32
+    oc = rng.choice(np.arange(1, d), size=4, replace=False)  # outlier channels: two per stack
+    outlier = outlier_rel * np.sqrt(d)                       # 158 (d = 128) .. 388 (768) .. 500 (1280)
+    shrink = outlier_rel                                     # what a LayerNorm behind an outlier of that size divides by
+
+    def gains(n, centre, lo_ch=()):
+        g = centre * np.exp(rng.standard_normal(n) * 0.6)
+        hot = rng.choice(n, size=max(1, n // 96), replace=False)
+        g[hot] = rng.uniform(12.0, 30.0, size=len(hot))
+        g = np.clip(g, 0.05, 30.0)
+        for c in lo_ch:
+            g[c] = rng.uniform(0.02, 0.1)
+        return g.astype(f32)
+
+    def ln_bias(n):
+        b = rng.standard_normal(n) * 0.02
+        hot = rng.choice(n, size=max(1, n // 128), replace=False)
+        b[hot] = rng.uniform(-2.0, 2.0, size=len(hot))
+        return b.astype(f32)
+
+    # temps: factor on a head's query AND key rows: scores go with its square
+
+    def heads(prefix, first):
+        for h in range(H):
+            t = f32(temps[(h + 3 * first) % 4])
+            for n in ("query.weight", "query.bias", "key.weight"):
+                w[f"{prefix}.{n}"][h * 64:(h + 1) * 64] *= t
+            if t > 1.0 and v_damp:
+                # a head whose scores have std s turns a relative perturbation of q or k into s times that much on its
+                # output; with every head writing O(1) into the stream a 12-layer stack amplifies rounding 1e4-fold (fp32
+                # itself is then 0.1 logits from fp64, bfloat16 tens). Trained stacks are not chaotic: hot heads write
+                # proportionally less, so that sensitivity x weight is the same for every temperature
+                for n in ("value.weight", "value.bias"):
+                    w[f"{prefix}.{n}"][h * 64:(h + 1) * 64] /= t ** v_damp
+
+    def stack(side, n_layers, c_bias, c_row, cross):
+        for l in range(n_layers):
+            p = f"{side}.blocks.{l}"
+            behind = l > 0 or side == "decoder"   # an outlier channel is already in the stream
+            centre = min(shrink, gain_centre) if behind else 1.0
+            lo = (c_bias, c_row) if behind else ()
+            for ln in (["attn_ln", "cross_attn_ln", "mlp_ln"] if cross else ["attn_ln", "mlp_ln"]):
+                w[f"{p}.{ln}.weight"] = gains(d, centre, lo)
+                w[f"{p}.{ln}.bias"] = ln_bias(d)
+            heads(f"{p}.attn", l)
+            if cross:
+                heads(f"{p}.cross_attn", l + 2)
+            # a few hidden units far out: mlp.0 rows scaled up with a positive bias, their mlp.2 columns small
+            hot = rng.choice(4 * d, size=3, replace=False)
+            for j in hot:
+                w[f"{p}.mlp.0.weight"][j] *= f32(40.0)
+                w[f"{p}.mlp.0.bias"][j] = f32(hidden_peak * rng.uniform(0.5, 1.0))
+                w[f"{p}.mlp.2.weight"][:, j] *= f32(1e-4)
+            # out_scale > 1: what a block adds outgrows the stream. Kept at 1: every saturated head multiplies a relative
+            # perturbation by its score magnitude, and with larger block outputs fp32 itself drifts from fp64 tenfold
+            # per layer (probe_realistic_stats.py prints fp32-vs-fp64 next to the statistics)
+            for n in (["attn.out", "cross_attn.out", "mlp.2"] if cross else ["attn.out", "mlp.2"]):
+                w[f"{p}.{n}.weight"] *= f32(out_scale)
+        p0 = f"{side}.blocks.0"
+        w[f"{p0}.mlp.2.bias"][c_bias] = f32(outlier if side == "encoder" else -outlier)
+        w[f"{p0}.mlp.2.weight"][c_row] *= f32(20.0)
+
+    stack("encoder", dims["enc_layers"], oc[0], oc[1], False)
+    stack("decoder", dims["dec_layers"], oc[2], oc[3], True)
+    w["encoder.ln_post.weight"] = gains(d, min(shrink, gain_centre), (oc[0], oc[1]))
+    w["encoder.ln_post.bias"] = ln_bias(d)
+    # decoder: the outlier is there from the first LayerNorm on (positional embedding), varying along the context
+    pe = w["decoder.positional_embedding"] * f32(10.0)
+    t = np.arange(pe.shape[0], dtype=np.float64)
+    pe[:, oc[2]] += (0.75 * outlier * (1.0 + 0.2 * np.sin(t / 7.0))).astype(f32)
+    w["decoder.positional_embedding"] = pe
+    # ... and is taken out again by the last block (mean of the two injections), so that the final LayerNorm sees
+    # only its variation along the context: trained stacks remove their massive activations before the output
+    w[f"decoder.blocks.{dims['dec_layers'] - 1}.mlp.2.bias"][oc[2]] += f32(0.25 * outlier)
+    emb = w["decoder.token_embedding.weight"] * f32(12.0)
+    emb *= np.exp(rng.standard_normal(emb.shape[0]) * 0.3).astype(f32)[:, None]
+    emb[:, oc[2]] *= f32(0.1)   # the outlier channel reaches the logits through a tiny gain only
+    w["decoder.token_embedding.weight"] = emb
+    near_dup = True
+    # the stream's non-outlier part grows with depth, and the logit std with it: ~8-12 at every depth with this
+    g = gains(d, float(np.clip(80.0 / np.sqrt(d), 1.5, 8.0)) * logit_gain / (dims["dec_layers"] / 2.0), (oc[2], oc[3]))
+    w["decoder.ln.weight"] = g
+    w["decoder.ln.bias"] = ln_bias(d)
+    out = {k: _round16(v, dtype) for k, v in w.items()}
+    if near_dup:
+        # the top-2 margin spectrum of a trained vocabulary (near-synonyms, spelling variants): every other text row is its
+        # left neighbour with k of its entries moved to the next 16-bit value, k = 0 (an exact tie: the LOWER id must win,
+        # Whisper.cpp:42-45), 1, 2, 8, 32, all — margins from 0 over ~1e-3 to several units whenever such a pair leads
+        e = out["decoder.token_embedding.weight"]
+        ks = (0, 1, 2, 8, 32, d)
+        for v in range(1, 50257, 2):
+            if (v // 2) % 2:   # every other pair stays two independent rows (margins of units)
+                continue
+            k = ks[(v // 4) % len(ks)]
+            row = e[v - 1].copy()
+            if k:
+                idx = rng.choice(d, size=k, replace=False) if k < d else np.arange(d)
+                row[idx] = _next16(row[idx], dtype)
+            e[v] = row
+    return out
+
+
+def _next16(x: np.ndarray, dtype: str) -> np.ndarray:
+    """The next representable value of `dtype` away from zero (one unit in the last place)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if dtype == "F16":
+        h = x.astype(np.float16)
+        return (h.view(np.uint16) + np.uint16(1)).view(np.float16).astype(np.float32)
+    step = np.uint32(0x10000 if dtype == "BF16" else 0x100)
+    return (x.view(np.uint32) + step).view(np.float32)
+
+
 # ----------------------------------------------------------------------------- safetensors
 def write_safetensors(path: str, tensors: Dict[str, np.ndarray], dtype: str = "BF16") -> None:
     """Minimal safetensors writer (8-byte LE header length, JSON header, raw little-endian data)."""
