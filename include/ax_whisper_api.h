@@ -103,6 +103,14 @@ AX_WHISPER_API int AX_WHISPER_Detokenize(AX_WHISPER_HANDLE handle, const int32_t
  *  $AX_WHISPER_OPENCC_DIR, the working directory (the reference's rule) or the model directory. Host-only. */
 AX_WHISPER_API int AX_WHISPER_ConvertT2S(const char* config_path, const char* text, char** result);
 
+/** The file decode of AX_WHISPER_RunFile on its own, host only (no handle, no GPU): WAV / AIFF -> the mono f32 samples RunFile
+ *  feeds the engine (cpp/src/AudioFile.h:450-501,1241-1243 + the stereo average of ax_whisper_api.cpp:105-113). *samples is
+ *  malloc'd, the caller frees it; info (may be NULL): [0] sample rate, [1] channels. 0 ok, -1 error. */
+AX_WHISPER_API int AX_WHISPER_LoadAudioFile(const char* path, float** samples, int* n_samples, int* info);
+/** ids -> bytes through a {type}-tokens.txt file alone, host only (Whisper.cpp:115-127 table load, :224-229 + base64.cpp:84-120
+ *  decode): the bytes AX_WHISPER_Detokenize returns, with their count (an entry may hold a NUL). *result malloc'd. */
+AX_WHISPER_API int AX_WHISPER_DetokenizeWithTable(const char* tokens_path, const int32_t* ids, int n, char** result, int* n_bytes);
+
 /* ---- additions: stage-level entry points (parity tests, profiling) ------------------- */
 
 /** Whisper::preprocess (Whisper.cpp:151-184) on the GPU. mel_out: host [n_mels*3000] f32. */

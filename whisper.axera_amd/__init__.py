@@ -46,6 +46,8 @@ SYMBOLS = {
     "AX_WHISPER_Detokenize": (C.c_int, [C.c_void_p, ip, C.c_int, C.POINTER(C.c_void_p)]),
     "AX_WHISPER_Transcript": (C.c_int, [C.c_void_p, ip, C.c_int, C.POINTER(C.c_void_p)]),
     "AX_WHISPER_ConvertT2S": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "AX_WHISPER_LoadAudioFile": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "AX_WHISPER_DetokenizeWithTable": (C.c_int, [C.c_char_p, ip, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "AX_WHISPER_ComputeMel": (C.c_int, [C.c_void_p, fp, C.c_int, fp]),
     "AX_WHISPER_EncodeMel": (C.c_int, [C.c_void_p, fp, C.c_int]),
     "AX_WHISPER_GetCrossKV": (C.c_int, [C.c_void_p, C.c_int, fp, fp]),
@@ -97,6 +99,29 @@ def convert_t2s(config_path: str, text: str) -> str:
     s = C.string_at(out.value).decode("utf-8")
     L._free(out.value)
     return s
+
+
+def load_audio_file(path: str):
+    """The file decode of AX_WHISPER_RunFile on its own (host only) -> (mono f32 samples, sample rate, channels)."""
+    L = load_library()
+    out, n, info = C.c_void_p(), C.c_int(), (C.c_int * 2)()
+    if L.AX_WHISPER_LoadAudioFile(os.fspath(path).encode(), C.byref(out), C.byref(n), info) != 0:
+        raise RuntimeError("AX_WHISPER_LoadAudioFile failed: " + (L.AX_WHISPER_LastError(None) or b"").decode())
+    a = np.ctypeslib.as_array(C.cast(out, fp), shape=(max(n.value, 1),))[: n.value].copy()
+    L._free(out.value)
+    return a, info[0], info[1]
+
+
+def detokenize_with_table(tokens_path: str, ids) -> bytes:
+    """ids -> bytes through a tokens file alone (host only): what Whisper.detokenize returns for them."""
+    L = load_library()
+    a = np.ascontiguousarray(ids, dtype=np.int32)
+    out, n = C.c_void_p(), C.c_int()
+    if L.AX_WHISPER_DetokenizeWithTable(os.fspath(tokens_path).encode(), a.ctypes.data_as(ip), len(a), C.byref(out), C.byref(n)) != 0:
+        raise RuntimeError("AX_WHISPER_DetokenizeWithTable failed: " + (L.AX_WHISPER_LastError(None) or b"").decode())
+    b = C.string_at(out.value, n.value)
+    L._free(out.value)
+    return b
 
 
 def _f32(a):

@@ -293,6 +293,55 @@ AX_WHISPER_API int AX_WHISPER_ConvertT2S(const char* config_path, const char* te
   }
 }
 
+// the two byte paths of the drop-in boundary on their own, host only (no handle, no GPU): parity tests hold them bit-equal to
+// the reference's AudioFile.h / base64.cpp compiled into oracle/_ref (tests/test_byte_paths.py)
+AX_WHISPER_API int AX_WHISPER_LoadAudioFile(const char* path, float** samples, int* n_samples, int* info) {
+  if (!path || !samples || !n_samples) return -1;
+  *samples = nullptr;
+  *n_samples = 0;
+  try {
+    axw::WavData wav;
+    std::string err;
+    if (!axw::load_audio_file(path, wav, err)) { g_init_error = "load wav failed: " + err; return -1; }
+    *samples = static_cast<float*>(malloc(std::max<size_t>(wav.mono.size(), 1) * sizeof(float)));
+    if (!*samples) return -1;
+    memcpy(*samples, wav.mono.data(), wav.mono.size() * sizeof(float));
+    *n_samples = (int)wav.mono.size();
+    if (info) { info[0] = wav.sample_rate; info[1] = wav.channels; }
+    return 0;
+  } catch (const std::exception& e) {
+    g_init_error = e.what();
+    return -1;
+  } catch (...) {
+    g_init_error = "unknown error";
+    return -1;
+  }
+}
+
+AX_WHISPER_API int AX_WHISPER_DetokenizeWithTable(const char* tokens_path, const int32_t* ids, int n, char** result, int* n_bytes) {
+  if (!tokens_path || (n > 0 && !ids) || !result || !n_bytes) return -1;
+  *result = nullptr;
+  *n_bytes = 0;
+  try {
+    const std::vector<std::string> table = axw::load_token_table(tokens_path);
+    std::string s;
+    for (int i = 0; i < n; ++i)
+      if (ids[i] >= 0 && (size_t)ids[i] < table.size()) s += table[(size_t)ids[i]];
+    *result = static_cast<char*>(malloc(s.size() + 1));
+    if (!*result) return -1;
+    memcpy(*result, s.data(), s.size());
+    (*result)[s.size()] = 0;
+    *n_bytes = (int)s.size();
+    return 0;
+  } catch (const std::exception& e) {
+    g_init_error = e.what();
+    return -1;
+  } catch (...) {
+    g_init_error = "unknown error";
+    return -1;
+  }
+}
+
 AX_WHISPER_API int AX_WHISPER_GetConfigInt(AX_WHISPER_HANDLE handle, const char* key) {
   Handle* h = H(handle);
   if (!h || !key || h->group.size() == 0) return INT_MIN;

@@ -257,6 +257,9 @@ inline std::vector<std::string> load_token_table(const std::string& path) {
     size_t i = line.find(' ');
     std::string b64 = line.substr(0, i), bytes;
     if (!base64_decode(b64, bytes)) throw std::runtime_error("bad base64 in tokens file line " + std::to_string(table.size()));
+    // the reference appends an entry as a C string (base64.cpp:117 strcpy, Whisper.cpp:228 `s += str`): bytes from a NUL on
+    // never reach the text (id 188 decodes to one NUL byte: it contributes nothing, and the text goes on behind it)
+    bytes.resize(strlen(bytes.c_str()));
     table.push_back(bytes);
   }
   return table;
