@@ -398,6 +398,7 @@ void launch_advance(const AdvanceParams& p, hipStream_t s);
 typedef unsigned long long u64;
 struct PersistParams {
   const h16* wl; const float* fl;   // decoder-layer weight arenas (DecArena layout)
+  const float* qf;                  // one-clip launch, d_model <= 768: the query-fold arena (decode_persistent.hip), nullptr = unfolded
   const h16* tok_emb; const float* pos; const float* ln_w; const float* ln_b;
   const h16* cross_k; const h16* cross_v; long cross_layer_stride;  // this clip's slot, layer 0
   int n_layer, n_vocab, n_ctx, n_audio_ctx;
@@ -426,6 +427,8 @@ struct PersistParams {
 bool decode_persistent_supported(int d_model, int n_head, int n_layer, int n_cu);
 int decode_persistent_grid(int d_model, int n_cu);
 size_t decode_persistent_gran_bytes(int d_model, int grid);   // granule area; the error word sits in its last 8 bytes
+size_t qfold_floats(int d_model, int n_layer);                // floats of the query-fold arena
+void launch_qfold_build(const h16* wl, const float* fl, float* qf, int d_model, int n_layer, hipStream_t s);
 hipError_t launch_decode_persistent(const PersistParams& p, int d_model, int grid, hipStream_t s);
 hipError_t launch_decode_persistent2(const PersistParams& p, int d_model, int grid, hipStream_t s);  // n_clip == 2 (decode_persistent2.hip)
 int decode_persistent_max_clips(int d_model, int n_head, int n_layer, int grid);  // clips per persistent launch: 1, 2 or 3  // shapes whose every linear layer is ONE pass of rows per workgroup

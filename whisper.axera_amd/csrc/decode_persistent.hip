@@ -32,9 +32,87 @@
 namespace axw {
 inline namespace AXW_NS {
 
+// ---------------------------------------------------------------------------------------- query fold (round 5)
+// A layer of the launch was eight dependent all-to-all hand-offs; three of them carried the self-attention output to the
+// cross-attention units:   att -> [hop] -> out-projection rows -> y1 -> [hop] -> LayerNorm(x0 + y1) -> query rows -> [hop]
+// The query is linear in everything but the LayerNorm statistics (export_onnx.py:221-230, 238-261):
+//   cq_j = r (A0_j + (M a)_j + d_j - mu s_j) + c_j,    x1 = x0 + W_o a + b_o,  mu / r = mean / rstd of x1
+//   A0 = W_cq (g . x0)   — needs only the layer's input: computed by the row producers WHILE self-attention runs
+//   M  = W_cq diag(g) W_o (fp32, built once at load), d = W_cq (g . b_o), s = W_cq g, c = W_cq beta + b_cq
+// so the 16-row producers of y1 also produce T = A0 + M a + d for the same 16 rows and the two sums of their x1 slice, and
+// a cross-attention unit finishes its head's query from 64 T granules + 2 x (number of producers) statistics: the middle
+// hop, the LayerNorm stage (two workgroup barriers in every workgroup) and the query-row phase are gone; y1 is added to
+// the residual copies together with y2 (same order of additions: the stream is bit-identical to the unfolded launch).
+// fp32 weight rows of M: LPR lanes share a row, 2 * CH chunks of 4 floats per lane (element layout of rows_dot).
+template <int LPR, int CH>
+struct RowSetF32 {
+  u32x4 w[2 * CH];
+  float bias;
+  __device__ __forceinline__ void prefetch(const float* W, const float* b, int K, int row, bool on, int ctid) {
+    const int j = ctid % LPR;
+    const float* wr = W + (long)row * K;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      w[2 * i] = *reinterpret_cast<const u32x4*>(wr + (j + LPR * i) * 8);
+      w[2 * i + 1] = *reinterpret_cast<const u32x4*>(wr + (j + LPR * i) * 8 + 4);
+    }
+    bias = (on && j == 0) ? b[row] : 0.f;
+  }
+  __device__ __forceinline__ float run(const float* act, int ctid) const {
+    const int j = ctid % LPR;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const float4 x0 = *reinterpret_cast<const float4*>(act + (j + LPR * i) * 8);
+      const float4 x1 = *reinterpret_cast<const float4*>(act + (j + LPR * i) * 8 + 4);
+      a0 = fmaf(__uint_as_float(w[2 * i][0]), x0.x, a0); a1 = fmaf(__uint_as_float(w[2 * i][1]), x0.y, a1);
+      a0 = fmaf(__uint_as_float(w[2 * i][2]), x0.z, a0); a1 = fmaf(__uint_as_float(w[2 * i][3]), x0.w, a1);
+      a0 = fmaf(__uint_as_float(w[2 * i + 1][0]), x1.x, a0); a1 = fmaf(__uint_as_float(w[2 * i + 1][1]), x1.y, a1);
+      a0 = fmaf(__uint_as_float(w[2 * i + 1][2]), x1.z, a0); a1 = fmaf(__uint_as_float(w[2 * i + 1][3]), x1.w, a1);
+    }
+    return group_sum<LPR>(a0 + a1) + bias;
+  }
+};
+
+// per-layer block of the fold arena (floats): M [D][D], then d, s, c [D] each
+__host__ __device__ constexpr long qfold_stride(int d) { return (long)d * d + 3L * d; }
+
+// M = W_cq diag(g) W_o in double, one thread per element; d, s, c by the first D threads of block row 0
+__global__ void qfold_build_kernel(const h16* __restrict__ wl, const float* __restrict__ fl, float* __restrict__ qf, int D) {
+  const int l = blockIdx.z;
+  const long DD = (long)D * D;
+  const h16* wq = wl + (long)l * DecArena::w_stride(D) + DecArena::W_CQ * DD;
+  const h16* wo = wl + (long)l * DecArena::w_stride(D) + DecArena::W_O * DD;
+  const float* F = fl + (long)l * DecArena::f_stride(D);
+  const float *g = F + DecArena::F_CROSS_LN_W * D, *be = F + DecArena::F_CROSS_LN_B * D, *bo = F + DecArena::F_B_O * D, *bq = F + DecArena::F_B_CQ * D;
+  float* out = qf + (long)l * qfold_stride(D);
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (k >= D) return;
+  double acc = 0.0;
+  for (int i = 0; i < D; ++i) acc += (double)(float)wq[(long)j * D + i] * (double)g[i] * (double)(float)wo[(long)i * D + k];
+  out[(long)j * D + k] = (float)acc;
+  if (k == 0) {
+    double dd = 0.0, ss = 0.0, cc = 0.0;
+    for (int i = 0; i < D; ++i) {
+      const double w = (double)(float)wq[(long)j * D + i];
+      dd += w * (double)g[i] * (double)bo[i];
+      ss += w * (double)g[i];
+      cc += w * (double)be[i];
+    }
+    out[DD + j] = (float)dd;
+    out[DD + D + j] = (float)ss;
+    out[DD + 2 * D + j] = (float)(cc + (double)bq[j]);
+  }
+}
+void launch_qfold_build(const h16* wl, const float* fl, float* qf, int d_model, int n_layer, hipStream_t s) {
+  qfold_build_kernel<<<dim3((d_model + 127) / 128, d_model, n_layer), 128, 0, s>>>(wl, fl, qf, d_model);
+}
+size_t qfold_floats(int d_model, int n_layer) { return (size_t)n_layer * (size_t)qfold_stride(d_model); }
+
 // ---------------------------------------------------------------------------------------- the kernel
 // d_model = 8*LD*CD (rows with K = d: LD lanes x CD 16-byte chunks), 4*d_model = 8*LF*CF.
-template <int LD, int CD, int LF, int CF, bool PROF>
+// QF: the query fold above (d_model <= 768: the fp32 rows of M cost 2 * CD more registers per lane)
+template <int LD, int CD, int LF, int CF, bool PROF, bool QF>
 __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) {
   constexpr int D = 8 * LD * CD, F = 8 * LF * CF, H = D / 64;
   static_assert(F == 4 * D, "mlp width");
@@ -45,7 +123,8 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   constexpr int NU = kCrossSplit * H;  // cross-attention units per layer
   // granule buffers (u64 units)
   constexpr int O_QKV = 0, O_ATT = 3 * D, O_Y1 = 4 * D, O_CQ = 5 * D, O_PART = 6 * D, O_Y2 = 10 * D, O_HID = 11 * D, O_Y3 = 15 * D,
-                O_AMAX = 16 * D;
+                O_AMAX = 16 * D, O_STAT = 16 * D + 512;  // statistics of producer p: granules O_STAT + 16 p, + 1 (a line of its own)
+  constexpr int XG = D, X0R = 2 * D;  // QF: act[XG..) = g_cross . x0, act[X0R..) = x0 (written with the QKV LayerNorm, read by the row producers)
   static_assert(NPART <= 3 * D + D / 8 && NU * kRec <= 4 * D, "partial buffer");
   static_assert(kCrossSplit * NCW == 24, "cross-attention key blocks");
 
@@ -54,8 +133,8 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   h16* sV = sK + NCW * 4096;                                // cross tiles: [512 keys][64]; self-attention cache: per block [8 (key/8)][64 dims][8 keys]
   float* act = reinterpret_cast<float*>(smem + kKvBytes);    // [F + D/8] input vector of the current rows phase
   float* wpart = act + F + D / 8;                            // [NCW][kPS] per-wave attention partials
-  float* red = wpart + NCW * kPS;                            // [2*NPW] LayerNorm partial sums
-  unsigned* qs = reinterpret_cast<unsigned*>(red + 2 * NPW);  // [64] query of the attention phase as packed h16 pairs: [32] hi, [32] lo
+  float* red = wpart + NCW * kPS;                            // [2*NPW] LayerNorm partial sums, [2*NPW] = the stage's mean (QF: the statistics' shift)
+  unsigned* qs = reinterpret_cast<unsigned*>(red + 2 * NPW + 4);  // [64] query of the attention phase as packed h16 pairs: [32] hi, [32] lo
   float* am_v = reinterpret_cast<float*>(qs) + 64;           // [16] argmax scratch
   int* am_i = reinterpret_cast<int*>(am_v + 16);             // [16]
   int* ctl = am_i + 16;                                      // [16]: 0 give-up flag, 1 argmax of the step
@@ -133,6 +212,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     // ======================================================================================= pollers
     float x[GD];        // residual stream, element tid + k*PL
     float lg[GD], lb[GD];
+    float g2[GD];       // QF: see the QKV stage
+#pragma unroll
+    for (int k = 0; k < GD; ++k) g2[k] = 0.f;
     float shift = 0.f;  // LayerNorm variance shift (previous mean): sums stay small without a second pass
     auto el = [&](int k) { return 2 * (tid + (k >> 1) * PL) + (k & 1); };  // vector element of register slot k
     auto ln_prefetch = [&](const float* g, const float* be) {
@@ -147,7 +229,10 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
 #define AXW_PAIRS_D(BASE) [&](int j) { const int pr = tid + j * PL; return 2 * pr < D ? (BASE) + 2 * pr : -1; }
 
     // x += y, LayerNorm into act[0..D): two workgroup barriers
-#define AXW_LN_STAGE(Y, ADD, FAIL, CODE)                                                    \
+#define AXW_LN_STAGE(Y, ADD, FAIL, CODE) AXW_LN_STAGE_X(Y, ADD, FAIL, CODE, false)
+    // XGW (QF, row producers, QKV stage): also leave g_cross . x and x itself in act[XG..), act[X0R..) — behind the stage's
+    // first barrier, when the compute waves have left the previous phase (mlp.2 reads all of act)
+#define AXW_LN_STAGE_X(Y, ADD, FAIL, CODE, XGW)                                             \
   {                                                                                          \
     float s1 = 0.f, s2 = 0.f;                                                                \
     _Pragma("unroll") for (int k = 0; k < GD; ++k) {                                         \
@@ -165,9 +250,11 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     _Pragma("unroll") for (int w2 = 0; w2 < NPW; ++w2) { t1 += red[2 * w2]; t2 += red[2 * w2 + 1]; } \
     const float dm = t1 / D, var = fmaxf(t2 / D - dm * dm, 0.f);                             \
     const float mean = shift + dm, rstd = rsqrtf(var + 1e-5f);                               \
+    if (QF && tid == 0) red[2 * NPW] = mean;                                                 \
     _Pragma("unroll") for (int k = 0; k < GD; ++k) {                                         \
       const int i = el(k);                                                                   \
       if (i < D) act[i] = (x[k] - mean) * rstd * lg[k] + lb[k];                              \
+      if (QF && (XGW) && i < D) { act[XG + i] = x[k] * g2[k]; act[X0R + i] = x[k]; }         \
     }                                                                                        \
     shift = mean;                                                                            \
     wg_barrier();                                                                            \
@@ -191,11 +278,18 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         {
           unsigned y[GD];
           bool fail = false;
+          if constexpr (QF) {  // row producers: the cross-attention LayerNorm's gain (A0 = W_cq (g . x0))
+            if (in_o) {
+#pragma unroll
+              for (int k = 0; k < GD; ++k) { const int i = el(k); g2[k] = i < D ? FL[DecArena::F_CROSS_LN_W * D + i] : 0.f; }
+            }
+          }
           if (l > 0) fail = gather2<GPD>(GR, tag - 1, y, p.err, ctl, AXW_PAIRS_D(O_Y3));
           AXW_STAMP(0)
           AXW_TL(0)
-          AXW_LN_STAGE(y, l > 0, fail, 0x100 + l)
-          ln_prefetch(FL + DecArena::F_CROSS_LN_W * D, FL + DecArena::F_CROSS_LN_B * D);
+          AXW_LN_STAGE_X(y, l > 0, fail, 0x100 + l, in_o)
+          if constexpr (QF) ln_prefetch(FL + DecArena::F_MLP_LN_W * D, FL + DecArena::F_MLP_LN_B * D);
+          else ln_prefetch(FL + DecArena::F_CROSS_LN_W * D, FL + DecArena::F_CROSS_LN_B * D);
           AXW_STAMP(1)
           AXW_TL(1)
         }
@@ -236,7 +330,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_BARRIER_CHECK(0x300 + l)
         }
         // ---- cross-attention query
-        {
+        if constexpr (!QF) {
           unsigned y[GD];
           const bool fail = gather2<GPD>(GR, tag, y, p.err, ctl, AXW_PAIRS_D(O_Y1));
           AXW_STAMP(5)
@@ -250,15 +344,51 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         const int cu = ca_unit_of(step * L + l);
         if (cu >= 0) {
           const int ca_head = cu / kCrossSplit;
-          unsigned v[2];
-          const bool fail = gather2<1>(GR, tag, v, p.err, ctl, [&](int) { return tid < 32 ? O_CQ + ca_head * 64 + 2 * tid : -1; });
-          if (tid < 32) {
-            unsigned hi, lo;
-            h16split2(__uint_as_float(v[0]), __uint_as_float(v[1]), hi, lo);
-            qs[tid] = hi;
-            qs[32 + tid] = lo;
+          if constexpr (QF) {
+            // wave 0: lanes 0-31 the head's 64 T values (pairs), lanes 32.. the producers' statistics (NP_D pairs, up to two per
+            // lane); cq_j = r (T_j - mu s_j) + c_j with mu, r from the summed statistics (shift = this layer's input mean,
+            // the same bits in every workgroup)
+            constexpr int SL = (NP_D + 1) / 2;  // lanes that hold statistics
+            static_assert(32 + SL <= 64, "statistics lanes");
+            float sj[2] = {0.f, 0.f}, cj[2] = {0.f, 0.f};
+            if (tid < 32) {
+              const float* qfl = AXW_COLD(qf) + (long)l * qfold_stride(D) + (long)D * D;
+              const float2 s2 = *reinterpret_cast<const float2*>(qfl + D + ca_head * 64 + 2 * tid);
+              const float2 c2 = *reinterpret_cast<const float2*>(qfl + 2 * D + ca_head * 64 + 2 * tid);
+              sj[0] = s2.x; sj[1] = s2.y; cj[0] = c2.x; cj[1] = c2.y;
+            }
+            unsigned v[4];
+            const bool fail = gather2<2>(GR, tag, v, p.err, ctl, [&](int k2) {
+              if (tid < 32) return k2 == 0 ? O_CQ + ca_head * 64 + 2 * tid : -1;
+              const int pi = (tid - 32) + k2 * SL;
+              return (tid < 32 + SL && pi < NP_D) ? O_STAT + 16 * pi : -1;
+            });
+            if (tid < 64) {
+              const bool st = tid >= 32;
+              const float t1 = wsum(st ? __uint_as_float(v[0]) + __uint_as_float(v[2]) : 0.f);
+              const float t2 = wsum(st ? __uint_as_float(v[1]) + __uint_as_float(v[3]) : 0.f);
+              const float dm = t1 / D, var = fmaxf(t2 / D - dm * dm, 0.f);
+              const float mu = shift + dm, r = rsqrtf(var + 1e-5f);
+              if (tid < 32) {
+                const float q0 = r * (__uint_as_float(v[0]) - mu * sj[0]) + cj[0], q1 = r * (__uint_as_float(v[1]) - mu * sj[1]) + cj[1];
+                unsigned hi, lo;
+                h16split2(q0, q1, hi, lo);
+                qs[tid] = hi;
+                qs[32 + tid] = lo;
+              }
+            }
+            if (fail) ctl[0] = 1;
+          } else {
+            unsigned v[2];
+            const bool fail = gather2<1>(GR, tag, v, p.err, ctl, [&](int) { return tid < 32 ? O_CQ + ca_head * 64 + 2 * tid : -1; });
+            if (tid < 32) {
+              unsigned hi, lo;
+              h16split2(__uint_as_float(v[0]), __uint_as_float(v[1]), hi, lo);
+              qs[tid] = hi;
+              qs[32 + tid] = lo;
+            }
+            if (fail) ctl[0] = 1;
           }
-          if (fail) ctl[0] = 1;
           AXW_STAMP(7)
           AXW_BARRIER_CHECK(0x500 + l)
           AXW_STAMP(8)
@@ -302,7 +432,19 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_TL(6)
         }
         // ---- mlp.0
-        {
+        if constexpr (QF) {  // x += y1, then += y2: the unfolded launch's order of additions
+          unsigned y[2 * GD];
+          const bool fail = gather2<2 * GPD>(GR, tag, y, p.err, ctl, [&](int j) { const int pr = tid + (j % GPD) * PL; return 2 * pr < D ? (j < GPD ? O_Y1 : O_Y2) + 2 * pr : -1; });
+#pragma unroll
+          for (int k = 0; k < GD; ++k) if (el(k) < D) x[k] = (x[k] + __uint_as_float(y[k])) + __uint_as_float(y[GD + k]);
+          AXW_STAMP(11)
+          AXW_TL(7)
+          AXW_LN_STAGE(y, false, fail, 0x700 + l)
+          if (l + 1 < L) ln_prefetch(FL + DecArena::f_stride(D) + DecArena::F_ATTN_LN_W * D, FL + DecArena::f_stride(D) + DecArena::F_ATTN_LN_B * D);
+          else ln_prefetch(AXW_COLD(ln_w), AXW_COLD(ln_b));
+          AXW_STAMP(12)
+          AXW_TL(8)
+        } else {
           unsigned y[GD];
           const bool fail = gather2<GPD>(GR, tag, y, p.err, ctl, AXW_PAIRS_D(O_Y2));
           AXW_STAMP(11)
@@ -375,6 +517,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
       }
     }
 #undef AXW_LN_STAGE
+#undef AXW_LN_STAGE_X
 #undef AXW_PAIRS_D
   } else {
     // ======================================================================================= compute waves
@@ -404,6 +547,8 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     // in the other (qkv A, o B, cq A, co B, mlp.0 A, [mlp.2 F], next qkv / vocabulary A)
     RowSet<LD, CD> ra, rb;
     RowSet<LF, CF> rs_fc2;
+    RowSetF32<LD, CD> rm;  // QF: this producer's rows of M = W_cq diag(g) W_o
+    float a0 = 0.f;        // QF: A0 of this slot's row
     ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, rwg, P, ctid, pk_qkv);
     {  // the first layer's cross-attention unit has no previous layer to hide behind
       const int cu0 = ca_unit_of(0);
@@ -455,6 +600,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         ra.run(w_qkv, b_qkv, D, act, ctid, res);
         ra.publish(ctid, res, pk, ctl + 2, G + O_QKV, tag, [](float v) { return v; });
         rb.prefetch(w_o, b_o, D, D, rwg, P, ctid, pk_d);
+        if constexpr (QF) {
+          if (in_o) ra.prefetch(w_cq, nullptr, D, D, rwg, P, ctid, pk_d);  // rows of W_cq for A0 (used behind the self-attention section)
+        }
         kv_piece(0, 2);
         AXW_STAMP(17)
         AXW_TL(10)
@@ -479,28 +627,72 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_TL(11)
         }
         // ---- attention output projection
-        if (in_o) {
-          AXW_BARRIER_CHECK(0x300 + l)
-          AXW_STAMP(19)
-          AXW_TL(19)
-          rb.run(w_o, b_o, D, act, ctid, res);
-          rb.publish(ctid, res, pk, ctl + 2, G + O_Y1, tag, [](float v) { return v; });
+        if constexpr (QF) {
+          // row producers: A0 = W_cq (g . x0) of this slot's row while the self-attention owners work (x0 has been in LDS since
+          // the QKV stage), then the rows of M are requested into the registers W_cq's rows leave
+          if (in_o) {
+            float ra0[2];
+            ra.run(w_cq, nullptr, D, act + XG, ctid, ra0);
+            a0 = ra0[0];
+            const float* qfl = AXW_COLD(qf) + (long)l * qfold_stride(D);
+            const int slot = ctid / LD, row = rb.r0 + slot < rb.r1 ? rb.r0 + slot : rb.r0;
+            rm.prefetch(qfl, qfl + (long)D * D, D, row, rb.r0 + slot < rb.r1, ctid);
+            AXW_BARRIER_CHECK(0x300 + l)
+            AXW_STAMP(19)
+            AXW_TL(19)
+            // y1 rows as always, T = A0 + M a + d for the same rows, and the two sums of this slice of x1 = x0 + y1:
+            // three lines, one store instruction each, all by the compute wave that arrives last
+            rb.run(w_o, b_o, D, act, ctid, res);
+            const float tq = rm.run(act, ctid) + a0;
+            const int j = ctid % LD, nrows = rb.r1 - rb.r0;
+            if (j == 0 && slot < nrows) {
+              pk[slot] = res[0];
+              pk[32 + slot] = tq;
+              pscr[slot] = (act[X0R + rb.r0 + slot] + res[0]) - red[2 * NPW];
+            }
+            __builtin_amdgcn_wave_barrier();
+            int old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(ctl + 2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if ((old + 1) % NCW == 0) {
+              const bool on = lane < nrows;
+              const float tv = on ? pscr[lane] : 0.f;
+              if (on) {
+                gput(G + O_Y1 + rb.r0 + lane, tag, pk[lane]);
+                gput(G + O_CQ + rb.r0 + lane, tag, pk[32 + lane]);
+              }
+              const float s1 = wsum(tv), s2 = wsum(tv * tv);
+              if (lane < 2) gput(G + O_STAT + 16 * rwg + lane, tag, lane == 0 ? s1 : s2);
+            }
+          }
+          rb.prefetch(w_co, b_co, D, D, rwg, P, ctid, pk_d);
+          kv_piece(2, 8);
+          AXW_STAMP(20)
+          AXW_TL(12)
+        } else {
+          if (in_o) {
+            AXW_BARRIER_CHECK(0x300 + l)
+            AXW_STAMP(19)
+            AXW_TL(19)
+            rb.run(w_o, b_o, D, act, ctid, res);
+            rb.publish(ctid, res, pk, ctl + 2, G + O_Y1, tag, [](float v) { return v; });
+          }
+          ra.prefetch(w_cq, b_cq, D, D, rwg, P, ctid, pk_d);
+          kv_piece(2, 5);
+          AXW_STAMP(20)
+          AXW_TL(12)
+          // ---- cross-attention query (export_onnx.py:221-230)
+          AXW_BARRIER_CHECK(0x400 + l)
+          wg_barrier();
+          AXW_STAMP(21)
+          AXW_TL(20)
+          ra.run(w_cq, b_cq, D, act, ctid, res);
+          ra.publish(ctid, res, pk, ctl + 2, G + O_CQ, tag, [](float v) { return v; });
+          rb.prefetch(w_co, b_co, D, D, rwg, P, ctid, pk_d);
+          kv_piece(5, 8);
+          AXW_STAMP(22)
+          AXW_TL(13)
         }
-        ra.prefetch(w_cq, b_cq, D, D, rwg, P, ctid, pk_d);
-        kv_piece(2, 5);
-        AXW_STAMP(20)
-        AXW_TL(12)
-        // ---- cross-attention query (export_onnx.py:221-230)
-        AXW_BARRIER_CHECK(0x400 + l)
-        wg_barrier();
-        AXW_STAMP(21)
-        AXW_TL(20)
-        ra.run(w_cq, b_cq, D, act, ctid, res);
-        ra.publish(ctid, res, pk, ctl + 2, G + O_CQ, tag, [](float v) { return v; });
-        rb.prefetch(w_co, b_co, D, D, rwg, P, ctid, pk_d);
-        kv_piece(5, 8);
-        AXW_STAMP(22)
-        AXW_TL(13)
         // ---- cross-attention over one third of the 1536 padded keys
         if (cu >= 0) {
           const int ca_head = cu / kCrossSplit, ca_split = cu % kCrossSplit;
@@ -720,16 +912,18 @@ bool decode_persistent_supported(int d_model, int n_head, int n_layer, int n_cu)
   if (P - n_layer * n_head < 2 * kCrossSplit * n_head) return false;  // and units of one workgroup >= 2 layers apart
   switch (d_model) { case 128: case 256: case 384: case 512: case 768: case 1280: return true; default: return false; }
 }
-size_t decode_persistent_gran_bytes(int d_model, int grid) { return ((size_t)16 * d_model + 2 * (size_t)grid + 64) * 8; }
+// 16 d-wide buffers, the argmax pairs at 16 d (up to 512 granules), the fold's statistics at 16 d + 512 (one 16-granule line
+// per row producer, at most d / 16 of them), the error word last
+size_t decode_persistent_gran_bytes(int d_model, int grid) { return ((size_t)16 * d_model + 512 + (size_t)d_model + 64 + 0 * (size_t)grid) * 8; }
 
 static size_t persist_lds_bytes(int d) {
-  return (size_t)kKvBytes + ((size_t)4 * d + d / 8 + NCW * kPS + 2 * NPW + 64 + 16 + 16 + 16 + 64 + NCW * 64) * 4 + 64 * 8 + 64;
+  return (size_t)kKvBytes + ((size_t)4 * d + d / 8 + NCW * kPS + 2 * NPW + 4 + 64 + 16 + 16 + 16 + 64 + NCW * 64) * 4 + 64 * 8 + 64;
 }
 
-template <int LD, int CD, int LF, int CF, bool PROF>
+template <int LD, int CD, int LF, int CF, bool PROF, bool QF>
 static hipError_t launch_one_prof(const PersistParams& p, int grid, hipStream_t s) {
   const size_t lds = persist_lds_bytes(8 * LD * CD);
-  auto kfn = decode_persistent_kernel<LD, CD, LF, CF, PROF>;
+  auto kfn = decode_persistent_kernel<LD, CD, LF, CF, PROF, QF>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(PT), lds, s, p);
@@ -739,7 +933,10 @@ static hipError_t launch_one_prof(const PersistParams& p, int grid, hipStream_t 
 // the profiling stamps are a separate instantiation: the production kernel carries none of their code
 template <int LD, int CD, int LF, int CF>
 static hipError_t launch_one(const PersistParams& p, int grid, hipStream_t s) {
-  return p.prof ? launch_one_prof<LD, CD, LF, CF, true>(p, grid, s) : launch_one_prof<LD, CD, LF, CF, false>(p, grid, s);
+  if constexpr (8 * LD * CD <= 768) {  // the query fold, when the engine built its arena (p.qf)
+    if (p.qf) return p.prof ? launch_one_prof<LD, CD, LF, CF, true, true>(p, grid, s) : launch_one_prof<LD, CD, LF, CF, false, true>(p, grid, s);
+  }
+  return p.prof ? launch_one_prof<LD, CD, LF, CF, true, false>(p, grid, s) : launch_one_prof<LD, CD, LF, CF, false, false>(p, grid, s);
 }
 
 hipError_t launch_decode_persistent(const PersistParams& p, int d_model, int grid, hipStream_t s) {

@@ -91,6 +91,17 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
       const char* e2 = getenv("AX_WHISPER_PERSIST2");
       persist_max_clips_ = decode_persistent_max_clips(cfg_.n_text_state, cfg_.n_text_head, cfg_.n_text_layer, persist_grid_);
       if (e2 && e2[0] >= '0' && e2[0] <= '9') persist_max_clips_ = std::max(1, std::min(persist_max_clips_, atoi(e2)));
+      // the one-clip launch with the cross-attention query folded through the output projection (decode_persistent.hip, round 5):
+      // M = W_cq diag(g) W_o in fp32 and three vectors per layer, built once here; AX_WHISPER_QFOLD=0: the unfolded launch
+      {
+        const char* eq = getenv("AX_WHISPER_QFOLD");
+        if (cfg_.n_text_state <= 768 && !(eq && eq[0] == '0')) {
+          d_qfold_ = (float*)dalloc(qfold_floats(cfg_.n_text_state, cfg_.n_text_layer) * sizeof(float));
+          allocs_.push_back(d_qfold_);
+          launch_qfold_build(dec_w_arena_, dec_f_arena_, d_qfold_, cfg_.n_text_state, cfg_.n_text_layer, own_stream_);
+          HIP_CHECK(hipStreamSynchronize(own_stream_));
+        }
+      }
       if (persist_max_clips_ >= 2) {
         self1_bytes_ = (size_t)cfg_.n_text_layer * cfg_.n_text_head * 8 * 4096 * 2;  // one later clip's cache (K; V alike)
         d_self_k1_ = (h16*)dalloc((persist_max_clips_ - 1) * self1_bytes_, true);
@@ -103,6 +114,7 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
   cfg_.ints["persistent_two_clips"] = persist_max_clips_ >= 2 ? 1 : 0;
   cfg_.ints["persistent_max_clips"] = persist_max_clips_;
   cfg_.ints["persistent_decode"] = persistent_ok_ ? 1 : 0;  // visible through AX_WHISPER_GetConfigInt
+  cfg_.ints["persistent_qfold"] = d_qfold_ ? 1 : 0;
   cfg_.ints["persistent_giveups"] = 0;
   {  // batched decode as clip-block GEMMs with LayerNorm prologue / residual epilogue (enqueue_decode_step_batched)
     const char* e = getenv("AX_WHISPER_BATCHED_LN");

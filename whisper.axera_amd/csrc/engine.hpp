@@ -188,6 +188,7 @@ class Engine final : public IEngine {
   void persistent_succeeded();
   int persist_grid_ = 0;
   u64* d_gran_ = nullptr; size_t gran_bytes_ = 0;
+  float* d_qfold_ = nullptr;  // query-fold arena of the one-clip launch (d_model <= 768), nullptr = unfolded
   std::map<long, hipGraphExec_t> graphs_;  // key: batch * 1024 + max_new
   hipEvent_t ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };

@@ -521,6 +521,7 @@ int Engine::run_persistent(int max_new, const int* d_forced, int n_forced, float
   const int Tc = cfg_.n_text_ctx, H = cfg_.n_text_head;
   PersistParams p{};
   p.wl = dec_w_arena_; p.fl = dec_f_arena_;
+  p.qf = d_qfold_;
   p.tok_emb = tok_emb_; p.pos = dec_pos_; p.ln_w = dec_ln_w_; p.ln_b = dec_ln_b_;
   p.cross_k = d_cross_k_ + (size_t)slot * H * t_pad_ * 64;  // this clip's slot, layer 0
   p.cross_v = d_cross_v_ + (size_t)slot * H * t_pad_ * 64;
