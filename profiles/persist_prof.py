@@ -31,6 +31,8 @@ if __name__ == "__main__":
     main(sys.argv[1])
 
 
+# (query fold, round 5: "P cq gathered" = a cross-attention unit has its query (T + statistics gathered), "C cq published" = a row
+# producer has published y1 / T / statistics; "P cq ln done" and "C cq rows start" do not exist there)
 TL = ["P qkv gathered", "P qkv ln done", "P o gathered", "P cq gathered", "P cq ln done", "P co gathered", "P co merged",
       "P fc1 gathered", "P fc1 ln done", "P fc2 gathered",
       "C qkv published", "C sa published", "C o published", "C cq published", "C ca published", "C co published",

@@ -109,7 +109,8 @@ def test_stream_beyond_64_slots(built_lib, micro_case):
             ck, cv = micro_case.oracle_bf16.encoder(mel)
             ids, lg = micro_case.oracle_bf16.greedy(ck, cv, "zh", max_new=budgets[i], want_logits=True)
             assert_ids_equal_or_tie(e, mel, got[i], ids, lg, f"clip {i} through 72 slots")
-        assert len(diff) <= 8
+        # the 150 clips are 8 distinct ones: a clip that sits on a tie differs in every instance whose budget reaches that step
+        assert len({i % 8 for i in diff}) <= 2, sorted({i % 8 for i in diff})
     finally:
         e.close()
 

@@ -123,8 +123,10 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   constexpr int NU = kCrossSplit * H;  // cross-attention units per layer
   // granule buffers (u64 units)
   constexpr int O_QKV = 0, O_ATT = 3 * D, O_Y1 = 4 * D, O_CQ = 5 * D, O_PART = 6 * D, O_Y2 = 10 * D, O_HID = 11 * D, O_Y3 = 15 * D,
-                O_AMAX = 16 * D, O_STAT = 16 * D + 512;  // statistics of producer p: granules O_STAT + 16 p, + 1 (a line of its own)
-  constexpr int XG = D, X0R = 2 * D;  // QF: act[XG..) = g_cross . x0, act[X0R..) = x0 (written with the QKV LayerNorm, read by the row producers)
+                O_AMAX = 16 * D, O_STAT = 16 * D + 512;  // statistics of producer p: granules O_STAT + 16 p, + 1: a line of its own (packed, 8
+                                                        // producers' partial-line stores per line: units gather 0.4 us later, 108.7 -> 111.1 ms)
+  constexpr int XG = D, X0R = 2 * D, A0S = 3 * D;  // QF: act[XG..) = g_cross . x0, act[X0R..) = x0 (written with the QKV LayerNorm, read by
+                                                  // the row producers), act[A0S + slot] = A0 of the slot's row (free until the partial records)
   static_assert(NPART <= 3 * D + D / 8 && NU * kRec <= 4 * D, "partial buffer");
   static_assert(kCrossSplit * NCW == 24, "cross-attention key blocks");
 
@@ -212,11 +214,15 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     // ======================================================================================= pollers
     float x[GD];        // residual stream, element tid + k*PL
     float lg[GD], lb[GD];
-    float g2[GD];       // QF: see the QKV stage
-#pragma unroll
-    for (int k = 0; k < GD; ++k) g2[k] = 0.f;
+    float g2[GD];       // QF, row producers: the cross-attention LayerNorm's gain of the NEXT layer to run (A0 = W_cq (g . x0)),
+                        // requested a stage ahead like lg / lb: a polling wave must have no load in flight
     float shift = 0.f;  // LayerNorm variance shift (previous mean): sums stay small without a second pass
     auto el = [&](int k) { return 2 * (tid + (k >> 1) * PL) + (k & 1); };  // vector element of register slot k
+    auto g2_prefetch = [&](int layer) {
+#pragma unroll
+      for (int k = 0; k < GD; ++k) { const int i = el(k); g2[k] = (QF && in_o && i < D) ? p.fl[(long)layer * DecArena::f_stride(D) + DecArena::F_CROSS_LN_W * D + i] : 0.f; }
+    };
+    g2_prefetch(0);
     auto ln_prefetch = [&](const float* g, const float* be) {
 #pragma unroll
       for (int k = 0; k < GD; ++k) {
@@ -278,12 +284,6 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         {
           unsigned y[GD];
           bool fail = false;
-          if constexpr (QF) {  // row producers: the cross-attention LayerNorm's gain (A0 = W_cq (g . x0))
-            if (in_o) {
-#pragma unroll
-              for (int k = 0; k < GD; ++k) { const int i = el(k); g2[k] = i < D ? FL[DecArena::F_CROSS_LN_W * D + i] : 0.f; }
-            }
-          }
           if (l > 0) fail = gather2<GPD>(GR, tag - 1, y, p.err, ctl, AXW_PAIRS_D(O_Y3));
           AXW_STAMP(0)
           AXW_TL(0)
@@ -378,6 +378,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
               }
             }
             if (fail) ctl[0] = 1;
+            AXW_TL(3)
           } else {
             unsigned v[2];
             const bool fail = gather2<1>(GR, tag, v, p.err, ctl, [&](int) { return tid < 32 ? O_CQ + ca_head * 64 + 2 * tid : -1; });
@@ -442,6 +443,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_LN_STAGE(y, false, fail, 0x700 + l)
           if (l + 1 < L) ln_prefetch(FL + DecArena::f_stride(D) + DecArena::F_ATTN_LN_W * D, FL + DecArena::f_stride(D) + DecArena::F_ATTN_LN_B * D);
           else ln_prefetch(AXW_COLD(ln_w), AXW_COLD(ln_b));
+          g2_prefetch(l + 1 < L ? l + 1 : 0);
           AXW_STAMP(12)
           AXW_TL(8)
         } else {
@@ -547,8 +549,6 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     // in the other (qkv A, o B, cq A, co B, mlp.0 A, [mlp.2 F], next qkv / vocabulary A)
     RowSet<LD, CD> ra, rb;
     RowSet<LF, CF> rs_fc2;
-    RowSetF32<LD, CD> rm;  // QF: this producer's rows of M = W_cq diag(g) W_o
-    float a0 = 0.f;        // QF: A0 of this slot's row
     ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, rwg, P, ctid, pk_qkv);
     {  // the first layer's cross-attention unit has no previous layer to hide behind
       const int cu0 = ca_unit_of(0);
@@ -599,10 +599,19 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         float res[2];
         ra.run(w_qkv, b_qkv, D, act, ctid, res);
         ra.publish(ctid, res, pk, ctl + 2, G + O_QKV, tag, [](float v) { return v; });
-        rb.prefetch(w_o, b_o, D, D, rwg, P, ctid, pk_d);
         if constexpr (QF) {
-          if (in_o) ra.prefetch(w_cq, nullptr, D, D, rwg, P, ctid, pk_d);  // rows of W_cq for A0 (used behind the self-attention section)
+          // row producers: A0 = W_cq (g . x0) of this slot's row NOW — the self-attention owners' q, k, v are still travelling
+          // (x0 has been in LDS since the QKV stage) — then W_o's rows and the rows of M into the registers W_cq's rows leave.
+          // W_cq's rows are requested first: results return in issue order, and an owner's publish of its attention vector
+          // waits for every load issued before it
+          if (in_o) {
+            ra.prefetch(w_cq, nullptr, D, D, rwg, P, ctid, pk_d);
+            float ra0[2];
+            ra.run(w_cq, nullptr, D, act + XG, ctid, ra0);
+            if (ctid % LD == 0) act[A0S + ctid / LD] = ra0[0];  // parked in LDS: the attention blocks of an owner need the registers
+          }
         }
+        rb.prefetch(w_o, b_o, D, D, rwg, P, ctid, pk_d);  // (unconditional: a set assigned on one path only stays live around the step loop)
         kv_piece(0, 2);
         AXW_STAMP(17)
         AXW_TL(10)
@@ -628,14 +637,12 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         }
         // ---- attention output projection
         if constexpr (QF) {
-          // row producers: A0 = W_cq (g . x0) of this slot's row while the self-attention owners work (x0 has been in LDS since
-          // the QKV stage), then the rows of M are requested into the registers W_cq's rows leave
           if (in_o) {
-            float ra0[2];
-            ra.run(w_cq, nullptr, D, act + XG, ctid, ra0);
-            a0 = ra0[0];
+            // the rows of M: behind the self-attention section (24 registers that the attention blocks need), and behind an
+            // owner's publish of its attention vector (a store waits for every load issued before it)
             const float* qfl = AXW_COLD(qf) + (long)l * qfold_stride(D);
             const int slot = ctid / LD, row = rb.r0 + slot < rb.r1 ? rb.r0 + slot : rb.r0;
+            RowSetF32<LD, CD> rm;  // this producer's rows of M = W_cq diag(g) W_o (scoped: a set that lived across the step loop was spilled)
             rm.prefetch(qfl, qfl + (long)D * D, D, row, rb.r0 + slot < rb.r1, ctid);
             AXW_BARRIER_CHECK(0x300 + l)
             AXW_STAMP(19)
@@ -643,11 +650,11 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
             // y1 rows as always, T = A0 + M a + d for the same rows, and the two sums of this slice of x1 = x0 + y1:
             // three lines, one store instruction each, all by the compute wave that arrives last
             rb.run(w_o, b_o, D, act, ctid, res);
-            const float tq = rm.run(act, ctid) + a0;
+            const float tq = rm.run(act, ctid);
             const int j = ctid % LD, nrows = rb.r1 - rb.r0;
             if (j == 0 && slot < nrows) {
               pk[slot] = res[0];
-              pk[32 + slot] = tq;
+              pk[32 + slot] = tq + act[A0S + slot];
               pscr[slot] = (act[X0R + rb.r0 + slot] + res[0]) - red[2 * NPW];
             }
             __builtin_amdgcn_wave_barrier();
@@ -657,13 +664,12 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
             if ((old + 1) % NCW == 0) {
               const bool on = lane < nrows;
               const float tv = on ? pscr[lane] : 0.f;
-              if (on) {
-                gput(G + O_Y1 + rb.r0 + lane, tag, pk[lane]);
-                gput(G + O_CQ + rb.r0 + lane, tag, pk[32 + lane]);
-              }
               const float s1 = wsum(tv), s2 = wsum(tv * tv);
+              if (on) gput(G + O_CQ + rb.r0 + lane, tag, pk[32 + lane]);   // the units wait for T and the statistics: first
               if (lane < 2) gput(G + O_STAT + 16 * rwg + lane, tag, lane == 0 ? s1 : s2);
+              if (on) gput(G + O_Y1 + rb.r0 + lane, tag, pk[lane]);        // y1 is not needed before the mlp LayerNorm
             }
+            AXW_TL(13)
           }
           rb.prefetch(w_co, b_co, D, D, rwg, P, ctid, pk_d);
           kv_piece(2, 8);
