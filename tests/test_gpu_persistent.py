@@ -58,7 +58,7 @@ def test_persistent_equals_graph_path_and_oracle(built_lib, oracle_mod, tmp_path
             e_paths = float(np.abs(lp[0, :n] - lgp[0, :n]).max())
             e_ref = float(np.abs(lp[0, :n] - ref_lg).max())
             print(model_type, "logits: persistent vs graph", e_paths, "persistent vs oracle", e_ref)
-            assert e_paths < 3e-4 and e_ref < 3e-3  # measured 4.3e-5 .. 5.6e-5 and 3.1e-4 .. 7.4e-4
+            assert e_paths < 5e-4 and e_ref < 4e-3  # measured 4.3e-5 .. 5.6e-5 and 3.1e-4 .. 7.4e-4 (a margin for other compiler / driver versions)
             assert np.array_equal(ap, ag)
             top2 = np.sort(ref_lg, axis=1)[:, -2:]
             margin = float((top2[:, 1] - top2[:, 0]).min())
@@ -124,6 +124,16 @@ def test_persistent_gives_up_and_falls_back(built_lib, micro_case, monkeypatch):
         e.close()
 
 
+
+def _need_clips(e, n):
+    """The multi-clip launches need grid - L*H >= 3*n*H workgroups without a head: all 256 CUs of an MI355X for Whisper-small.
+    On a smaller part or a CU-masked queue the engine decodes such groups another way: skip, do not fail."""
+    have = e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_max_clips")
+    if have < n:
+        e.close()
+        pytest.skip(f"this device runs {have} clip(s) per persistent launch, the test needs {n}")
+
+
 def test_two_clips_run_one_persistent_launch(built_lib, micro_case):
     """Two clips per call: ONE two-clip persistent launch (decode_persistent2.hip; round 4 — it was one launch per clip);
     ids equal the one-clip runs, per-clip budgets are honoured, and every clip reads ITS slot's cross K/V (seeded
@@ -134,6 +144,7 @@ def test_two_clips_run_one_persistent_launch(built_lib, micro_case):
 
     e = built_lib.Whisper("micro", micro_case.root, "zh", device=0, max_batch=2)
     try:
+        _need_clips(e, 2)
         assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_two_clips") == 1
         mels = [demo_mel(80), np.full((80, 3000), 5.0, dtype=np.float32)]
         single = []
@@ -185,6 +196,7 @@ def test_two_clip_launch_equals_one_clip_launches(built_lib, tmp_path, monkeypat
     clips = [load_demo_pcm(), modelgen.synth_clip(seed, 200000), modelgen.synth_clip(seed + 1, 90000)]
     e = built_lib.Whisper(model_type, case.root, "zh", device=0, max_batch=2)
     try:
+        _need_clips(e, 2)
         assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_two_clips") == 1
         mels = np.stack([e.compute_mel(c) for c in clips])
         single = []
@@ -225,6 +237,7 @@ def test_three_clip_launch_equals_one_clip_launches(built_lib, tmp_path, monkeyp
     clips = [load_demo_pcm(), modelgen.synth_clip(seed, 200000), modelgen.synth_clip(seed + 1, 90000)]
     e = built_lib.Whisper(model_type, case.root, "zh", device=0, max_batch=3)
     try:
+        _need_clips(e, 3)
         assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_max_clips") == 3
         assert e.L.AX_WHISPER_GetConfigInt(e.h, b"fp16") == (1 if dtype == "F16" else 0)
         mels = np.stack([e.compute_mel(c) for c in clips])

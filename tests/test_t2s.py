@@ -68,6 +68,34 @@ def test_dictionary_is_read_completely(built_lib, CFG):
     assert t2s(out) == out
 
 
+def test_every_key_of_both_dictionaries_against_an_independent_reader(built_lib, CFG):
+    """EXHAUSTIVE: all 4113 keys of TSCharacters.ocd2 and all 278 of TSPhrases.ocd2, enumerated and paired with their value
+    lists by tests/ocd2_reader.py (a separate reader: forward walk of the trie, sequential read of the value table), go
+    through AX_WHISPER_ConvertT2S and must come out as their FIRST value (OpenCC's rule; `阪` has two, `彷` has two). Keys are
+    sent '|'-separated in one text, so no phrase can form across two of them; a phrase key is its own longest match."""
+    import ocd2_reader
+
+    t2s = lambda s: built_lib.convert_t2s(CFG, s)
+    chars = ocd2_reader.read_ocd2(os.path.join(OCC, "TSCharacters.ocd2"))
+    phrases = ocd2_reader.read_ocd2(os.path.join(OCC, "TSPhrases.ocd2"))
+    assert len(chars) == 4113 and len(phrases) == 278
+    assert all(len(k.decode("utf-8")) == 1 for k, _ in chars)          # one code point per key
+    assert sum(1 for _, v in chars if len(v) > 1) == 56 and sum(1 for _, v in phrases if len(v) > 1) == 4
+    for table in (chars, phrases):
+        keys = [k.decode("utf-8") for k, _ in table]
+        want = [v[0].decode("utf-8") for _, v in table]
+        got = t2s("|".join(keys)).split("|")
+        assert len(got) == len(keys)
+        bad = [(k, w, g) for k, w, g in zip(keys, want, got) if w != g]
+        assert not bad, bad[:10]
+    # a phrase key wins over the characters it is made of wherever the two disagree, also inside running text
+    tab = {k.decode("utf-8"): v[0].decode("utf-8") for k, v in chars}
+    differ = [(k.decode("utf-8"), v[0].decode("utf-8")) for k, v in phrases if "".join(tab.get(c, c) for c in k.decode("utf-8")) != v[0].decode("utf-8")]
+    assert len(differ) >= 50
+    for k, v in differ:
+        assert t2s("我" + k + "。") == "我" + v + "。", k
+
+
 def test_bad_files_fail_cleanly(built_lib, tmp_path, CFG):
     with pytest.raises(RuntimeError):
         built_lib.convert_t2s(str(tmp_path / "missing.json"), "x")

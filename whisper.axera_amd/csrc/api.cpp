@@ -28,12 +28,16 @@
 using Engine = axw::IEngine;
 
 namespace axw {
-std::recursive_mutex& device_capture_mutex(int) {
-  // ONE mutex for the whole process, not one per device: whether an allocation on device 1 can invalidate a thread-local
-  // capture on device 0 was never observable on a one-GPU box, so the exclusion does not depend on the answer. The cost is
-  // that engines of one AX_WHISPER_InitMulti handle are constructed one after the other (seconds, once per handle).
-  static std::recursive_mutex mu;
-  return mu;
+std::recursive_mutex& device_capture_mutex(int device) {
+  // Default: ONE mutex for the whole process, not one per device: whether an allocation on device 1 can invalidate a
+  // thread-local capture on device 0 was never observable on a one-GPU box, so the exclusion does not depend on the answer.
+  // The cost is that engines of one AX_WHISPER_InitMulti handle are constructed one after the other (seconds, once per
+  // handle), and that creating a handle at run time stalls StreamOpen / capacity growth / first-time graph capture of every
+  // serving handle for that long (INTEGRATION.md "Threading"). AX_WHISPER_CAPTURE_MUTEX=device: one mutex per device — for
+  // multi-GPU hosts once the first 8-GPU run has shown that captures on different devices do not disturb each other.
+  static std::recursive_mutex mu[65];
+  static const bool per_device = [] { const char* e = getenv("AX_WHISPER_CAPTURE_MUTEX"); return e && !strcmp(e, "device"); }();
+  return per_device ? mu[1 + (device & 63)] : mu[0];
 }
 std::mutex& persistent_launch_mutex(int device) {
   static std::mutex mu[64];  // one per device: engines of different GPUs never wait for each other

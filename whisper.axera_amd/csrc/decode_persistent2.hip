@@ -299,7 +299,12 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
               for (int e = 0; e < 2; ++e) {
                 const int dd = 2 * (tid & 31) + e;
                 const float val = __uint_as_float(v[e]);
-                // the global stores are for the LATER steps (nobody waits for them); this step's row travels through LDS
+                // the global stores are for the LATER steps (nobody waits for them); this step's row travels through LDS.
+                // Why the readers of the next step see them without a fence: gfx9 counts a wave's loads AND stores in one
+                // in-order counter, so by the time this wave has consumed the result of ANY later poll (s_waitcnt vmcnt on a
+                // load issued behind these stores: the very next gather) the stores have been acknowledged by L2; the reading
+                // waves are on this CU, at least one workgroup barrier behind that point (a whole decoder step, in fact), and
+                // read with sc0 = past the L1 that may still hold the line from an earlier step
                 if (tid < 64) kd[(step >> 6) * 4096 + (dd >> 3) * 512 + (step & 63) * 8 + (dd & 7)] = (h16)val;
                 else vd[(step >> 6) * 4096 + ((step >> 3) & 7) * 512 + dd * 8 + (step & 7)] = (h16)val;
                 kvtc[c][(tid < 64 ? 0 : 64) + dd] = (h16)val;

@@ -469,13 +469,15 @@ int Engine::greedy_loop(int batch, int max_new, const int* max_new_clip) {
   // computed while the others' hand-offs are in flight; decode_persistent2.hip) — Whisper-small, 444 ids per clip: 134 ms per
   // pair against 2 x 116 ms for one launch per clip (shapes without a multi-clip launch, AX_WHISPER_PERSIST2=0) and 316 ms through
   // the launch-per-phase path. Each clip stops at its own eot / budget.
-  if (batch >= 2 && batch <= persist_max_clips_ && persistent_usable()) {
+  // (asked ONCE per request: persistent_usable() counts a back-off down)
+  const bool usable = batch <= std::max(2, persist_max_clips_) && persistent_usable();
+  if (usable && batch >= 2 && batch <= persist_max_clips_) {
     int mn[3] = {max_new, -1, -1};
     for (int b = 0; b < batch; ++b) mn[b] = (max_new_clip && max_new_clip[b] > 0) ? std::min(max_new, max_new_clip[b]) : max_new;
     const int st = run_persistent(mn[0], nullptr, 0, nullptr, nullptr, 0, mn[1], mn[2]);
     if (st >= 0) { persistent_succeeded(); return st; }
     persistent_gave_up();
-  } else if (batch <= 2 && persistent_usable()) {
+  } else if (usable && batch <= 2) {
     int steps = 0, b = 0;
     for (; b < batch; ++b) {
       int mn = max_new;

@@ -159,7 +159,9 @@ static void slot_scheduler(AX_WHISPER_HANDLE model, int n_slots, int wait_ms, in
       run_alone(take[0]);
       continue;
     }
-    if (busy == 0 && take.size() >= 2 && (int)take.size() <= launch_clips) {
+    // (persistent_decode is 0 while the engine backs off after a give-up — CUs taken by another process: the group path would then
+    // run the launch-per-phase sequence synchronously, ~316 ms per pair against ~240 ms through slots, with no admission meanwhile)
+    if (busy == 0 && take.size() >= 2 && (int)take.size() <= launch_clips && AX_WHISPER_GetConfigInt(model, "persistent_decode") == 1) {
       // two or three requests on an idle device: their greedy loops in ONE persistent launch (134 ms for a pair of Whisper-small
       // clips of 444 ids against ~240 ms for two live slots of the step sequence); a refused group (one bad request) is served one by one
       if (open) { AX_WHISPER_StreamClose(model); open = false; }
