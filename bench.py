@@ -212,6 +212,9 @@ def stage_rooflines(eng, dims, model, B):
     stages = {"frontend": {"ms": round(ms_fe, 4), "GBs": round(B * (4 * N_SAMP + 2 * dims["n_mels"] * 3000) / (ms_fe * 1e-3) / 1e9, 1),
                            "fp32_TFLOPs": round(fe_flop / (ms_fe * 1e-3) / 1e12, 2), "peak_fp32_matrix_TFLOPs": 157.3,
                            "frac": round(fe_flop / (ms_fe * 1e-3) / 1e12 / 157.3, 4),
+                           # SURVEY §8(d) bounds this stage by HBM (4 B per sample in, 2 B per mel value out): next to the matrix
+                           # figure, because the DFT-as-GEMM does ~37x the arithmetic of a 400-point FFT
+                           "frac_of_hbm_bound": round(B * (4 * N_SAMP + 2 * dims["n_mels"] * 3000) / (ms_fe * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                            "bound": "fp32 MFMA (DFT of 201 bins as a GEMM + mel projection) at batch, launch latency at one clip"}}
     if enc_flop:
         tf = enc_flop * B / (ms_enc * 1e-3) / 1e12
@@ -695,6 +698,13 @@ def run_rank(args) -> int:
                                        "launch_ms": round(l_s * 1e3, 3), "bytes_per_launch": int(bts),
                                        "us_per_decode_step": round(l_s * 1e6 / n_st, 2)}
                     out["batch%d" % nb] = leg
+                # four and eight clips per call: the clip-block step sequence (one step = ~87 dependent launches whatever the clip
+                # count). The low-load ladder of a server in one place: clips/s at 1, 2, 3, 4, 8 clips per call
+                for nb in (4, 8):
+                    leg, idsp = batch_leg(torch, dev, dev_index, sync, "small", dtype, nb, min(n2, 3), 0, args.model_dir, rooflines=False)
+                    leg["clip0_ids_equal_batch1"] = idsp[0] == ids[0]
+                    out["batch%d" % nb] = leg
+                out["low_load_clips_per_s"] = {"1": out["value"], **{str(nb): out["batch%d" % nb]["value"] for nb in (2, 3, 4, 8)}}
             if not args.no_realistic and args.max_new == 0:
                 # realistic utterance lengths (SURVEY §8d asks for them beside the full context): every clip of the 64 leaves the
                 # loop at its own budget of 60-150 ids; then the same workload through the slot scheduler (384 clips, 64 slots)
