@@ -74,8 +74,38 @@ struct RowSetF32 {
   }
 };
 
-// per-layer block of the fold arena (floats): M [D][D], then d, s, c [D] each
-__host__ __device__ constexpr long qfold_stride(int d) { return (long)d * d + 3L * d; }
+// per-layer block of the fold arena (floats): M [D][D], then d, s, c [D] each, then the LayerNorm fold of the two LayerNorm-fed
+// row phases (below): s_qkv, c_qkv [3D], s_fc1, c_fc1 [4D]
+__host__ __device__ constexpr long qfold_stride(int d) { return (long)d * d + 17L * d; }
+constexpr int QF_SQKV = 3, QF_CQKV = 6, QF_SFC1 = 9, QF_CFC1 = 13;  // vector offsets behind M, in units of D
+
+// LayerNorm folded into the rows it feeds: W LN(x) + b = r (W (g . x) - mu s) + c with s = W g, c = W beta + b, so the pollers
+// hand the compute waves g . x and the two sums behind ONE workgroup barrier instead of statistics, barrier, normalised
+// vector, barrier; every compute wave derives mu and r from the eight partial sums itself.
+__global__ void qfold_vec_kernel(const h16* __restrict__ wl, const float* __restrict__ fl, float* __restrict__ qf, int D) {
+  const int l = blockIdx.y;
+  const long DD = (long)D * D;
+  const h16* WL = wl + (long)l * DecArena::w_stride(D);
+  const float* F = fl + (long)l * DecArena::f_stride(D);
+  float* out = qf + (long)l * qfold_stride(D) + DD;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < 3 * D) {
+    const h16* w = WL + DecArena::W_QKV * DD + (long)j * D;
+    const float *g = F + DecArena::F_ATTN_LN_W * D, *be = F + DecArena::F_ATTN_LN_B * D;
+    double ss = 0.0, cc = 0.0;
+    for (int i = 0; i < D; ++i) { const double wv = (double)(float)w[i]; ss += wv * (double)g[i]; cc += wv * (double)be[i]; }
+    out[QF_SQKV * D + j] = (float)ss;
+    out[QF_CQKV * D + j] = (float)(cc + (double)F[DecArena::F_B_QKV * D + j]);
+  }
+  if (j < 4 * D) {
+    const h16* w = WL + DecArena::W_FC1 * DD + (long)j * D;
+    const float *g = F + DecArena::F_MLP_LN_W * D, *be = F + DecArena::F_MLP_LN_B * D;
+    double ss = 0.0, cc = 0.0;
+    for (int i = 0; i < D; ++i) { const double wv = (double)(float)w[i]; ss += wv * (double)g[i]; cc += wv * (double)be[i]; }
+    out[QF_SFC1 * D + j] = (float)ss;
+    out[QF_CFC1 * D + j] = (float)(cc + (double)F[DecArena::F_B_FC1 * D + j]);
+  }
+}
 
 // M = W_cq diag(g) W_o in double, one thread per element; d, s, c by the first D threads of block row 0
 __global__ void qfold_build_kernel(const h16* __restrict__ wl, const float* __restrict__ fl, float* __restrict__ qf, int D) {
@@ -106,6 +136,7 @@ __global__ void qfold_build_kernel(const h16* __restrict__ wl, const float* __re
 }
 void launch_qfold_build(const h16* wl, const float* fl, float* qf, int d_model, int n_layer, hipStream_t s) {
   qfold_build_kernel<<<dim3((d_model + 127) / 128, d_model, n_layer), 128, 0, s>>>(wl, fl, qf, d_model);
+  qfold_vec_kernel<<<dim3((4 * d_model + 127) / 128, n_layer), 128, 0, s>>>(wl, fl, qf, d_model);
 }
 size_t qfold_floats(int d_model, int n_layer) { return (size_t)n_layer * (size_t)qfold_stride(d_model); }
 
@@ -235,6 +266,31 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
 #define AXW_PAIRS_D(BASE) [&](int j) { const int pr = tid + j * PL; return 2 * pr < D ? (BASE) + 2 * pr : -1; }
 
     // x += y, LayerNorm into act[0..D): two workgroup barriers
+    // QF: the stage of a LayerNorm that is folded into its rows (QKV, mlp.0): g . x and the two sums, ONE barrier. The caller has
+    // added the gathered update to x. Writing act before the barrier is safe: the update that was just gathered (or, in the first
+    // layer, the barrier at the end of the previous step) lies behind every read of act by this workgroup's compute waves.
+#define AXW_RAW_STAGE(FAIL, CODE, XGW)                                                      \
+  {                                                                                          \
+    float s1 = 0.f, s2 = 0.f;                                                                \
+    _Pragma("unroll") for (int k = 0; k < GD; ++k) {                                         \
+      const int i = el(k);                                                                   \
+      if (i < D) {                                                                           \
+        const float t = x[k] - shift;                                                        \
+        s1 += t; s2 += t * t;                                                                \
+        act[i] = x[k] * lg[k];                                                               \
+        if (XGW) { act[XG + i] = x[k] * g2[k]; act[X0R + i] = x[k]; }                        \
+      }                                                                                      \
+    }                                                                                        \
+    s1 = wsum(s1); s2 = wsum(s2);                                                            \
+    if ((tid & 63) == 0) { red[2 * (tid >> 6)] = s1; red[2 * (tid >> 6) + 1] = s2; }         \
+    if (tid == 0) red[2 * NPW + 1] = shift;                                                  \
+    if (FAIL) ctl[0] = 1;                                                                    \
+    AXW_BARRIER_CHECK(CODE)                                                                  \
+    float t1 = 0.f;                                                                          \
+    _Pragma("unroll") for (int w2 = 0; w2 < NPW; ++w2) t1 += red[2 * w2];                    \
+    shift += t1 / D;                                                                         \
+    if (tid == 0) red[2 * NPW] = shift;                                                      \
+  }
 #define AXW_LN_STAGE(Y, ADD, FAIL, CODE) AXW_LN_STAGE_X(Y, ADD, FAIL, CODE, false)
     // XGW (QF, row producers, QKV stage): also leave g_cross . x and x itself in act[XG..), act[X0R..) — behind the stage's
     // first barrier, when the compute waves have left the previous phase (mlp.2 reads all of act)
@@ -287,9 +343,17 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           if (l > 0) fail = gather2<GPD>(GR, tag - 1, y, p.err, ctl, AXW_PAIRS_D(O_Y3));
           AXW_STAMP(0)
           AXW_TL(0)
-          AXW_LN_STAGE_X(y, l > 0, fail, 0x100 + l, in_o)
-          if constexpr (QF) ln_prefetch(FL + DecArena::F_MLP_LN_W * D, FL + DecArena::F_MLP_LN_B * D);
-          else ln_prefetch(FL + DecArena::F_CROSS_LN_W * D, FL + DecArena::F_CROSS_LN_B * D);
+          if constexpr (QF) {
+            if (l > 0) {
+#pragma unroll
+              for (int k = 0; k < GD; ++k) if (el(k) < D) x[k] += __uint_as_float(y[k]);
+            }
+            AXW_RAW_STAGE(fail, 0x100 + l, in_o)
+            ln_prefetch(FL + DecArena::F_MLP_LN_W * D, FL + DecArena::F_MLP_LN_B * D);
+          } else {
+            AXW_LN_STAGE_X(y, l > 0, fail, 0x100 + l, in_o)
+            ln_prefetch(FL + DecArena::F_CROSS_LN_W * D, FL + DecArena::F_CROSS_LN_B * D);
+          }
           AXW_STAMP(1)
           AXW_TL(1)
         }
@@ -440,7 +504,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           for (int k = 0; k < GD; ++k) if (el(k) < D) x[k] = (x[k] + __uint_as_float(y[k])) + __uint_as_float(y[GD + k]);
           AXW_STAMP(11)
           AXW_TL(7)
-          AXW_LN_STAGE(y, false, fail, 0x700 + l)
+          AXW_RAW_STAGE(fail, 0x700 + l, false)
           if (l + 1 < L) ln_prefetch(FL + DecArena::f_stride(D) + DecArena::F_ATTN_LN_W * D, FL + DecArena::f_stride(D) + DecArena::F_ATTN_LN_B * D);
           else ln_prefetch(AXW_COLD(ln_w), AXW_COLD(ln_b));
           g2_prefetch(l + 1 < L ? l + 1 : 0);
@@ -479,6 +543,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
       asm volatile("" : "+v"(tid));
       if (step < 3) {  // SOT steps: feed the next forced token, logits are discarded (Whisper.cpp:214-217)
         tok = AXW_COLD(sot)[step + 1];
+        if constexpr (QF) wg_barrier();  // the next step's first stage writes act before its barrier: nobody may still be reading it
         continue;
       }
       // ---- final LayerNorm for the vocabulary projection, then merge the argmax partials of every workgroup
@@ -520,6 +585,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     }
 #undef AXW_LN_STAGE
 #undef AXW_LN_STAGE_X
+#undef AXW_RAW_STAGE
 #undef AXW_PAIRS_D
   } else {
     // ======================================================================================= compute waves
@@ -549,7 +615,26 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     // in the other (qkv A, o B, cq A, co B, mlp.0 A, [mlp.2 F], next qkv / vocabulary A)
     RowSet<LD, CD> ra, rb;
     RowSet<LF, CF> rs_fc2;
-    ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, rwg, P, ctid, pk_qkv);
+    // QKV rows of layer `ly`: with their LayerNorm folded in (QF) or with their plain bias
+    auto qkv_prefetch = [&](int ly) {
+      const h16* w = p.wl + (long)ly * DecArena::w_stride(D);
+      if constexpr (QF) {
+        const float* v = AXW_COLD(qf) + (long)ly * qfold_stride(D) + (long)D * D;
+        ra.prefetch_ln(w, v + QF_SQKV * D, v + QF_CQKV * D, D, 3 * D, rwg, P, ctid, pk_qkv);
+      } else {
+        ra.prefetch(w, p.fl + (long)ly * DecArena::f_stride(D) + DecArena::F_B_QKV * D, D, 3 * D, rwg, P, ctid, pk_qkv);
+      }
+    };
+    // mean and rstd of the stage the pollers have just closed: the eight partial sums + the shift they are relative to
+    auto stage_stats = [&](float& mean, float& rstd) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NPW; ++w2) { t1 += red[2 * w2]; t2 += red[2 * w2 + 1]; }
+      const float dm = t1 / D, var = fmaxf(t2 / D - dm * dm, 0.f);
+      mean = red[2 * NPW + 1] + dm;
+      rstd = rsqrtf(var + 1e-5f);
+    };
+    qkv_prefetch(0);
     {  // the first layer's cross-attention unit has no previous layer to hide behind
       const int cu0 = ca_unit_of(0);
       if (cu0 >= 0) {
@@ -593,11 +678,20 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         };
         // ---- QKV rows (export_onnx.py:245-247)
         AXW_BARRIER_CHECK(0x100 + l)
-        wg_barrier();
-        AXW_STAMP(16)
-        AXW_TL(18)
         float res[2];
-        ra.run(w_qkv, b_qkv, D, act, ctid, res);
+        if constexpr (QF) {
+          AXW_STAMP(16)
+          AXW_TL(18)
+          float mean, rstd;
+          stage_stats(mean, rstd);
+          const float* v = AXW_COLD(qf) + (long)l * qfold_stride(D) + (long)D * D;
+          ra.run_ln(w_qkv, v + QF_SQKV * D, v + QF_CQKV * D, D, act, ctid, res, mean, rstd);
+        } else {
+          wg_barrier();
+          AXW_STAMP(16)
+          AXW_TL(18)
+          ra.run(w_qkv, b_qkv, D, act, ctid, res);
+        }
         ra.publish(ctid, res, pk, ctl + 2, G + O_QKV, tag, [](float v) { return v; });
         if constexpr (QF) {
           // row producers: A0 = W_cq (g . x0) of this slot's row NOW — the self-attention owners' q, k, v are still travelling
@@ -745,7 +839,12 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           rb.run(w_co, b_co, D, act, ctid, res);
           rb.publish(ctid, res, pk, ctl + 2, G + O_Y2, tag, [](float v) { return v; });
         }
-        ra.prefetch(w_fc1, b_fc1, D, F, rwg, P, ctid, pk_f);
+        if constexpr (QF) {
+          const float* v = AXW_COLD(qf) + (long)l * qfold_stride(D) + (long)D * D;
+          ra.prefetch_ln(w_fc1, v + QF_SFC1 * D, v + QF_CFC1 * D, D, F, rwg, P, ctid, pk_f);
+        } else {
+          ra.prefetch(w_fc1, b_fc1, D, F, rwg, P, ctid, pk_f);
+        }
         if constexpr (kEarlyFc2) {
           if (early_fc2) rs_fc2.prefetch(w_fc2, b_fc2, F, D, rwg, P, ctid, pk_d);
         }
@@ -754,10 +853,19 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         AXW_TL(15)
         // ---- mlp.0 + GELU (export_onnx.py:298)
         AXW_BARRIER_CHECK(0x700 + l)
-        wg_barrier();
-        AXW_STAMP(26)
-        AXW_TL(22)
-        ra.run(w_fc1, b_fc1, D, act, ctid, res);
+        if constexpr (QF) {
+          AXW_STAMP(26)
+          AXW_TL(22)
+          float mean, rstd;
+          stage_stats(mean, rstd);
+          const float* v = AXW_COLD(qf) + (long)l * qfold_stride(D) + (long)D * D;
+          ra.run_ln(w_fc1, v + QF_SFC1 * D, v + QF_CFC1 * D, D, act, ctid, res, mean, rstd);
+        } else {
+          wg_barrier();
+          AXW_STAMP(26)
+          AXW_TL(22)
+          ra.run(w_fc1, b_fc1, D, act, ctid, res);
+        }
         ra.publish(ctid, res, pk, ctl + 2, G + O_HID, tag, [](float v) { return gelu_erf(v); });
         if (!early_fc2) rs_fc2.prefetch(w_fc2, b_fc2, F, D, rwg, P, ctid, pk_d);
         kv_piece(11, 13);
@@ -784,9 +892,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_STAMP(31)
         }
         // next consumer of the residual stream: the next layer's QKV rows, the vocabulary projection, or the next step
-        if (l + 1 < L) ra.prefetch(w_qkv + DecArena::w_stride(D), b_qkv + DecArena::f_stride(D), D, 3 * D, rwg, P, ctid, pk_qkv);
+        if (l + 1 < L) qkv_prefetch(l + 1);
         else if (step >= 3) ra.prefetch(AXW_COLD(tok_emb), nullptr, D, AXW_COLD(n_vocab), rwg, P, ctid);
-        else ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, rwg, P, ctid, pk_qkv);
+        else qkv_prefetch(0);
         kv_piece(13, 16);
         AXW_STAMP(29)
         AXW_TL(17)
@@ -796,6 +904,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
       asm volatile("" : "+v"(ctid));
       if (step < 3) {
         tok = AXW_COLD(sot)[step + 1];
+        if constexpr (QF) wg_barrier();
         continue;
       }
       // ---- logits = token_embedding . ln(x)  (tied embedding, export_onnx.py:364-385) + argmax (first max wins, Whisper.cpp:42-45)
@@ -855,7 +964,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           }
         }
         // the next step's first rows: requested before the token is even known
-        ra.prefetch(p.wl, p.fl + DecArena::F_B_QKV * D, D, 3 * D, rwg, P, ctid, pk_qkv);
+        qkv_prefetch(0);
         // workgroup argmax: lanes with j == 0 hold candidates; the lower index wins ties
         if (j != 0) { bv = -INFINITY; bi = 0x7fffffff; }
         wave_argmax(bv, bi);

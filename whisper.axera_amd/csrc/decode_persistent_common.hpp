@@ -213,6 +213,7 @@ template <int LPR, int CH>
 struct RowSet {
   u32x4 w[CH];
   float bias;
+  float sfac;  // run_ln only: s_j = sum_i W_ji g_i of this slot's row (the LayerNorm folded into the rows)
   int r0, r1;
   // first < 0: rows dealt evenly over all workgroups; else one full pass (SLOTS rows) per producer, producers =
   // workgroups first, first + 1, ... (the others get no rows)
@@ -231,6 +232,27 @@ struct RowSet {
     const int row = r0 + slot;
     rows_load<LPR, CH>(w, W, K, row < r1 ? row : r0, ctid);
     bias = (b && row < r1 && j == 0) ? b[row] : 0.f;
+  }
+  // The same for rows that carry their LayerNorm (decode_persistent.hip, round 5): bias = c_j = W beta + b, sfac = s_j = W g
+  __device__ __forceinline__ void prefetch_ln(const h16* W, const float* sv, const float* cv, int K, int N, int wg, int P, int ctid, int first) {
+    prefetch(W, cv, K, N, wg, P, ctid, first);
+    const int slot = ctid / LPR, j = ctid % LPR, row = r0 + slot;
+    sfac = (row < r1 && j == 0) ? sv[row] : 0.f;
+  }
+  // act holds g . x (not normalised): res = rstd (W (g . x) - mean s) + c. One pass, or two where the rows are dealt evenly.
+  __device__ __forceinline__ void run_ln(const h16* W, const float* sv, const float* cv, int K, const float* act, int ctid, float (&res)[2], float mean, float rstd) {
+    constexpr int SLOTS = CT / LPR;
+    const int slot = ctid / LPR, j = ctid % LPR;
+    res[0] = rstd * (rows_dot<LPR, CH>(w, act, ctid) - mean * sfac) + bias;
+    res[1] = 0.f;
+    const int row1 = r0 + slot + SLOTS;
+    if (row1 < r1) {
+      rows_load<LPR, CH>(w, W, K, row1, ctid);
+      const float c1 = j == 0 ? cv[row1] : 0.f, s1 = j == 0 ? sv[row1] : 0.f;
+      int ctid2 = ctid;
+      asm volatile("" : "+v"(ctid2));
+      res[1] = rstd * (rows_dot<LPR, CH>(w, act, ctid2) - mean * s1) + c1;
+    }
   }
   // Computes this slot's rows (at most two passes: every supported shape has <= 2 * slots rows per workgroup) into
   // res[]. The caller requests the NEXT phase's rows before it publishes: a write-through store in front of a load
