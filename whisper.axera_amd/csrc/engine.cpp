@@ -57,6 +57,13 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
   HIP_CHECK(hipStreamCreateWithFlags(&branch_stream_[0], hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&admit_stream_, hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+  if (const char* e = getenv("AX_WHISPER_PAD_STREAMS")) {  // diagnostic (profiles/scripts/stream_mode_probe.py): shifts which hardware
+    for (int i = 0; i < atoi(e) && i < 8; ++i) {            // queue every LATER stream of the process lands on (graph-internal ones too)
+      hipStream_t pad = nullptr;
+      HIP_CHECK(hipStreamCreateWithFlags(&pad, hipStreamNonBlocking));
+      pad_streams_.push_back(pad);
+    }
+  }
   for (auto& e : ev_ring_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : ev_step_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&ev_upload_, hipEventDisableTiming));
@@ -157,6 +164,8 @@ void Engine::destroy() {
   for (auto& b : branch_stream_) if (b) { (void)hipStreamDestroy(b); b = nullptr; }
   if (admit_stream_) { (void)hipStreamDestroy(admit_stream_); admit_stream_ = nullptr; }
   if (copy_stream_) { (void)hipStreamDestroy(copy_stream_); copy_stream_ = nullptr; }
+  for (auto& ps : pad_streams_) (void)hipStreamDestroy(ps);
+  pad_streams_.clear();
   for (auto& e : ev_ring_) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   for (auto& e : ev_step_) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (ev_upload_) { (void)hipEventDestroy(ev_upload_); ev_upload_ = nullptr; }

@@ -94,6 +94,8 @@ class Engine final : public IEngine {
   bool device_set_ = false;
   void* load_stage_ = nullptr;  // staging buffer of load_weights
   hipStream_t own_stream_ = nullptr, user_stream_ = nullptr;
+  std::vector<hipStream_t> pad_streams_;  // align_graph_queue() (engine_stream.cpp); AX_WHISPER_PAD_STREAMS (diagnostic)
+  bool graph_branch_shares_queue(hipGraphExec_t exec, hipStream_t other);
   static constexpr int kMaxBranches = 4;   // parallel branches of the batched step graph
   hipStream_t branch_stream_[kMaxBranches - 1] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork_ = nullptr, ev_join_[kMaxBranches - 1] = {nullptr, nullptr, nullptr};

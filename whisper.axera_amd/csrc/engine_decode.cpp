@@ -456,6 +456,23 @@ hipGraphExec_t Engine::step_graph(int batch, int max_new) {
   }
   hipGraphExec_t exec = nullptr;
   HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  {  // which hardware queue the graph's second branch runs on decides the slot stream's rate (engine_stream.cpp:
+     // graph_branch_shares_queue); AX_WHISPER_ALIGN_QUEUES=0: as it falls
+    static const bool align = [] { const char* e = getenv("AX_WHISPER_ALIGN_QUEUES"); return !(e && e[0] == '0'); }();
+    if (align && !user_stream_ && batch > gemv_max_ && batched_ln_ && decode_branches(batch) >= 2 && step_mask_ == 15) {
+      int tries = 0;
+      while (!graph_branch_shares_queue(exec, branch_stream_[0]) && tries < 4) {
+        HIP_CHECK(hipGraphExecDestroy(exec));
+        exec = nullptr;
+        hipStream_t pad = nullptr;
+        HIP_CHECK(hipStreamCreateWithFlags(&pad, hipStreamNonBlocking));
+        pad_streams_.push_back(pad);
+        HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        ++tries;
+      }
+      cfg_.ints["graph_queue_tries"] = tries;
+    }
+  }
   HIP_CHECK(hipGraphDestroy(graph));
   graphs_[key] = exec;
   return exec;
@@ -489,8 +506,8 @@ int Engine::greedy_loop(int batch, int max_new, const int* max_new_clip) {
     if (b == batch) { persistent_succeeded(); return steps; }
     persistent_gave_up();  // these utterances (and the next few) take the launch-per-phase path
   }
+  hipGraphExec_t g = step_graph(batch, max_new);  // (a fresh multi-branch graph is probed with replays: before the state is set)
   reset_decode_state(batch, max_new_clip);
-  hipGraphExec_t g = step_graph(batch, max_new);
   hipStream_t s = stream();
   const int total = std::min(Tc, 4 + max_new);
   const int kPoll = 8;  // steps between done-counter polls; at most 2*kPoll steps run past the last eot

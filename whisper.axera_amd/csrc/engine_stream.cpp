@@ -28,6 +28,7 @@ void Engine::stream_open(int n_slots) {
   ensure_capacity(std::max(n_slots, 3));
   const int n = std::max(n_slots, 3);  // the step sequence of 3+ slots handles any mix of idle and active slots
   hipStream_t s = stream();
+  (void)step_graph(n, cfg_.n_text_ctx - 4);  // captured here, outside the serving loop (and probed with replays: before the state is set)
   reset_decode_state(n);
   std::vector<int> ones(n, 1);         // every slot idle: its attention launches return at once
   HIP_CHECK(hipMemcpy(d_done_, ones.data(), (size_t)n * 4, hipMemcpyHostToDevice));
@@ -39,7 +40,6 @@ void Engine::stream_open(int n_slots) {
     HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ev_admit_.push_back(e);
   }
-  (void)step_graph(n, cfg_.n_text_ctx - 4);  // captured here, outside the serving loop
   HIP_CHECK(hipStreamSynchronize(s));
   slot_state_.assign(n, kIdle);
   slot_max_new_.assign(n, 0);
@@ -219,8 +219,82 @@ int Engine::scan_stored16(int batch, int n_max, char (*names)[32], long long* no
   return n;
 }
 
+// ------------------------------------------------------------------------------ which of the engine's streams run side by side?
+// The runtime multiplexes a process's HIP streams onto a few hardware queues (four by default); two streams on one queue
+// execute one after the other. A spinner kernel on stream A and a time stamp on stream B, issued right behind it: if the stamp is
+// taken before the spinner ends, A and B are on different queues.
+__global__ static void queue_probe_spin(unsigned long long* out, long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+  out[0] = (unsigned long long)t0;
+  out[1] = (unsigned long long)wall_clock64();
+}
+__global__ static void queue_probe_mark(unsigned long long* out) { out[0] = (unsigned long long)wall_clock64(); }
+
+static bool streams_concurrent(hipStream_t a, hipStream_t b, unsigned long long* d_buf /*[4]*/) {
+  unsigned long long h[4] = {0, 0, 0, 0};
+  HIP_CHECK(hipStreamSynchronize(a));
+  HIP_CHECK(hipStreamSynchronize(b));
+  HIP_CHECK(hipMemset(d_buf, 0, 32));
+  queue_probe_spin<<<1, 64, 0, a>>>(d_buf, 30000);  // 300 us on the 100 MHz wall clock
+  queue_probe_mark<<<1, 64, 0, b>>>(d_buf + 2);
+  HIP_CHECK(hipStreamSynchronize(a));
+  HIP_CHECK(hipStreamSynchronize(b));
+  HIP_CHECK(hipMemcpy(h, d_buf, 32, hipMemcpyDeviceToHost));
+  return h[2] != 0 && h[2] + 5000 < h[1];  // stamped at least 50 us before the spinner ended
+}
+
+// hipGraphInstantiate gives every parallel branch of a captured step a stream of its own, and the runtime deals a process's
+// streams onto its hardware queues (four by default) round-robin: which queue the branch lands on depends on how many streams the
+// process has created before. Measured with 0..5 unused pad streams created ahead (profiles/r05_stream_queue_root_cause.txt,
+// stream64, period 4): 335 / 367 / 341 / 345 clips/s — the "bimodality" of rounds 3-4 was this draw (plain step replays do not care:
+// 1.130-1.142 ms; the slot stream does, because admission passes and result copies run beside the steps).
+// The one good place is the queue of branch_stream_[0], which only ever carries the capture and never a replay. So a freshly
+// instantiated multi-branch step is PROBED — a 3 ms spinner on branch_stream_[0], then one replay: if a branch shares that queue the
+// replay takes > 3 ms instead of ~1 — and re-instantiated behind one more pad stream until it does (at most 4 times, ~5 ms each, once
+// per captured graph). The replays run on whatever the decode state holds: callers reset the state AFTER they have the graph.
+bool Engine::graph_branch_shares_queue(hipGraphExec_t exec, hipStream_t other) {
+  hipStream_t s = stream();
+  unsigned long long* d_buf = nullptr;
+  HIP_CHECK(hipMalloc((void**)&d_buf, 32));
+  HIP_CHECK(hipStreamSynchronize(s));
+  HIP_CHECK(hipStreamSynchronize(other));
+  HIP_CHECK(hipGraphLaunch(exec, s));  // first launch of a fresh exec: paid here, not inside the measurement
+  HIP_CHECK(hipStreamSynchronize(s));
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0));
+  HIP_CHECK(hipEventCreate(&e1));
+  queue_probe_spin<<<1, 64, 0, other>>>(d_buf, 300000);  // 3 ms
+  HIP_CHECK(hipEventRecord(e0, s));
+  HIP_CHECK(hipGraphLaunch(exec, s));
+  HIP_CHECK(hipEventRecord(e1, s));
+  HIP_CHECK(hipEventSynchronize(e1));
+  HIP_CHECK(hipStreamSynchronize(other));
+  float ms = 0.f;
+  HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d_buf);
+  return ms > 2.5f;
+}
+
 float Engine::bench(const std::string& what, int batch, int arg, int iters) {
   require_no_stream("bench");
+  if (what == "queue_probe") {
+    // bit i set: pair i runs side by side. Pairs: 0 main-admission, 1 main-branch0, 2 main-copies, 3 admission-branch0,
+    // 4 admission-copies, 5 branch0-copies (diagnostic of the slot stream's process-to-process bimodality)
+    HIP_CHECK(hipSetDevice(device_));
+    std::lock_guard<std::recursive_mutex> capture_lock(device_capture_mutex(device_));
+    unsigned long long* d_buf = nullptr;
+    HIP_CHECK(hipMalloc((void**)&d_buf, 32));
+    hipStream_t st[4] = {own_stream_, admit_stream_, branch_stream_[0], copy_stream_};
+    const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
+    int mask = 0;
+    for (int i = 0; i < 6; ++i)
+      if (streams_concurrent(st[pa[i]], st[pb[i]], d_buf)) mask |= 1 << i;
+    (void)hipFree(d_buf);
+    return (float)mask;
+  }
   HIP_CHECK(hipSetDevice(device_));
   ensure_capacity(batch);
   hipStream_t s = stream();
