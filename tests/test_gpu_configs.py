@@ -101,6 +101,31 @@ def test_config2_small_batch64(built_lib, oracle_mod, small_case):
         # the whole context: 444 ids per clip, so self-attention walks all 7 key blocks at d = 768 with 64 clips in
         # flight (16 ids never left the first block)
         _batch_vs_single_and_oracle(e, small_case, oracle_mod, _clips(B), 444, oracle_clips=(0, 16, 63), n_mels=80)
+        # (round 5) the oracle also sees the BATCHED path's logits in every clip block and both graph branches of the 64-clip
+        # step: one more clip per block (5, 21, 37, 53 + the three above), 8 teacher-forced steps each, all 64 clips in flight
+        clips = _clips(B)
+        mels = np.stack([e.compute_mel(c) for c in clips])
+        extra = (5, 21, 37, 53)
+        refs = {}
+        for b in extra:
+            mel, _, _ = oracle_mod.log_mel(clips[b], 80)
+            ck, cv = small_case.oracle_bf16.encoder(mel)
+            refs[b] = small_case.oracle_bf16.greedy(ck, cv, "zh", max_new=8, want_logits=True)
+        e.encode_mel(mels)
+        forced = np.zeros((B, 8), dtype=np.int32)
+        for b in range(B):
+            forced[b] = refs[extra[b % 4]][0] if b not in extra else refs[b][0]
+        worst = 0.0
+        logits, am = e.decode_forced(B, forced)
+        for b in extra:
+            ids, lg = refs[b]
+            err = np.abs(logits[b] - lg).max(axis=1)
+            worst = max(worst, float(err.max()))
+            srt = np.sort(lg, axis=1)
+            for s_ in range(9):
+                assert am[b, s_] == int(lg[s_].argmax()) or srt[s_, -1] - srt[s_, -2] < 2 * err[s_] + 1e-4, (b, s_)
+        print(f"B=64 batched path vs bf16-policy oracle, clips {extra}: logits err {worst:.3e}")
+        assert worst < 6e-3, worst   # 5x the 1.2e-3 the other full-size tests measure for this path
     finally:
         e.close()
 

@@ -320,3 +320,50 @@ def test_natural_eot_under_realistic_statistics(built_lib, oracle_mod, tmp_path,
             report.append(f"natural eot {mode} B={B}: {n_eq}/{B} clips id-for-id equal to the oracle, all stops within the tie rule")
         finally:
             e.close()
+
+
+@pytest.mark.parametrize("dtype", ["BF16", "F16"])
+def test_realistic_statistics_full_context(built_lib, oracle_mod, tmp_path, report, dtype):
+    """The whole 448-step context under the realistic statistics (self-attention over all 7 key blocks with saturated heads,
+    positions up to 447 of the outlier-carrying positional embedding): teacher-forced with the policy oracle's own 444 ids, every
+    logits row and every argmax of the one-clip launch and of the clip-block sequence against both oracles."""
+    case = ModelCase(tmp_path, "micro", 49, dtype=dtype, kind="realistic")
+    clips = _clips(2)
+    tol = TOL[("micro", dtype)]
+    o_pol, o_f32 = case.oracle_bf16, case.oracle_fp32
+    refs = []
+    for c in clips:
+        mel, _, _ = oracle_mod.log_mel(c, 80)
+        ck, cv = o_pol.encoder(mel)
+        ids, _ = o_pol.greedy(ck, cv, "zh", max_new=444, want_logits=True)
+        forced = ids if len(ids) >= 444 else ids + [(13 * i + 7) % 50257 for i in range(444 - len(ids))]
+        _, lg_p = o_pol.greedy(ck, cv, "zh", max_new=444, forced=forced, want_logits=True)
+        ckf, cvf = o_f32.encoder(mel)
+        _, lg_f = o_f32.greedy(ckf, cvf, "zh", max_new=444, forced=forced, want_logits=True)
+        refs.append((mel, forced, lg_p, lg_f))
+    for B in (1, 4):
+        e = built_lib.Whisper("micro", case.root, "zh", device=0, max_batch=B)
+        try:
+            mels = np.stack([refs[b % 2][0] for b in range(B)])
+            e.encode_mel(mels)
+            logits, am = e.decode_forced(B, np.array([refs[b % 2][1] for b in range(B)], dtype=np.int32))
+            wp = wf = 0.0
+            ties = 0
+            for b in range(B):
+                _, _, lg_p, lg_f = refs[b % 2]
+                for lg, which in ((lg_p, 0), (lg_f, 1)):
+                    err = np.abs(logits[b] - lg).max(axis=1)
+                    if which == 0:
+                        wp = max(wp, float(err.max()))
+                    else:
+                        wf = max(wf, float(err.max()))
+                    mg = _margins(lg)
+                    want = lg.argmax(axis=1)
+                    for s_ in np.nonzero(am[b] != want)[0]:
+                        assert mg[s_] < 2 * err[s_] + 1e-4, (B, b, int(s_), float(mg[s_]), float(err[s_]))
+                        ties += which == 0
+            report.append(f"micro {dtype} full context B={B}: 445 logits rows, err vs policy oracle {wp:.3e}, vs fp32 oracle {wf:.3e}; ties accepted {ties}")
+            assert wp < 2 * tol[0] and wf < 2 * tol[1], (wp, wf)   # 444 cached rows deep: twice the short-run bound
+            _scan_ok(e, B, dtype, report, f"micro {dtype} full context B={B}")
+        finally:
+            e.close()
