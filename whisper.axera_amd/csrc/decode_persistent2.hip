@@ -26,7 +26,11 @@ inline namespace AXW_NS {
 // (128 KB of 160), so clip 1's self-attention cache and cross K/V stay in global memory and its attention blocks read
 // them from there; the d-wide input vectors and the attention query exist once per clip (3.3 KB more LDS), the two wide
 // LDS vectors (mlp hidden, cross-attention partial records) are shared and handed over with one more barrier.
-template <int LD, int CD, int LF, int CF, bool PROF, int NC>
+// QF: the cross-attention query folded through the output projection, as in the one-clip launch (decode_persistent.hip, round 5):
+// the row producers of y1 also publish T = A0 + M a + d and the sums of their slice of x1 = x0 + y1, a unit finishes its head's
+// query from them; the per-clip query LayerNorm stage and query-row phase are gone. Per clip: g . x0 [D] in the wide LDS vector
+// (act + D .., free between the QKV stage and the partial records), and 68 words for A0, the x0 slice and the statistics' shift.
+template <int LD, int CD, int LF, int CF, bool PROF, int NC, bool QF>
 __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) {
   static_assert(NC == 2 || NC == 3, "two or three clips per launch");
   constexpr int D = 8 * LD * CD, F = 8 * LF * CF, H = D / 64;
@@ -39,7 +43,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   constexpr int NUC = NC * NU;         // ... per layer: unit r = clip r / NU, (head, key range) r % NU
   // granule buffers (u64 units)
   constexpr int O_QKV = 0, O_ATT = 3 * D, O_Y1 = 4 * D, O_CQ = 5 * D, O_PART = 6 * D, O_Y2 = 10 * D, O_HID = 11 * D, O_Y3 = 15 * D,
-                O_AMAX = 16 * D;
+                O_AMAX = 16 * D, O_STAT = 16 * D + 512;  // (QF) statistics of row producer p: granules O_STAT + 16 p, + 1
   static_assert(NPART <= 3 * D + D / 8 && NU * kRec <= 4 * D, "partial buffer");
   static_assert(kCrossSplit * NCW == 24, "cross-attention key blocks");
 
@@ -76,6 +80,11 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
   }
   float* wpart1 = xbase + (NC - 1) * XW;  // [NPW][kPS] + [NPW][64]: the poller waves' own attention scratch (they run the later clips'
   float* pscr1 = wpart1 + NPW * kPS;      //  self-attention blocks while the compute waves run clip 0's)
+  float* const qfs = pscr1 + NPW * 64;    // QF: per clip [32] A0 of this producer's rows, [32] its slice of x0, [4] the statistics' shift
+  auto xgc = [&](int c) { return act + D + c * D; };   // QF: g_cross . x0 of clip c
+  auto a0s = [&](int c) { return qfs + c * 68; };
+  auto x0s = [&](int c) { return qfs + c * 68 + 32; };
+  auto shs = [&](int c) { return qfs + c * 68 + 64; };
 
   // tid is re-derived behind an opaque asm at the top of every layer: without it the compiler hoists every
   // per-thread address of every phase out of the step loop and keeps >100 registers of loop invariants alive
@@ -168,6 +177,13 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
 #pragma unroll
     for (int c = 0; c < NC; ++c) shift[c] = 0.f;
     auto el = [&](int k) { return 2 * (tid + (k >> 1) * PL) + (k & 1); };  // vector element of register slot k
+    float g2[GD];       // QF, row producers: the cross-attention LayerNorm's gain of the next layer to run (requested a stage ahead)
+    auto g2_prefetch = [&](int layer) {
+#pragma unroll
+      for (int k = 0; k < GD; ++k) { const int i = el(k); g2[k] = (QF && in_o && i < D) ? p.fl[(long)layer * DecArena::f_stride(D) + DecArena::F_CROSS_LN_W * D + i] : 0.f; }
+    };
+    g2_prefetch(0);
+    const int row0 = rwg * (CT / LD);  // QF: first row of this producer's slice of the d-wide layers
     auto ln_prefetch = [&](const float* g, const float* be) {
 #pragma unroll
       for (int k = 0; k < GD; ++k) {
@@ -180,7 +196,9 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
 #define AXW_PAIRS_D(BASE, C) [&](int j) { const int pr = tid + j * PL; return 2 * pr < D ? (C) * gco + (BASE) + 2 * pr : -1; }
 
     // x[C] += y, LayerNorm into clip C's input vector: two workgroup barriers
-#define AXW_LN_STAGE(Y, ADD, FAIL, CODE, C)                                                 \
+#define AXW_LN_STAGE(Y, ADD, FAIL, CODE, C) AXW_LN_STAGE_X(Y, ADD, FAIL, CODE, C, false)
+    // XGW (QF, row producers, QKV stage): also leave g_cross . x, this producer's slice of x and the mean for the compute waves
+#define AXW_LN_STAGE_X(Y, ADD, FAIL, CODE, C, XGW)                                          \
   {                                                                                          \
     float s1 = 0.f, s2 = 0.f;                                                                \
     _Pragma("unroll") for (int k = 0; k < GD; ++k) {                                         \
@@ -201,7 +219,12 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
     _Pragma("unroll") for (int k = 0; k < GD; ++k) {                                         \
       const int i = el(k);                                                                   \
       if (i < D) actc[C][i] = (x[C][k] - mean) * rstd * lg[k] + lb[k];                       \
+      if (QF && (XGW) && i < D) {                                                            \
+        xgc(C)[i] = x[C][k] * g2[k];                                                         \
+        if (i >= row0 && i < row0 + CT / LD) x0s(C)[i - row0] = x[C][k];                     \
+      }                                                                                      \
     }                                                                                        \
+    if (QF && (XGW) && tid == 0) shs(C)[0] = mean;                                           \
     shift[C] = mean;                                                                         \
     wg_barrier();                                                                            \
   }
@@ -259,12 +282,13 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           if (l > 0) fail = gather2<GPD>(GR, tag - 1, y, p.err, ctl, AXW_PAIRS_D(O_Y3, c));
           AXW_STAMP(0)
           AXW_TL(0)
-          AXW_LN_STAGE(y, l > 0, fail, 0x100 + l, c)
+          AXW_LN_STAGE_X(y, l > 0, fail, 0x100 + l, c, in_o)
           AXW_STAMP(1)
           AXW_TL(1)
           if (c == 0 && l == sa_layer && sa_first) AXW_SA0_POLL
         }
-        ln_prefetch(FL + DecArena::F_CROSS_LN_W * D, FL + DecArena::F_CROSS_LN_B * D);
+        if constexpr (QF) ln_prefetch(FL + DecArena::F_MLP_LN_W * D, FL + DecArena::F_MLP_LN_B * D);
+        else ln_prefetch(FL + DecArena::F_CROSS_LN_W * D, FL + DecArena::F_CROSS_LN_B * D);
         // ---- self-attention owner (clip 0: LDS cache, clip 1: global memory)
         if (l == sa_layer) {
           if (!sa_first) AXW_SA0_POLL
@@ -356,9 +380,51 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           }
         }
         const int cu = ca_unit_of(step * L + l);
+        if constexpr (QF) {
+          // ---- cross-attention unit: T of the head + the producers' statistics of ITS clip -> the head's query (decode_persistent.hip)
+          if (cu >= 0) {
+            const int ca_clip = cu / NU, ca_head = (cu % NU) / kCrossSplit;
+            constexpr int SL = (NP_D + 1) / 2;
+            static_assert(32 + SL <= 64, "statistics lanes");
+            float sj[2] = {0.f, 0.f}, cj[2] = {0.f, 0.f};
+            if (tid < 32) {
+              const float* qfl = AXW_COLD(qf) + (long)l * qfold_stride(D) + (long)D * D;
+              const float2 s2 = *reinterpret_cast<const float2*>(qfl + D + ca_head * 64 + 2 * tid);
+              const float2 c2 = *reinterpret_cast<const float2*>(qfl + 2 * D + ca_head * 64 + 2 * tid);
+              sj[0] = s2.x; sj[1] = s2.y; cj[0] = c2.x; cj[1] = c2.y;
+            }
+            unsigned v[4];
+            const bool fail = gather2<2>(GR, tag, v, p.err, ctl, [&](int k2) {
+              if (tid < 32) return k2 == 0 ? ca_clip * gco + O_CQ + ca_head * 64 + 2 * tid : -1;
+              const int pi = (tid - 32) + k2 * SL;
+              return (tid < 32 + SL && pi < NP_D) ? ca_clip * gco + O_STAT + 16 * pi : -1;
+            });
+            if (tid < 64) {
+              const bool st = tid >= 32;
+              const float t1 = wsum(st ? __uint_as_float(v[0]) + __uint_as_float(v[2]) : 0.f);
+              const float t2 = wsum(st ? __uint_as_float(v[1]) + __uint_as_float(v[3]) : 0.f);
+              const float dm = t1 / D, var = fmaxf(t2 / D - dm * dm, 0.f);
+              float shc = shift[0];
+#pragma unroll
+              for (int c = 1; c < NC; ++c) shc = ca_clip == c ? shift[c] : shc;
+              const float mu = shc + dm, r = rsqrtf(var + 1e-5f);
+              if (tid < 32) {
+                const float q0 = r * (__uint_as_float(v[0]) - mu * sj[0]) + cj[0], q1 = r * (__uint_as_float(v[1]) - mu * sj[1]) + cj[1];
+                unsigned hi, lo;
+                h16split2(q0, q1, hi, lo);
+                qs[tid] = hi;
+                qs[32 + tid] = lo;
+              }
+            }
+            if (fail) ctl[0] = 1;
+            AXW_STAMP(7)
+            AXW_BARRIER_CHECK(0x500 + l)
+            AXW_STAMP(8)
+          }
+        }
         // ---- cross-attention query
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
+        for (int c = 0; c < NC && !QF; ++c) {
           unsigned y[GD];
           const bool fail = gather2<GPD>(GR, tag, y, p.err, ctl, AXW_PAIRS_D(O_Y1, c));
           AXW_STAMP(5)
@@ -384,7 +450,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
             AXW_STAMP(8)
           }
         }
-        ln_prefetch(FL + DecArena::F_MLP_LN_W * D, FL + DecArena::F_MLP_LN_B * D);
+        if constexpr (!QF) ln_prefetch(FL + DecArena::F_MLP_LN_W * D, FL + DecArena::F_MLP_LN_B * D);
         // ---- cross-attention output projection: merge the partials of every head
         if (in_o) {
 #pragma unroll
@@ -429,14 +495,25 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         // ---- mlp.0
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          unsigned y[GD];
-          const bool fail = gather2<GPD>(GR, tag, y, p.err, ctl, AXW_PAIRS_D(O_Y2, c));
-          AXW_STAMP(11)
-          AXW_TL(7)
-          AXW_LN_STAGE(y, true, fail, 0x700 + l, c)
+          if constexpr (QF) {  // x += y1, then += y2: the unfolded launch's order of additions
+            unsigned y[2 * GD];
+            const bool fail = gather2<2 * GPD>(GR, tag, y, p.err, ctl, [&](int j) { const int pr = tid + (j % GPD) * PL; return 2 * pr < D ? c * gco + (j < GPD ? O_Y1 : O_Y2) + 2 * pr : -1; });
+#pragma unroll
+            for (int k = 0; k < GD; ++k) if (el(k) < D) x[c][k] = (x[c][k] + __uint_as_float(y[k])) + __uint_as_float(y[GD + k]);
+            AXW_STAMP(11)
+            AXW_TL(7)
+            AXW_LN_STAGE(y, false, fail, 0x700 + l, c)
+          } else {
+            unsigned y[GD];
+            const bool fail = gather2<GPD>(GR, tag, y, p.err, ctl, AXW_PAIRS_D(O_Y2, c));
+            AXW_STAMP(11)
+            AXW_TL(7)
+            AXW_LN_STAGE(y, true, fail, 0x700 + l, c)
+          }
           AXW_STAMP(12)
           AXW_TL(8)
         }
+        g2_prefetch(l + 1 < L ? l + 1 : 0);
         if (l + 1 < L) ln_prefetch(FL + DecArena::f_stride(D) + DecArena::F_ATTN_LN_W * D, FL + DecArena::f_stride(D) + DecArena::F_ATTN_LN_B * D);
         else ln_prefetch(AXW_COLD(ln_w), AXW_COLD(ln_b));
         // ---- mlp.2: the 4d-wide hidden vector is the largest hand-off; the pollers collect its first half, the compute
@@ -530,6 +607,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
       }
     }
 #undef AXW_LN_STAGE
+#undef AXW_LN_STAGE_X
 #undef AXW_SA0_POLL
 #undef AXW_PAIRS_D
   } else {
@@ -643,30 +721,113 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           AXW_TL(10)
           if (c == 0 && l == sa_layer && sa_first) AXW_SA0_COMP
         }
+        // QF, row producers: A0 = W_cq (g . x0) of this slot's row for EVERY clip (g . x0 has been in LDS since the clip's QKV stage);
+        // the rows of W_cq take the set the QKV rows leave. In the layer whose head this workgroup owns, behind clip 0's blocks.
+        auto a0_rows = [&]() {
+          if constexpr (QF) {
+            if (in_o) {
+#pragma unroll
+              for (int c = 0; c < NC; ++c) {
+                float ra0[2];
+                ra.run(w_cq, nullptr, D, xgc(c), ctid, ra0);
+                if (ctid % LD == 0) a0s(c)[ctid / LD] = ra0[0];
+              }
+            }
+          }
+        };
+        if constexpr (QF) {
+          if (in_o) ra.prefetch(w_cq, nullptr, D, D, rwg, P, ctid, pk_d);
+          if (l != sa_layer) a0_rows();
+        }
         // ---- self-attention (clip 1's blocks are the poller waves' — see there: only the hand-over of its query is shared)
         if (l == sa_layer) {
           if (!sa_first) AXW_SA0_COMP
+          a0_rows();
 #pragma unroll
           for (int c = 1; c < NC; ++c) AXW_BARRIER_CHECK(0x200 + l)
         }
         // ---- attention output projection
-        if (in_o) {
+        if constexpr (QF) {
+          if (in_o) {
+            // y1 rows as always, T = A0 + M a + d for the same rows and the two sums of this slice of x1 = x0 + y1, clip by clip:
+            // three lines, one store instruction each, all by the compute wave that arrives last (decode_persistent.hip)
+            const float* qfl = AXW_COLD(qf) + (long)l * qfold_stride(D);
+            const int slot = ctid / LD, row = rb.r0 + slot < rb.r1 ? rb.r0 + slot : rb.r0;
+            RowSetF32<LD, CD> rm;
+            rm.prefetch(qfl, qfl + (long)D * D, D, row, rb.r0 + slot < rb.r1, ctid);
 #pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            AXW_BARRIER_CHECK(0x300 + l)
-            AXW_STAMP(19)
-            AXW_TL(19)
-            rb.run(w_o, b_o, D, actc[c], ctid, res);
-            rb.publish(ctid, res, pk, ctl + 2, G + c * gco + O_Y1, tag, [](float v) { return v; });
+            for (int c = 0; c < NC; ++c) {
+              AXW_BARRIER_CHECK(0x300 + l)
+              AXW_STAMP(19)
+              AXW_TL(19)
+              rb.run(w_o, b_o, D, actc[c], ctid, res);
+              const float tq = rm.run(actc[c], ctid);
+              const int j = ctid % LD, nrows = rb.r1 - rb.r0;
+              if (j == 0 && slot < nrows) {
+                pk[slot] = res[0];
+                pk[32 + slot] = tq + a0s(c)[slot];
+                pscr[slot] = (x0s(c)[slot] + res[0]) - shs(c)[0];
+              }
+              __builtin_amdgcn_wave_barrier();
+              int old = 0;
+              if (lane == 0) old = __hip_atomic_fetch_add(ctl + 2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+              old = __builtin_amdgcn_readfirstlane(old);
+              if ((old + 1) % NCW == 0) {
+                const bool on = lane < nrows;
+                const float tv = on ? pscr[lane] : 0.f;
+                const float s1 = wsum(tv), s2 = wsum(tv * tv);
+                u64* Gc = G + c * gco;
+                if (on) gput(Gc + O_CQ + rb.r0 + lane, tag, pk[32 + lane]);
+                if (lane < 2) gput(Gc + O_STAT + 16 * rwg + lane, tag, lane == 0 ? s1 : s2);
+                if (on) gput(Gc + O_Y1 + rb.r0 + lane, tag, pk[lane]);
+              }
+            }
           }
+          rb.prefetch(w_co, b_co, D, D, rwg, P, ctid, pk_d);
+          kv_piece(11, 16);
+          AXW_STAMP(20)
+          AXW_TL(12)
+          // ---- cross-attention over one third of the 1536 padded keys, if this workgroup holds a unit of this layer
+          if (cu >= 0) {
+            const int ca_clip = cu / NU, ca_head = (cu % NU) / kCrossSplit, ca_split = cu % kCrossSplit;
+            AXW_BARRIER_CHECK(0x500 + l)
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's own K/V tiles have landed
+            asm volatile("" ::: "memory");
+            const int key = (ca_split * NCW + cw) * 64 + lane;
+            attn_block<false>(sK + cw * 4096, sV + cw * 4096, qs, key < p.n_audio_ctx, pscr + cw * 64, wpart + cw * kPS, lane);
+            __builtin_amdgcn_wave_barrier();
+            int old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(ctl + 3, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if ((old + 1) % NCW == 0) {
+              float m, lt, ov;
+              merge_partials(wpart, NCW, lane, &m, &lt, &ov);
+              u64* out = G + ca_clip * gco + O_PART + (ca_head * kCrossSplit + ca_split) * kRec;
+              gput(out + lane, tag, ov);
+              if (lane < 2) gput(out + 64 + lane, tag, lane == 0 ? m : lt);
+            }
+            AXW_STAMP(23)
+            AXW_TL(14)
+          }
+        } else {
+          if (in_o) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              AXW_BARRIER_CHECK(0x300 + l)
+              AXW_STAMP(19)
+              AXW_TL(19)
+              rb.run(w_o, b_o, D, actc[c], ctid, res);
+              rb.publish(ctid, res, pk, ctl + 2, G + c * gco + O_Y1, tag, [](float v) { return v; });
+            }
+          }
+          ra.prefetch(w_cq, b_cq, D, D, rwg, P, ctid, pk_d);
+          kv_piece(11, 16);
+          AXW_STAMP(20)
+          AXW_TL(12)
         }
-        ra.prefetch(w_cq, b_cq, D, D, rwg, P, ctid, pk_d);
-        kv_piece(11, 16);
-        AXW_STAMP(20)
-        AXW_TL(12)
         // ---- cross-attention query (export_onnx.py:221-230)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
+        for (int c = 0; c < NC && !QF; ++c) {
           AXW_BARRIER_CHECK(0x400 + l)
           wg_barrier();
           AXW_STAMP(21)
@@ -934,7 +1095,7 @@ static size_t persist2_lds_bytes(int d, int nc) {
   // the one-clip launch's LDS + per later clip its d-wide input vector, query (64 words), argmax scratch (32) and the
   // self-attention k, v rows of its current step (64) + the poller waves' attention scratch
   return (size_t)kKvBytes + ((size_t)4 * d + d / 8 + NCW * kPS + 2 * NPW + 64 + 16 + 16 + 16 + 64 + NCW * 64) * 4 + 64 * 8 + 64 +
-         ((size_t)(nc - 1) * (d + 64 + 32 + 64) + NPW * kPS + NPW * 64) * 4;
+         ((size_t)(nc - 1) * (d + 64 + 32 + 64) + NPW * kPS + NPW * 64 + (size_t)nc * 68) * 4;  // (+ the query fold's 68 words per clip)
 }
 int decode_persistent_max_clips(int d_model, int n_head, int n_layer, int grid) {
   // every linear layer must be ONE pass of rows per workgroup (a second pass overwrites the rows the next clip still
@@ -947,14 +1108,18 @@ int decode_persistent_max_clips(int d_model, int n_head, int n_layer, int grid) 
   return nc;
 }
 
-template <int LD, int CD, int LF, int CF, int NC, bool PROF = false>
-static hipError_t launch_multi(const PersistParams& p, int grid, hipStream_t s) {
+template <int LD, int CD, int LF, int CF, int NC, bool PROF, bool QF>
+static hipError_t launch_multi_q(const PersistParams& p, int grid, hipStream_t s) {
   const size_t lds = persist2_lds_bytes(8 * LD * CD, NC);
-  auto kfn = decode_persistent_kernel<LD, CD, LF, CF, PROF, NC>;
+  auto kfn = decode_persistent_kernel<LD, CD, LF, CF, PROF, NC, QF>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(PT), lds, s, p);
   return hipGetLastError();
+}
+template <int LD, int CD, int LF, int CF, int NC, bool PROF = false>
+static hipError_t launch_multi(const PersistParams& p, int grid, hipStream_t s) {  // the query fold where the engine built its arena
+  return p.qf ? launch_multi_q<LD, CD, LF, CF, NC, PROF, true>(p, grid, s) : launch_multi_q<LD, CD, LF, CF, NC, PROF, false>(p, grid, s);
 }
 template <int LD, int CD, int LF, int CF>
 static hipError_t launch_nc(const PersistParams& p, int grid, hipStream_t s) {

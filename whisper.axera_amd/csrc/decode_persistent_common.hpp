@@ -466,5 +466,42 @@ __device__ __forceinline__ void merge_partials(const float* wpart, int nb, int c
 }
 
 
+// ---------------------------------------------------------------------------------------- the query fold's pieces (decode_persistent.hip)
+// fp32 weight rows of M: LPR lanes share a row, 2 * CH chunks of 4 floats per lane (element layout of rows_dot).
+template <int LPR, int CH>
+struct RowSetF32 {
+  u32x4 w[2 * CH];
+  float bias;
+  __device__ __forceinline__ void prefetch(const float* W, const float* b, int K, int row, bool on, int ctid) {
+    const int j = ctid % LPR;
+    const float* wr = W + (long)row * K;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      w[2 * i] = *reinterpret_cast<const u32x4*>(wr + (j + LPR * i) * 8);
+      w[2 * i + 1] = *reinterpret_cast<const u32x4*>(wr + (j + LPR * i) * 8 + 4);
+    }
+    bias = (on && j == 0) ? b[row] : 0.f;
+  }
+  __device__ __forceinline__ float run(const float* act, int ctid) const {
+    const int j = ctid % LPR;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const float4 x0 = *reinterpret_cast<const float4*>(act + (j + LPR * i) * 8);
+      const float4 x1 = *reinterpret_cast<const float4*>(act + (j + LPR * i) * 8 + 4);
+      a0 = fmaf(__uint_as_float(w[2 * i][0]), x0.x, a0); a1 = fmaf(__uint_as_float(w[2 * i][1]), x0.y, a1);
+      a0 = fmaf(__uint_as_float(w[2 * i][2]), x0.z, a0); a1 = fmaf(__uint_as_float(w[2 * i][3]), x0.w, a1);
+      a0 = fmaf(__uint_as_float(w[2 * i + 1][0]), x1.x, a0); a1 = fmaf(__uint_as_float(w[2 * i + 1][1]), x1.y, a1);
+      a0 = fmaf(__uint_as_float(w[2 * i + 1][2]), x1.z, a0); a1 = fmaf(__uint_as_float(w[2 * i + 1][3]), x1.w, a1);
+    }
+    return group_sum<LPR>(a0 + a1) + bias;
+  }
+};
+
+// per-layer block of the fold arena (floats): M [D][D], then d, s, c [D] each, then the LayerNorm fold of the two LayerNorm-fed
+// row phases (below): s_qkv, c_qkv [3D], s_fc1, c_fc1 [4D]
+__host__ __device__ constexpr long qfold_stride(int d) { return (long)d * d + 17L * d; }
+constexpr int QF_SQKV = 3, QF_CQKV = 6, QF_SFC1 = 9, QF_CFC1 = 13;  // vector offsets behind M, in units of D
+
 }  // inline namespace AXW_NS
 }  // namespace axw
