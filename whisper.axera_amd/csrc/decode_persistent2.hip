@@ -384,38 +384,11 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           // ---- cross-attention unit: T of the head + the producers' statistics of ITS clip -> the head's query (decode_persistent.hip)
           if (cu >= 0) {
             const int ca_clip = cu / NU, ca_head = (cu % NU) / kCrossSplit;
-            constexpr int SL = (NP_D + 1) / 2;
-            static_assert(32 + SL <= 64, "statistics lanes");
-            float sj[2] = {0.f, 0.f}, cj[2] = {0.f, 0.f};
-            if (tid < 32) {
-              const float* qfl = AXW_COLD(qf) + (long)l * qfold_stride(D) + (long)D * D;
-              const float2 s2 = *reinterpret_cast<const float2*>(qfl + D + ca_head * 64 + 2 * tid);
-              const float2 c2 = *reinterpret_cast<const float2*>(qfl + 2 * D + ca_head * 64 + 2 * tid);
-              sj[0] = s2.x; sj[1] = s2.y; cj[0] = c2.x; cj[1] = c2.y;
-            }
-            unsigned v[4];
-            const bool fail = gather2<2>(GR, tag, v, p.err, ctl, [&](int k2) {
-              if (tid < 32) return k2 == 0 ? ca_clip * gco + O_CQ + ca_head * 64 + 2 * tid : -1;
-              const int pi = (tid - 32) + k2 * SL;
-              return (tid < 32 + SL && pi < NP_D) ? ca_clip * gco + O_STAT + 16 * pi : -1;
-            });
-            if (tid < 64) {
-              const bool st = tid >= 32;
-              const float t1 = wsum(st ? __uint_as_float(v[0]) + __uint_as_float(v[2]) : 0.f);
-              const float t2 = wsum(st ? __uint_as_float(v[1]) + __uint_as_float(v[3]) : 0.f);
-              const float dm = t1 / D, var = fmaxf(t2 / D - dm * dm, 0.f);
-              float shc = shift[0];
+            float shc = shift[0];
 #pragma unroll
-              for (int c = 1; c < NC; ++c) shc = ca_clip == c ? shift[c] : shc;
-              const float mu = shc + dm, r = rsqrtf(var + 1e-5f);
-              if (tid < 32) {
-                const float q0 = r * (__uint_as_float(v[0]) - mu * sj[0]) + cj[0], q1 = r * (__uint_as_float(v[1]) - mu * sj[1]) + cj[1];
-                unsigned hi, lo;
-                h16split2(q0, q1, hi, lo);
-                qs[tid] = hi;
-                qs[32 + tid] = lo;
-              }
-            }
+            for (int c = 1; c < NC; ++c) shc = ca_clip == c ? shift[c] : shc;
+            const bool fail = qfold_unit_query<D, NP_D>(GR, tag, tid, ca_clip * gco + O_CQ, ca_clip * gco + O_STAT,
+                                                        AXW_COLD(qf) + (long)l * qfold_stride(D) + (long)D * D, ca_head, shc, qs, p.err, ctl);
             if (fail) ctl[0] = 1;
             AXW_STAMP(7)
             AXW_BARRIER_CHECK(0x500 + l)
@@ -768,19 +741,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
                 pk[32 + slot] = tq + a0s(c)[slot];
                 pscr[slot] = (x0s(c)[slot] + res[0]) - shs(c)[0];
               }
-              __builtin_amdgcn_wave_barrier();
-              int old = 0;
-              if (lane == 0) old = __hip_atomic_fetch_add(ctl + 2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-              old = __builtin_amdgcn_readfirstlane(old);
-              if ((old + 1) % NCW == 0) {
-                const bool on = lane < nrows;
-                const float tv = on ? pscr[lane] : 0.f;
-                const float s1 = wsum(tv), s2 = wsum(tv * tv);
-                u64* Gc = G + c * gco;
-                if (on) gput(Gc + O_CQ + rb.r0 + lane, tag, pk[32 + lane]);
-                if (lane < 2) gput(Gc + O_STAT + 16 * rwg + lane, tag, lane == 0 ? s1 : s2);
-                if (on) gput(Gc + O_Y1 + rb.r0 + lane, tag, pk[lane]);
-              }
+              qfold_publish(lane, pk, pscr, ctl + 2, G + c * gco, O_CQ, O_STAT, O_Y1, rb.r0, nrows, rwg, tag);
             }
           }
           rb.prefetch(w_co, b_co, D, D, rwg, P, ctid, pk_d);

@@ -503,5 +503,63 @@ struct RowSetF32 {
 __host__ __device__ constexpr long qfold_stride(int d) { return (long)d * d + 17L * d; }
 constexpr int QF_SQKV = 3, QF_CQKV = 6, QF_SFC1 = 9, QF_CFC1 = 13;  // vector offsets behind M, in units of D
 
+// A cross-attention unit's side of the query fold: wave 0 gathers the head's 64 T values (lanes 0-31, pairs at granule base_cq)
+// and the row producers' statistics (lanes 32.., up to two producers each, one 16-granule line per producer at base_stat),
+// derives mu / r of x1 = x0 + y1 (shift = the mean of x0, the same bits in every workgroup) and leaves the query
+// cq_j = r (T_j - mu s_j) + c_j as packed (hi, lo) h16 pairs in qs. vec: the layer's fold vectors behind M (d, s, c at 0, D, 2D).
+// Every wave of the pollers calls it (the gather's give-up logic is workgroup-wide); returns true on give-up.
+template <int D, int NP_D>
+__device__ __forceinline__ bool qfold_unit_query(__amdgpu_buffer_rsrc_t GR, unsigned tag, int tid, int base_cq, int base_stat, const float* vec,
+                                                 int head, float shift, unsigned* qs, const unsigned* err, const int* ctl) {
+  constexpr int SL = (NP_D + 1) / 2;  // lanes that hold statistics
+  static_assert(32 + SL <= 64, "statistics lanes");
+  float sj[2] = {0.f, 0.f}, cj[2] = {0.f, 0.f};
+  if (tid < 32) {
+    const float2 s2 = *reinterpret_cast<const float2*>(vec + D + head * 64 + 2 * tid);
+    const float2 c2 = *reinterpret_cast<const float2*>(vec + 2 * D + head * 64 + 2 * tid);
+    sj[0] = s2.x; sj[1] = s2.y; cj[0] = c2.x; cj[1] = c2.y;
+  }
+  unsigned v[4];
+  const bool fail = gather2<2>(GR, tag, v, err, ctl, [&](int k2) {
+    if (tid < 32) return k2 == 0 ? base_cq + head * 64 + 2 * tid : -1;
+    const int pi = (tid - 32) + k2 * SL;
+    return (tid < 32 + SL && pi < NP_D) ? base_stat + 16 * pi : -1;
+  });
+  if (tid < 64) {
+    const bool st = tid >= 32;
+    const float t1 = wsum(st ? __uint_as_float(v[0]) + __uint_as_float(v[2]) : 0.f);
+    const float t2 = wsum(st ? __uint_as_float(v[1]) + __uint_as_float(v[3]) : 0.f);
+    const float dm = t1 / D, var = fmaxf(t2 / D - dm * dm, 0.f);
+    const float mu = shift + dm, r = rsqrtf(var + 1e-5f);
+    if (tid < 32) {
+      const float q0 = r * (__uint_as_float(v[0]) - mu * sj[0]) + cj[0], q1 = r * (__uint_as_float(v[1]) - mu * sj[1]) + cj[1];
+      unsigned hi, lo;
+      h16split2(q0, q1, hi, lo);
+      qs[tid] = hi;
+      qs[32 + tid] = lo;
+    }
+  }
+  return fail;
+}
+
+// A row producer's side: the slot leaders have left y1 in pk[slot], T in pk[32 + slot] and x1 - shift in pscr[slot]; the compute
+// wave that arrives last (LDS counter cnt) stores T, the two sums and y1 — three lines, one store instruction each, the ones
+// the units wait for first. Gc: the clip's granule area; o_cq / o_stat / o_y1: buffer offsets; r0: first row, nrows <= 32.
+__device__ __forceinline__ void qfold_publish(int lane, const float* pk, const float* pscr, int* cnt, u64* Gc, int o_cq, int o_stat, int o_y1,
+                                              int r0, int nrows, int producer, unsigned tag) {
+  __builtin_amdgcn_wave_barrier();
+  int old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  old = __builtin_amdgcn_readfirstlane(old);
+  if ((old + 1) % NCW == 0) {
+    const bool on = lane < nrows;
+    const float tv = on ? pscr[lane] : 0.f;
+    const float s1 = wsum(tv), s2 = wsum(tv * tv);
+    if (on) gput(Gc + o_cq + r0 + lane, tag, pk[32 + lane]);
+    if (lane < 2) gput(Gc + o_stat + 16 * producer + lane, tag, lane == 0 ? s1 : s2);
+    if (on) gput(Gc + o_y1 + r0 + lane, tag, pk[lane]);
+  }
+}
+
 }  // inline namespace AXW_NS
 }  // namespace axw
