@@ -412,19 +412,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
           for (int k = 0; k < GD; ++k) {
             const int i = tid + k * PL;
             if (i < D) {
-              const float* pp = pbuf + (i >> 6) * kCrossSplit * kPS;  // records [o[64], m, l] of this head's key ranges
-              float m = pp[64];
-#pragma unroll
-              for (int sp = 1; sp < kCrossSplit; ++sp) m = fmaxf(m, pp[sp * kPS + 64]);
-              float lt = 0.f, ov = 0.f;
-#pragma unroll
-              for (int sp = 0; sp < kCrossSplit; ++sp) {
-                const float ms = pp[sp * kPS + 64];
-                const float f = ms > -INFINITY ? __expf(ms - m) : 0.f;
-                lt += f * pp[sp * kPS + 65];
-                ov += f * pp[sp * kPS + (i & 63)];
-              }
-              act[i] = ov / lt;
+              act[i] = merge_cross_records(pbuf, i);
             }
           }
           wg_barrier();
@@ -721,25 +709,7 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(PersistParams p) 
         if (cu >= 0) {
           const int ca_head = cu / kCrossSplit, ca_split = cu % kCrossSplit;
           AXW_BARRIER_CHECK(0x500 + l)
-          // this wave's own K/V tiles have landed. The builtin, not inline asm: behind an asm that may touch the counters the
-          // compiler drains vmcnt at every following join (measured: +18 ms on Whisper-small for one such asm in a cold path)
-          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-          asm volatile("" ::: "memory");
-          const int key = (ca_split * NCW + cw) * 64 + lane;
-          attn_block<false>(sK + cw * 4096, sV + cw * 4096, qs, key < p.n_audio_ctx, pscr + cw * 64, wpart + cw * kPS, lane);
-          __builtin_amdgcn_wave_barrier();
-          int old = 0;
-          if (lane == 0) old = __hip_atomic_fetch_add(ctl + 3, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-          old = __builtin_amdgcn_readfirstlane(old);
-          if ((old + 1) % NCW == 0) {  // the wave that arrives last merges and publishes
-            const int ctid = lane;
-            float m, lt, ov;
-            merge_partials(wpart, NCW, ctid, &m, &lt, &ov);
-            // one 64-lane store of o (four full lines) + one 2-lane store of (m, l)
-            u64* out = G + O_PART + (ca_head * kCrossSplit + ca_split) * kRec;
-            gput(out + ctid, tag, ov);
-            if (ctid < 2) gput(out + 64 + ctid, tag, ctid == 0 ? m : lt);
-          }
+          cross_unit_block(sK, sV, qs, pscr, wpart, ctl + 3, G + O_PART + (ca_head * kCrossSplit + ca_split) * kRec, tag, ca_split, p.n_audio_ctx, cw, lane);
           AXW_STAMP(23)
           AXW_TL(14)
         }

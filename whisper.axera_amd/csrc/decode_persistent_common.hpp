@@ -503,6 +503,48 @@ struct RowSetF32 {
 __host__ __device__ constexpr long qfold_stride(int d) { return (long)d * d + 17L * d; }
 constexpr int QF_SQKV = 3, QF_CQKV = 6, QF_SFC1 = 9, QF_CFC1 = 13;  // vector offsets behind M, in units of D
 
+// One cross-attention unit (a clip's head, one third of the 1536 padded keys) on the eight compute waves, behind the barrier that
+// handed over the query: every wave runs its 64-key block from the LDS tiles (export_onnx.py:221-230: fp32 softmax, no mask but
+// the padding), the wave that arrives last merges the eight partials and publishes the record — o[64] as four full lines, then
+// (m, l). out: the record's granules; cnt: the LDS arrival counter.
+__device__ __forceinline__ void cross_unit_block(const h16* sK, const h16* sV, const unsigned* qs, float* pscr, float* wpart, int* cnt, u64* out,
+                                                 unsigned tag, int ca_split, int n_audio_ctx, int cw, int lane) {
+  // this wave's own K/V tiles have landed. The builtin, not inline asm: behind an asm that may touch the counters the compiler
+  // drains vmcnt at every following join (measured: +18 ms on Whisper-small for one such asm in a cold path)
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  asm volatile("" ::: "memory");
+  const int key = (ca_split * NCW + cw) * 64 + lane;
+  attn_block<false>(sK + cw * 4096, sV + cw * 4096, qs, key < n_audio_ctx, pscr + cw * 64, wpart + cw * kPS, lane);
+  __builtin_amdgcn_wave_barrier();
+  int old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  old = __builtin_amdgcn_readfirstlane(old);
+  if ((old + 1) % NCW == 0) {
+    float m, lt, ov;
+    merge_partials(wpart, NCW, lane, &m, &lt, &ov);
+    gput(out + lane, tag, ov);
+    if (lane < 2) gput(out + 64 + lane, tag, lane == 0 ? m : lt);
+  }
+}
+
+// The row producers' merge of a head's kCrossSplit partial records (pbuf: [H][kCrossSplit][kPS] = o[64], m, l each) into the
+// attention vector element i of this lane (softmax over the whole key range: rescale to the common maximum, then normalise).
+__device__ __forceinline__ float merge_cross_records(const float* pbuf, int i) {
+  const float* pp = pbuf + (i >> 6) * kCrossSplit * kPS;
+  float m = pp[64];
+#pragma unroll
+  for (int sp = 1; sp < kCrossSplit; ++sp) m = fmaxf(m, pp[sp * kPS + 64]);
+  float lt = 0.f, ov = 0.f;
+#pragma unroll
+  for (int sp = 0; sp < kCrossSplit; ++sp) {
+    const float ms = pp[sp * kPS + 64];
+    const float f = ms > -INFINITY ? __expf(ms - m) : 0.f;
+    lt += f * pp[sp * kPS + 65];
+    ov += f * pp[sp * kPS + (i & 63)];
+  }
+  return ov / lt;
+}
+
 // A cross-attention unit's side of the query fold: wave 0 gathers the head's 64 T values (lanes 0-31, pairs at granule base_cq)
 // and the row producers' statistics (lanes 32.., up to two producers each, one 16-granule line per producer at base_stat),
 // derives mu / r of x1 = x0 + y1 (shift = the mean of x0, the same bits in every workgroup) and leaves the query
