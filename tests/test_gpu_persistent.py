@@ -265,3 +265,61 @@ def test_three_clip_launch_equals_one_clip_launches(built_lib, tmp_path, monkeyp
         assert [len(g) for g in got] == [len(s) for s in single]
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("model_type,seed,kind", [("micro", 11, "benign"), ("mini", 42, "realistic"), ("small", 45, "realistic")])
+def test_query_fold_equals_the_unfolded_launch(built_lib, oracle_mod, tmp_path, monkeypatch, model_type, seed, kind):
+    """Round 5: the persistent launches fold the cross-attention query through the output projection and the LayerNorm into
+    the QKV / mlp.0 rows (decode_persistent.hip). The folded and the unfolded launch (AX_WHISPER_QFOLD=0) evaluate the same
+    arithmetic in another association: teacher-forced logits within 2e-5 (benign) / 4e-4 (trained-model statistics) of the
+    logit scale, greedy ids equal (or a tie at
+    the first difference, measured), for one, two and three clips — on benign and on trained-model-like weights."""
+    import modelgen
+
+    case = ModelCase(tmp_path, model_type, seed, kind=kind)
+    clips = [load_demo_pcm(), modelgen.synth_clip(seed, 200000), modelgen.synth_clip(seed + 1, 90000)]
+    n_new = 40 if model_type != "small" else 24
+    res = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("AX_WHISPER_QFOLD", fold)
+        e = built_lib.Whisper(model_type, case.root, "zh", device=0, max_batch=3)
+        try:
+            assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_qfold") == int(fold)
+            mels = np.stack([e.compute_mel(c) for c in clips])
+            e.encode_mel(mels[0])
+            ids1 = e.decode_greedy(1, max_new=n_new)[0]
+            forced = np.array([ids1], dtype=np.int32) if fold == "1" else np.array([res["1"][0]], dtype=np.int32)
+            e.encode_mel(mels[0])
+            logits, _ = e.decode_forced(1, forced)
+            groups = []
+            for B in (2, 3):
+                if B > e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_max_clips"):
+                    continue
+                e.encode_mel(mels[:B])
+                groups.append(e.decode_greedy(B, max_new=n_new))
+            assert e.L.AX_WHISPER_GetConfigInt(e.h, b"persistent_giveups") == 0
+            res[fold] = (ids1, logits[0], groups)
+        finally:
+            e.close()
+    (ids_f, lg_f, gr_f), (ids_u, lg_u, gr_u) = res["1"], res["0"]
+    scale = float(np.abs(lg_u).max())
+    err = float(np.abs(lg_f - lg_u).max())
+    print(f"{model_type} ({kind}): folded vs unfolded logits differ by {err:.3e} at |logit| <= {scale:.1f}")
+    # benign weights: fp32 association noise. Trained-model statistics: a last-bit fp32 difference flips the 16-bit rounding of a
+    # stored self-attention K/V entry here and there (2^-9 relative), which the outlier channels amplify — the same size as the
+    # difference between any two decode paths of the battery (tests/test_gpu_realistic.py: 6.5e-2 / 8.2e-2 vs the oracle at
+    # these dims); measured 3.3e-2 at |logit| <= 189 (small), 3.4e-4 at 328 (mini)
+    rel = 2e-5 if kind == "benign" else 4e-4
+    assert err < rel * max(scale, 1.0) + 2e-5, (err, scale)
+
+    def same_or_tie(a, b, lg):
+        if a == b:
+            return True
+        i = next(i for i in range(min(len(a), len(b))) if a[i] != b[i])
+        srt = np.sort(lg[i])
+        return i < len(lg) and srt[-1] - srt[-2] < 2 * err + 1e-4
+
+    assert same_or_tie(ids_f, ids_u, lg_u)
+    for gf, gu in zip(gr_f, gr_u):
+        # group launches: the same association difference; a clip may leave the other's ids at a numerical tie only
+        assert sum(gf[b] == gu[b] for b in range(len(gf))) >= len(gf) - 1, [(len(a), len(b)) for a, b in zip(gf, gu)]

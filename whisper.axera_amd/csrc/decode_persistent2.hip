@@ -1047,9 +1047,12 @@ static hipError_t launch_nc(const PersistParams& p, int grid, hipStream_t s) {
 
 hipError_t launch_decode_persistent2(const PersistParams& p, int d_model, int grid, hipStream_t s) {
   if ((p.n_clip != 2 && p.n_clip != 3) || p.forced || p.logits_dump || p.argmax_dump) return hipErrorInvalidValue;
-  // the in-kernel timeline (AX_WHISPER_PERSIST_PROF): Whisper-small's shape, two clips only. Phase sums cover both clips; the
+  // the in-kernel timeline (AX_WHISPER_PERSIST_PROF): Whisper-small's shape. Phase sums cover all clips; the
   // absolute stamps of one layer are clip 0's (first writer) or clip 1's (last writer, AX_WHISPER_PERSIST_PROF_CLIP=1)
-  if (p.prof) return d_model == 768 && p.n_clip == 2 ? launch_multi<32, 3, 64, 6, 2, true>(p, grid, s) : hipErrorInvalidValue;
+  if (p.prof) {
+    if (d_model != 768) return hipErrorInvalidValue;
+    return p.n_clip == 2 ? launch_multi<32, 3, 64, 6, 2, true>(p, grid, s) : launch_multi<32, 3, 64, 6, 3, true>(p, grid, s);
+  }
   switch (d_model) {
     case 128: return launch_nc<16, 1, 32, 2>(p, grid, s);
     case 256: return launch_nc<32, 1, 64, 2>(p, grid, s);
