@@ -308,10 +308,14 @@ def stream_leg(torch, dev, dev_index, sync, model, dtype, n_slots, n_clips, mode
         eng.run_stream(clips[: 2 * n_slots], n_slots, max_new=budgets[: 2 * n_slots], min_admit=min_admit)  # warm: graphs, buffers
         sync()
         t0 = time.perf_counter()
-        got, calls = eng.run_stream(clips, n_slots, max_new=budgets, min_admit=min_admit)
+        stamps = []
+        got, calls = eng.run_stream(clips, n_slots, max_new=budgets, min_admit=min_admit, stamps=stamps)
         dt = time.perf_counter() - t0
         assert [len(g) for g in got] == budgets
-        res[f"min_admit_{min_admit}"] = {"clips_per_s": round(n_clips / dt, 2), "wall_s": round(dt, 4), "step_calls": calls}
+        # the burst as a whole (first fill and last drain included) and its middle: completions 25 % .. 75 % of the clips
+        q1, q3 = n_clips // 4, (3 * n_clips) // 4
+        res[f"min_admit_{min_admit}"] = {"clips_per_s": round(n_clips / dt, 2), "wall_s": round(dt, 4), "step_calls": calls,
+                                          "steady_state_clips_per_s": round((q3 - q1) / (stamps[q3] - stamps[q1]), 2)}
     enc_flop = {"tiny": 40.48e9, "small": 386.63e9, "turbo": 2313.09e9}.get(model)
     groups = {}
     for k in (1, 2, 4, 8, 16, 32, 64):
@@ -324,8 +328,10 @@ def stream_leg(torch, dev, dev_index, sync, model, dtype, n_slots, n_clips, mode
     return {"value": best["clips_per_s"], "unit": "clips/s", "dtype": dtype,
             "config": {"workload": f"whisper-{model} {dtype}, {n_clips} 30 s synthetic clips (host PCM) through {n_slots} refilled slots, "
                                    f"greedy decode, per-clip budgets U{{60..150}} ids (mean {float(np.mean(budgets)):.0f})"},
+            "steady_state_clips_per_s": best["steady_state_clips_per_s"],
             "by_admission_policy": res,
-            "what": "min_admit_k: an admission pass waits for k free slots while anything is still decoding (whisper_srv --min-admit)",
+            "what": "value: the whole burst, first fill and last drain included; steady_state: completions 25 % .. 75 % of the clips over the "
+                    "time between them. min_admit_k: an admission pass waits for k free slots while anything is still decoding (whisper_srv --min-admit)",
             "encoder_pass_by_group_size": groups}
 
 

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 import subprocess
 
 import numpy as np
@@ -317,10 +318,11 @@ class Whisper:
     def stream_close(self):
         self._check(self.L.AX_WHISPER_StreamClose(self.h), "StreamClose")
 
-    def run_stream(self, clips, n_slots: int, max_new=0, steps_per_call: int = 8, min_admit: int = 1):
+    def run_stream(self, clips, n_slots: int, max_new=0, steps_per_call: int = 8, min_admit: int = 1, stamps=None):
         """Feed `clips` through n_slots refillable slots in arrival order; max_new: one budget or one per clip.
         min_admit: free slots to wait for before an admission pass (a larger encoder batch per pass; the last clips are
-        admitted as they come). Returns (ids per clip, decoder-step calls made)."""
+        admitted as they come). stamps: a list that receives time.perf_counter() of every collected clip, in completion order.
+        Returns (ids per clip, decoder-step calls made)."""
         budgets = list(max_new) if hasattr(max_new, "__len__") else [max_new] * len(clips)
         self.stream_open(n_slots)
         try:
@@ -344,6 +346,8 @@ class Whisper:
                     if sl in owner:
                         out[owner.pop(sl)] = self.stream_collect(sl)
                         free.append(sl)
+                        if stamps is not None:
+                            stamps.append(time.perf_counter())
             return out, calls
         finally:
             self.stream_close()
