@@ -47,6 +47,16 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
   }
   if (device >= n_dev) throw std::runtime_error("HIP device ordinal out of range");
   device_ = device;
+  // Host-side file work first, OUTSIDE the allocation / capture mutex: configuration, vocabulary, the t2s dictionaries, and the
+  // weights file paged in. Creating a handle at run time (another model or dtype) then holds the mutex only for device work —
+  // allocations, uploads from memory, conversions — and not for seconds of disk reads, during which every serving handle's
+  // StreamOpen / capacity growth / first graph capture would have waited (iengine.hpp).
+  const std::string dir = model_path + "/" + model_type;
+  load_config(dir, model_type, language);
+  tokens_ = load_token_table(dir + "/" + model_type + "-tokens.txt");
+  load_t2s(model_path);
+  SafeTensors weights_file(dir + "/" + model_type + ".safetensors");
+  (void)weights_file.page_in();
   std::lock_guard<std::recursive_mutex> capture_lock(device_capture_mutex(device_));  // allocations + synchronous copies (iengine.hpp)
   HIP_CHECK(hipSetDevice(device_));
   device_set_ = true;
@@ -70,11 +80,7 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
   HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
   for (auto& e : ev_join_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 
-  const std::string dir = model_path + "/" + model_type;
-  load_config(dir, model_type, language);
-  tokens_ = load_token_table(dir + "/" + model_type + "-tokens.txt");
-  load_t2s(model_path);
-  load_weights(dir + "/" + model_type + ".safetensors");
+  load_weights(weights_file);
 
   if (max_batch <= 0) {
     const char* e = getenv("AX_WHISPER_MAX_BATCH");
@@ -297,8 +303,7 @@ static std::vector<float> make_mel_basis_t(int n_mels) {
   return out;
 }
 
-void Engine::load_weights(const std::string& path) {
-  SafeTensors st(path);
+void Engine::load_weights(const SafeTensors& st) {
   const int d = cfg_.n_text_state, nm = cfg_.n_mels, L = cfg_.n_text_layer, Le = cfg_.n_audio_layer;
   hipStream_t s = own_stream_;
 

@@ -18,6 +18,7 @@
 #include "t2s.hpp"
 
 namespace axw {
+class SafeTensors;  // host_io.hpp
 inline namespace AXW_NS {
 
 class Engine final : public IEngine {
@@ -60,7 +61,7 @@ class Engine final : public IEngine {
   hipStream_t stream() const { return user_stream_ ? user_stream_ : own_stream_; }
   void* dalloc(size_t bytes, bool zero = false);
   void load_config(const std::string& dir, const std::string& type, const std::string& language);
-  void load_weights(const std::string& path);
+  void load_weights(const SafeTensors& st);
   void load_t2s(const std::string& model_path);
   void ensure_capacity(int batch);
   void free_slot_buffers();

@@ -174,6 +174,14 @@ class SafeTensors {
   ~SafeTensors() { release(); }
   SafeTensors(const SafeTensors&) = delete;
   bool has(const std::string& n) const { return tensors_.count(n) != 0; }
+  // Read the whole file into the page cache now (one byte per page behind a WILLNEED hint), so that the uploads that follow —
+  // which the engine runs under its per-device allocation / capture mutex — copy from memory and never wait for the disk.
+  size_t page_in() const {
+    (void)madvise((void*)base_, size_, MADV_WILLNEED);
+    size_t acc = 0;
+    for (size_t o = 0; o < size_; o += 4096) acc += base_[o];
+    return acc;
+  }
   const TensorView& get(const std::string& n) const {
     auto it = tensors_.find(n);
     if (it == tensors_.end()) throw std::runtime_error("weights file lacks tensor '" + n + "'");
