@@ -254,3 +254,41 @@ def test_multi_device_handle_shards_a_batch(built_lib, micro_case, monkeypatch):
         assert e.run_tokens_batch(clips, max_new=8) == want            # every worker was joined; the handle is intact
     finally:
         e.close()
+
+
+def test_per_device_capture_mutex_switch(built_lib, micro_case, tmp_path):
+    """AX_WHISPER_CAPTURE_MUTEX=device (csrc/api.cpp device_capture_mutex: one mutex per device instead of one per process; read
+    once per process, so this runs in a child). Two handles on device 0, driven from two threads at once through the paths that
+    take that mutex — capacity growth, first-time capture of a 5-clip step graph, StreamOpen — give the ids of the same calls made
+    one after the other in the same process."""
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "child.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, threading
+        sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'whisper.axera_amd', 'tools')!r})
+        import numpy as np, torch
+        import modelgen, whisper_axera_amd as wa
+        clips = [modelgen.synth_clip(i, 50000 + 9000 * i) for i in range(6)]
+        def work(e, out):
+            out.append(e.run_tokens_batch(clips[:5], max_new=10))          # grows the capacity 1 -> 5, captures the 5-clip step graph
+            got, _ = e.run_stream(clips, 3, max_new=6, steps_per_call=2)  # StreamOpen + slot buffers
+            out.append(got)
+        a = wa.Whisper("micro", {micro_case.root!r}, "zh", device=0, max_batch=1)
+        want = []
+        work(a, want)
+        a.close()
+        hs = [wa.Whisper("micro", {micro_case.root!r}, "zh", device=0, max_batch=1) for _ in range(2)]
+        outs = [[], []]
+        ts = [threading.Thread(target=work, args=(h, o)) for h, o in zip(hs, outs)]
+        [t.start() for t in ts]; [t.join() for t in ts]
+        for h in hs: h.close()
+        assert outs[0] == want and outs[1] == want, "concurrent handles differ from the sequential run"
+        print("OK", len(want[0]), len(want[1]))
+    """))
+    env = dict(os.environ, AX_WHISPER_CAPTURE_MUTEX="device")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK 5 6" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
