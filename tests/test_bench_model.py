@@ -77,7 +77,7 @@ def test_bench_gpus_8_rehearsal_is_configs4():
     j = lines[0]
     assert j["n_gpus"] == 8 and j["config"]["batch_per_gpu"] == 64 and j["config"]["global_batch"] == 512
     assert j["gathered_rows"] == 512 and j["config"]["parallelism"] == "dp8" and j["scaling"] == "weak"
-    assert j["single_gpu_same_batch"]["steps"] == 2 and "weak_scaling_efficiency" in j  # the same-run reference of the ratio
+    assert j["single_gpu_same_batch"]["steps"] == 2 and "weak_scaling_efficiency" not in j  # the same-run one-GPU point; no efficiency claim
     assert j["value"] is None and "REHEARSAL" in j["data"]
 
 
