@@ -33,6 +33,8 @@ TOL = {   # measured on MI355X (profiles/r05_realistic_battery.txt): the bound i
     ("mini", "BF16"): (5e-2, 0.2, 0.13, 0.13),       # 9.6e-3 | 3.7e-2
     ("mini", "F16"): (6e-3, 3e-2, 1.6e-2, 1.6e-2),    # 1.3e-3 | 6.3e-3
     ("w512", "BF16"): (1.2e-2, 0.12, 0.13, 0.13),    # 2.2e-3 | 2.4e-2
+    ("tiny", "BF16"): (3.5e-2, 0.15, 0.13, 0.13),    # 6.9e-3 | 3.0e-2 (Whisper-tiny dims: logit std 7.8, |logit| up to 321)
+    ("tiny", "F16"): (3.5e-3, 1.7e-2, 1.6e-2, 1.6e-2),  # 6.3e-4 | 3.4e-3
     ("w1280", "F16"): (2e-3, 1.3e-2, 1.6e-2, 1.6e-2),  # 3.3e-4 | 2.6e-3
     ("small", "BF16"): (0.4, 0.75, 0.13, 0.13),      # 8.2e-2 | 0.15 (logit std 13.4, |logit| up to 160: 0.6 % / 1.1 % of the std)
     ("small", "F16"): (4e-2, 0.1, 1.6e-2, 1.6e-2),    # 7.6e-3 | 1.9e-2
@@ -210,9 +212,11 @@ def test_realistic_statistics_every_decode_path(built_lib, real_case, monkeypatc
         e.close()
 
 
-@pytest.mark.parametrize("model_type,dtype,seed,batches", [("w512", "BF16", 46, (1, 5)), ("w1280", "F16", 47, (1, 5, 18))])
+@pytest.mark.parametrize("model_type,dtype,seed,batches", [("w512", "BF16", 46, (1, 5)), ("w1280", "F16", 47, (1, 5, 18)),
+                                                           ("tiny", "BF16", 48, (1, 2, 3, 5)), ("tiny", "F16", 48, (1, 3, 5))])
 def test_realistic_statistics_other_widths(built_lib, oracle_mod, tmp_path, report, model_type, dtype, seed, batches):
-    """d_model 512 (its own persistent-launch instantiation) and 1280 (the split-K sequence of d_model > 1024, fp16)."""
+    """d_model 512 (its own persistent-launch instantiation), 1280 (the split-K sequence of d_model > 1024, fp16) and Whisper-tiny's
+    dims (BASELINE configs[0]: d 384, 4 + 4 layers — the one-, two- and three-clip persistent launches of that width)."""
     case = ModelCase(tmp_path, model_type, seed, dtype=dtype, kind="realistic")
     refs = Refs(case, oracle_mod, n_new=12, n_rand=8)
     clips = _clips(3)
