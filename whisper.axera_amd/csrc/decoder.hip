@@ -30,6 +30,7 @@ namespace axw {
 inline namespace AXW_NS {
 
 constexpr int kPartStride = 66;  // m, l, o[64]  (decode_gemv.hip merges these partials)
+constexpr int kAttnSplitMax = 6;  // workgroups per (clip, head) whose partials a launch folds itself (Engine::kCrossSplitMax)
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
 
@@ -67,8 +68,11 @@ __device__ __forceinline__ uint4 ld_kv(const h16* base, long off) {
 
 // STAMP (measurement builds of the kernel only): thread 0 of every workgroup records its start and end time, so that a decoder step's attention launches can be placed on one time axis while two graph
 // branches run them side by side (a profiler serialises the branches; hipEvents see only whole replays).
-template <bool FUSE_Q, bool STAMP = false>
-__global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, int cap_blocks) {
+// NCHL > 0 (FUSE_Q at few clips, where the launch is one dependent chain and registers are free): d_model = 32 * NCHL, the lane's
+// NCHL weight chunks of the query projection are ALL requested up front, unconditionally — one memory round trip and straight-line
+// code instead of one round trip per 8 chunks behind per-chunk bounds checks (which hipcc turns into a branch per load).
+template <bool FUSE_Q, bool STAMP = false, int NCHL = 0>
+__global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, int cap_blocks, int stamp_point) {
   __shared__ float s_part[4][kPartStride];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the block loop below is wave-uniform control flow
@@ -80,10 +84,14 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
     my_stamp = p.stamp + 2 * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
     if (tid == 0) my_stamp[0] = (unsigned long long)wall_clock64();
   }
-  auto stamp_end = [&] { if constexpr (STAMP) { if (tid == 0) my_stamp[1] = (unsigned long long)wall_clock64(); } };
+  auto stamp_end = [&] { if constexpr (STAMP) { if (tid == 0 && stamp_point == 0) my_stamp[1] = (unsigned long long)wall_clock64(); } };
+  // AX_WHISPER_ATTN_STAMP_POINT=k (measurement builds): the "end" stamp is taken at point k of the workgroup's path instead
+  auto stamp_at = [&](int k) { if constexpr (STAMP) { if (tid == 0 && stamp_point == k) my_stamp[1] = (unsigned long long)wall_clock64(); } };
   // A clip that has reached its eot keeps its slot in the batch but streams no K/V any more (the reference stops each
   // utterance at its own eot, Whisper.cpp:219-222). Its stale attention output feeds linear layers whose results
   // nobody reads: rows of different clips never mix, and advance_kernel re-seeds x[b] from the embedding every step.
+  // (measured, round 5: the flag requested here but looked at behind the first K/V / activation / weight requests — one round trip
+  //  less on paper — changes a 4-, 8- or 64-clip call by +-0.3 %: not kept)
   if (p.done && p.done[b]) { stamp_end(); return; }
   const int bps = (cap_blocks + p.n_split - 1) / p.n_split;
   const int blk_begin = split * bps, blk_cap_end = min(cap_blocks, blk_begin + bps);
@@ -119,6 +127,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
     load_v(blk, p.n_keys >= 0 ? p.n_keys : 0x7fffffff);
   }
   float qv[64];
+  stamp_at(1);
   if constexpr (FUSE_Q) {
     __shared__ __attribute__((aligned(16))) float s_act[1024];
     __shared__ float s_q[64];
@@ -137,9 +146,14 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
     const int qrow = tid >> 2, qj = tid & 3;
     const h16* wr = p.wq + (long)(head * 64 + qrow) * d;
     const int nch = d >> 3;  // 16-byte chunks per row
-    u32x4 wc[8];
+    constexpr int NWC = NCHL > 0 ? NCHL : 8;
+    u32x4 wc[NWC];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { const int c = qj + 4 * i; wc[i] = c < nch ? *reinterpret_cast<const u32x4*>(wr + c * 8) : u32x4{0u, 0u, 0u, 0u}; }
+    for (int i = 0; i < NWC; ++i) {
+      const int c = qj + 4 * i;
+      if constexpr (NCHL > 0) wc[i] = *reinterpret_cast<const u32x4*>(wr + c * 8);
+      else wc[i] = c < nch ? *reinterpret_cast<const u32x4*>(wr + c * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
     const float bq = p.bq[head * 64 + qrow];
     float s1 = (xv[0] + xv[1]) + (xv[2] + xv[3]);
     s1 = wave_sum(s1);
@@ -156,8 +170,26 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const int c = tid + 256 * e; if (c < d) s_act[c] = (xv[e] - mean) * rstd * gg[e] + bb[e]; }
     __syncthreads();
+    stamp_at(2);
     float a0 = 0.f, a1 = 0.f;
-    for (int c0 = 0; c0 < nch; c0 += 32) {  // 8 chunks of this lane per pass
+    if constexpr (NCHL > 0) {
+      float b0 = 0.f, b1 = 0.f;  // four independent chains
+#pragma unroll
+      for (int i = 0; i < NCHL; ++i) {
+        const int c = qj + 4 * i;
+        const float4 y0 = *reinterpret_cast<const float4*>(s_act + c * 8), y1 = *reinterpret_cast<const float4*>(s_act + c * 8 + 4);
+        a0 = fmaf(h16lo(wc[i][0]), y0.x, a0);
+        a1 = fmaf(h16hi(wc[i][0]), y0.y, a1);
+        b0 = fmaf(h16lo(wc[i][1]), y0.z, b0);
+        b1 = fmaf(h16hi(wc[i][1]), y0.w, b1);
+        a0 = fmaf(h16lo(wc[i][2]), y1.x, a0);
+        a1 = fmaf(h16hi(wc[i][2]), y1.y, a1);
+        b0 = fmaf(h16lo(wc[i][3]), y1.z, b0);
+        b1 = fmaf(h16hi(wc[i][3]), y1.w, b1);
+      }
+      a0 += b0; a1 += b1;
+    }
+    for (int c0 = 0; c0 < nch && NCHL == 0; c0 += 32) {  // 8 chunks of this lane per pass
       u32x4 cur[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) cur[i] = wc[i];
@@ -191,6 +223,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
     for (int c = 0; c < 64; ++c) qv[c] = qp[c];
   }
 
+  stamp_at(3);
   const int n_keys = p.n_keys >= 0 ? p.n_keys : p.off[b] + 1;  // self-attention: this clip's own position
   const int blk_end = min((n_keys + 63) >> 6, blk_cap_end);
 
@@ -242,6 +275,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
     if (prefetch) load_v(cur + 4, n_keys);
   };
   for (; blk < blk_end; blk += 4) one_block(blk, blk + 4 < blk_end);
+  stamp_at(4);
   // wave partial: sum o over the 8 key sub-rows (lanes with equal lane&7), sum l over the wave
   const float l_w = wave_sum(l_lane);
 #pragma unroll
@@ -273,6 +307,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
         ov += f * s_part[w][2 + tid];
       }
     }
+    stamp_at(5);
     if (p.out_hi && p.n_split > 1) {
       // Splits of one (clip, head) in the batched path at FEW clips (3 clips x 12 heads are 36 workgroups for 256 CUs,
       // each streaming its 24 key blocks one after the other). Every split publishes (m, l, o[64]) with write-through
@@ -286,6 +321,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
         __hip_atomic_store(mine + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp_at(6);
       // The hand-off is the first row of MI355X_MICROARCH.md's table of hand-offs that need no acquire: every payload
       // store is sc1 (write-through), the storing wave drains vmcnt, ONE lane adds to an agent-scope counter, and the
       // workgroup whose add came last — told by the value its add returned — reads the others' records with sc1 loads
@@ -299,22 +335,34 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
       }
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
       ticket = __builtin_amdgcn_readfirstlane(ticket);
+      stamp_at(7);
       if (ticket != (unsigned)p.n_split - 1u) { stamp_end(); return; }  // (the whole wave; the other waves are past their last use of LDS)
-      float M = -INFINITY, Ls = 0.f, O = 0.f;
-      for (int s2 = 0; s2 < p.n_split; ++s2) {
-        float m2 = m, l2 = l, o2 = ov;
-        if (s2 != split) {
+      // every other split's record is requested before the first one is used: ONE memory round trip for the fold, not one per
+      // split (five dependent sc1 round trips at six splits were a quarter of this launch at four clips)
+      float ms[kAttnSplitMax], ls[kAttnSplitMax], os[kAttnSplitMax];
+#pragma unroll
+      for (int s2 = 0; s2 < kAttnSplitMax; ++s2) {
+        ms[s2] = m; ls[s2] = l; os[s2] = ov;
+        if (s2 < p.n_split && s2 != split) {
           const float* other = base + s2 * kPartStride;
-          m2 = __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          l2 = __hip_atomic_load(other + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          o2 = __hip_atomic_load(other + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ms[s2] = __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ls[s2] = __hip_atomic_load(other + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          os[s2] = __hip_atomic_load(other + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const float mn = fmaxf(M, m2);
-        const float f1 = M > -INFINITY ? __expf(M - mn) : 0.f, f2 = m2 > -INFINITY ? __expf(m2 - mn) : 0.f;
-        Ls = f1 * Ls + f2 * l2;
-        O = f1 * O + f2 * o2;
-        M = mn;
       }
+      float M = -INFINITY, Ls = 0.f, O = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < kAttnSplitMax; ++s2) {
+        if (s2 < p.n_split) {
+          const float m2 = ms[s2], l2 = ls[s2], o2 = os[s2];
+          const float mn = fmaxf(M, m2);
+          const float f1 = M > -INFINITY ? __expf(M - mn) : 0.f, f2 = m2 > -INFINITY ? __expf(m2 - mn) : 0.f;
+          Ls = f1 * Ls + f2 * l2;
+          O = f1 * O + f2 * o2;
+          M = mn;
+        }
+      }
+      stamp_at(8);
       if (tid == 0) __hip_atomic_store(p.mcnt + b * p.n_head + head, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
       const float y = O / Ls;
       const h16 yh = (h16)y;
@@ -339,13 +387,23 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
 }
 
 void launch_decode_attention(const DecAttnParams& p, hipStream_t s) {
+  static const int stamp_point = [] { const char* e = getenv("AX_WHISPER_ATTN_STAMP_POINT"); return e ? atoi(e) : 0; }();
   if (p.wq) {
-    if (p.d_model > 1024 || p.d_model % 32 != 0 || (p.n_split != 1 && !(p.out_hi && p.mpart && p.mcnt))) { fprintf(stderr, "[ax_whisper] fused query projection: d_model %d, n_split %d unsupported\n", p.d_model, p.n_split); abort(); }
-    if (p.stamp) hipLaunchKernelGGL((decode_attention_kernel<true, true>), dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);
-    else hipLaunchKernelGGL((decode_attention_kernel<true>), dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);
+    if (p.d_model > 1024 || p.d_model % 32 != 0 || p.n_split > kAttnSplitMax || (p.n_split != 1 && !(p.out_hi && p.mpart && p.mcnt))) { fprintf(stderr, "[ax_whisper] fused query projection: d_model %d, n_split %d unsupported\n", p.d_model, p.n_split); abort(); }
+    static const bool qall = [] { const char* e = getenv("AX_WHISPER_ATTN_QALL"); return !(e && e[0] == '0'); }();  // A/B
+    const dim3 grid(p.n_split, p.n_head, p.batch);
+    const bool few = p.n_split > 1 && qall;  // the latency-bound regime (few clips): the projection's weights all up front
+    if (p.stamp) {
+      if (few && p.d_model == 768) hipLaunchKernelGGL((decode_attention_kernel<true, true, 24>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+      else hipLaunchKernelGGL((decode_attention_kernel<true, true>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+    } else if (few && p.d_model == 384) hipLaunchKernelGGL((decode_attention_kernel<true, false, 12>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+    else if (few && p.d_model == 512) hipLaunchKernelGGL((decode_attention_kernel<true, false, 16>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+    else if (few && p.d_model == 768) hipLaunchKernelGGL((decode_attention_kernel<true, false, 24>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+    else if (few && p.d_model == 1024) hipLaunchKernelGGL((decode_attention_kernel<true, false, 32>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+    else hipLaunchKernelGGL((decode_attention_kernel<true>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
   } else {
-    if (p.stamp) hipLaunchKernelGGL((decode_attention_kernel<false, true>), dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);
-    else hipLaunchKernelGGL((decode_attention_kernel<false>), dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks);
+    if (p.stamp) hipLaunchKernelGGL((decode_attention_kernel<false, true>), dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+    else hipLaunchKernelGGL((decode_attention_kernel<false>), dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks, stamp_point);
   }
 }
 

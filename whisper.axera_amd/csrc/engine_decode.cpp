@@ -152,11 +152,15 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
   // = one per wave each): at few clips one workgroup per (clip, head) leaves most CUs idle behind 24 sequential blocks
   // (3 clips: attention 0.245 -> 0.209 ms per step with 6 splits); from ~24 clips on there are enough (clip, head)
   // pairs and splitting only repeats the query projection (64 clips: 525 -> 588 ms with 2 splits).
+  // At most ONE workgroup per CU (round 5; the bound was 320): the launch's last workgroup starts ~13 ns per workgroup after its
+  // first, and every split repeats the query projection — decode ms per call at Whisper-small dims by splits
+  // (profiles/r05_cross_split_sweep.txt): 4 clips 6: 249, 4: 241, 3: 241, 2: 246 | 6 clips 4: 259, 3: 250, 2: 251 |
+  // 8 clips 6: 289, 4: 263, 3: 262, 2: 261 | 10 clips 2: 264.5, 1: 267 | 12 clips 2: 283, 1: 272.
   int cross_split = 1;
   {
     const int blocks = t_pad_ / 64;
     for (int c : {6, 4, 3, 2})
-      if (c <= kCrossSplitMax && blocks % c == 0 && nb * H * c <= 320) { cross_split = c; break; }
+      if (c <= kCrossSplitMax && blocks % c == 0 && nb * H * c <= std::max(n_cu_, 64)) { cross_split = c; break; }
     if (cross_split_env_ > 0 && cross_split_env_ <= kCrossSplitMax && blocks % cross_split_env_ == 0) cross_split = cross_split_env_;
   }
   auto cgo = [&](const DecCGemmParams& c) { if (step_mask_ & 1) launch_decode_cgemm(c, s); };
@@ -171,6 +175,7 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
   };
   const int n_blk = (nb + 15) / 16;
   // two row tiles per workgroup where one would make more workgroups than can be resident at once
+  // (fewer, fatter workgroups at few clips — two row tiles from 100 or from 40 workgroups on — measured 2 % slower at 4 and 8 clips)
   auto rt_for = [&](int N) { return (N / 16) * n_blk > 512 ? 2 : 1; };
 
   for (int l = 0; l < L; ++l) {
