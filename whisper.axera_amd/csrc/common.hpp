@@ -372,6 +372,9 @@ struct DecCGemmParams {
   h16* k_cache; h16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;
   const DecState* state;
   const int* off;                          // per-clip offsets [batch]
+  // measurement only (Engine::bench "attn_stamp"): [workgroups][2] = {begin, time at stamp_point} of every workgroup, 100 MHz ticks;
+  // a separate template instantiation (the production kernel carries no stamp code)
+  unsigned long long* stamp; int stamp_point;
 };
 void launch_decode_cgemm(const DecCGemmParams& p, hipStream_t s);
 int decode_gemm_grid(int N, int rt);

@@ -287,12 +287,21 @@ __device__ __forceinline__ float sum_lanes_16_32(float v) {
 // grid = (weight-row blocks of 16*RT, clip blocks of 16); 8 waves split K (k-steps w, w+8, ...), reduce through LDS;
 // at most one output per thread (RT <= 2), so the bias and the residual value are requested before anything else.
 // CH > 0: LayerNorm prologue, CH = k-steps per wave held in registers (K = 256*CH at most); CH == 0: h16-pair input.
-template <int RT, int CH>
+// STAMP (measurement builds only, Engine::bench "attn_stamp"): thread 0 of every workgroup records its start and the time it reaches
+// point p.stamp_point: 1 every request of the prologue is out | 2 LayerNorm statistics done (CH > 0) | 3 MFMAs issued | 4 the eight
+// waves' partial sums are in LDS (behind the barrier) | 0 end
+template <int RT, int CH, bool STAMP = false>
 __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
   __shared__ __attribute__((aligned(16))) float red[8 * RT * 256];  // [wave][t][clip][row]
   __shared__ float stat[2][8][16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: k-step selection is wave-uniform control flow
+  unsigned long long* my_stamp = nullptr;
+  if constexpr (STAMP) {
+    my_stamp = p.stamp + 2 * (blockIdx.y * gridDim.x + blockIdx.x);
+    if (tid == 0) my_stamp[0] = (unsigned long long)wall_clock64();
+  }
+  auto stamp_at = [&](int k) { if constexpr (STAMP) { if (tid == 0 && p.stamp_point == k) my_stamp[1] = (unsigned long long)wall_clock64(); } };
   const int r = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * (16 * RT), cb = blockIdx.y;
   const int KS = p.K / 32;
@@ -338,6 +347,7 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
         bb[c][u] = *reinterpret_cast<const f32x4*>(p.ln_b + k0 + 4 * u);
       }
     }
+    stamp_at(1);
     // two-pass statistics per clip: lanes (r, 0..3) of 8 waves hold one row between them
     float s1 = 0.f;
 #pragma unroll
@@ -369,6 +379,7 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
 #pragma unroll
     for (int w2 = 0; w2 < 8; ++w2) var += stat[1][w2][r];
     const float rstd = rsqrtf(var / (float)p.K + 1e-5f);
+    stamp_at(2);
 #pragma unroll
     for (int c = 0; c < CH; ++c)
       if (wave + 8 * c < KS) {
@@ -389,15 +400,24 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
         }
       }
   } else {
-    const h16* ahi = p.a_hi + (long)cb * 512 + lane * 8;
-    const h16* alo = p.a_lo + (long)cb * 512 + lane * 8;
+    // Activation fragments as buffer loads: lane (r, q) holds clip cb*16 + r, and the lanes of a clip the batch does not have get
+    // an out-of-range offset — their loads return zeros and move NO bytes. A clip block is 2 x 1 KB per k-step whatever it
+    // holds: at 4 clips mlp.2 (K = 3072) pulled 196 KB of activations per workgroup through its CU for 49 KB of content, and
+    // was the slowest GEMM launch of the few-clip step (6.0 us; profiles/r05_step_timeline_b4.txt).
     const long a_step = (long)p.nbs * 512;
+    const unsigned a_bytes = (unsigned)((long)KS * a_step * 2 - (long)cb * 1024);
+    const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a_hi + (long)cb * 512), 0, (int)a_bytes, 0x27000);
+    const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a_lo + (long)cb * 512), 0, (int)a_bytes, 0x27000);
+    const int a_off = cb * 16 + r < p.batch ? lane * 16 : 0x7ffffff0;
     struct Frag { h16x8 w[RT], h, l; };
     auto load = [&](Frag& f, int ks) {
 #pragma unroll
       for (int t = 0; t < RT; ++t) f.w[t] = *reinterpret_cast<const h16x8*>(wrow[t] + (long)ks * 512);
-      f.h = *reinterpret_cast<const h16x8*>(ahi + ks * a_step);
-      f.l = *reinterpret_cast<const h16x8*>(alo + ks * a_step);
+      const int so = (int)(ks * a_step * 2);  // wave-uniform: the scalar offset of the k-step
+      const u32x4 uh = __builtin_amdgcn_raw_buffer_load_b128(rs_hi, a_off, so, 0);
+      const u32x4 ul = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, a_off, so, 0);
+      f.h = __builtin_bit_cast(h16x8, uh);
+      f.l = __builtin_bit_cast(h16x8, ul);
     };
     auto mma = [&](const Frag& f) {
 #pragma unroll
@@ -406,13 +426,15 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
         acc[t] = AXW_MFMA_16x16x32(f.w[t], f.l, acc[t]);
       }
     };
-    // eight k-steps in flight per wave (96 VGPRs at RT = 1): K = 5120 is 20 k-steps per wave, i.e. 3 dependent round
-    // trips instead of 5 with four
-    constexpr int DEPTH = 8;
+    // twelve k-steps in flight per wave (144 VGPRs at RT = 1): K = 3072 (mlp.2 of d_model 768) is 12 k-steps per wave — ONE memory
+    // round trip instead of two with eight (the launch's last wave reached its MFMAs 2.5 us after its requests went out, the
+    // reduction barrier another 1.3 us later: profiles/r05_step_timeline_b4.txt) — and K = 5120 is 20, i.e. two instead of three
+    constexpr int DEPTH = 12;
     Frag f[DEPTH];
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i)
       if (wave + 8 * i < KS) load(f[i], wave + 8 * i);
+    stamp_at(1);
     for (int ks = wave; ks < KS; ks += 8 * DEPTH) {
 #pragma unroll
       for (int i = 0; i < DEPTH; ++i)
@@ -424,10 +446,12 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
   }
 
   // split-K reduction across the 8 waves: red[wave][t][clip r][row 4q + e]
+  stamp_at(3);
 #pragma unroll
   for (int t = 0; t < RT; ++t) *reinterpret_cast<f32x4*>(red + ((wave * RT + t) * 16 + r) * 16 + 4 * q) = acc[t];
   __syncthreads();
-  if (!has_out) return;
+  stamp_at(4);
+  if (!has_out) { stamp_at(0); return; }
   const int nl = tid % (16 * RT), bl = tid / (16 * RT);
   const int t = nl >> 4, nn = nl & 15;
   float y = bias_t;
@@ -452,12 +476,19 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
       break;
     }
   }
+  stamp_at(0);
 }
 
 template <int RT>
 static void launch_cg(const DecCGemmParams& p, hipStream_t s) {
   const dim3 grid((p.N + 16 * RT - 1) / (16 * RT), (p.batch + 15) / 16);
   const int ch = p.ln_w ? (p.K / 32 + 7) / 8 : 0;
+  if (p.stamp) {  // measurement builds: the shapes of d_model 768
+    if (ch == 0) hipLaunchKernelGGL((decode_cgemm_kernel<RT, 0, true>), grid, dim3(512), 0, s, p);
+    else if (ch == 3) hipLaunchKernelGGL((decode_cgemm_kernel<RT, 3, true>), grid, dim3(512), 0, s, p);
+    else { fprintf(stderr, "[ax_whisper] launch_decode_cgemm: no stamp build for K=%d\n", p.K); abort(); }
+    return;
+  }
   switch (ch) {
     case 0: hipLaunchKernelGGL((decode_cgemm_kernel<RT, 0>), grid, dim3(512), 0, s, p); break;
     case 1: case 2: hipLaunchKernelGGL((decode_cgemm_kernel<RT, 2>), grid, dim3(512), 0, s, p); break;

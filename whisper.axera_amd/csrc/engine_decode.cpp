@@ -163,7 +163,13 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
       if (c <= kCrossSplitMax && blocks % c == 0 && nb * H * c <= std::max(n_cu_, 64)) { cross_split = c; break; }
     if (cross_split_env_ > 0 && cross_split_env_ <= kCrossSplitMax && blocks % cross_split_env_ == 0) cross_split = cross_split_env_;
   }
-  auto cgo = [&](const DecCGemmParams& c) { if (step_mask_ & 1) launch_decode_cgemm(c, s); };
+  static const int gemm_stamp_point = [] { const char* e = getenv("AX_WHISPER_GEMM_STAMP_POINT"); return e ? atoi(e) : 0; }();
+  int cur_layer = 0;
+  // kind: 2 qkv, 3 o, 4 co, 5 fc1, 6 fc2 (0 / 1 are the attention launches) — bench "attn_stamp" puts every launch of the step on one axis
+  auto cgo = [&](DecCGemmParams c, int kind) {
+    if (step_mask_ & 16) { c.stamp = next_stamp(cur_layer, kind, b0, nb); c.stamp_point = gemm_stamp_point; }
+    if (step_mask_ & 1) launch_decode_cgemm(c, s);
+  };
   auto attn = [&](const h16* kc, const h16* vc, long stride, int n_keys, int cap_blocks) {
     DecAttnParams a{};
     a.q = qd; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = nullptr; a.n_split = 1;
@@ -179,6 +185,7 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
   auto rt_for = [&](int N) { return (N / 16) * n_blk > 512 ? 2 : 1; };
 
   for (int l = 0; l < L; ++l) {
+    cur_layer = l;
     const DecLayerW& w = dec_[l];
     const DecLayerWP& wq = dec_packed_[l];
     h16* sk = d_self_k_ + ((size_t)l * cap_ + b0) * self_stride;
@@ -188,11 +195,11 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
     DecCGemmParams c = cgemm(wq.w_qkv, w.b_qkv, 3 * d, d, GEPI_QKV_CACHE, rt_for(3 * d));
     c.x = x; c.ln_w = w.attn_ln_w; c.ln_b = w.attn_ln_b;
     c.out = qd; c.k_cache = sk; c.v_cache = sv; c.kv_batch_stride = self_stride;
-    cgo(c);
+    cgo(c, 2);
     if (step_mask_ & 2) { DecAttnParams a = attn(sk, sv, self_stride, -1, Tc / 64); a.stamp = next_stamp(l, 0, b0, nb); launch_decode_attention(a, s); }
     c = cgemm(wq.w_o, w.b_o, d, d, GEPI_RESID, 1);
     c.a_hi = att_hi; c.a_lo = att_lo; c.out = x;
-    cgo(c);
+    cgo(c, 3);
     if (fuse_cq && d <= 1024) {  // the cross-attention workgroups project their own queries (decode_attention_kernel<true>)
       DecAttnParams a = attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64);
       a.q = nullptr;
@@ -205,18 +212,18 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
     } else {
       c = cgemm(wq.w_cq, w.b_cq, d, d, GEPI_STORE, 1);
       c.x = x; c.ln_w = w.cross_ln_w; c.ln_b = w.cross_ln_b; c.out = qd;
-      cgo(c);
+      cgo(c, 7);
       if (step_mask_ & 2) { DecAttnParams a = attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64); a.stamp = next_stamp(l, 1, b0, nb); launch_decode_attention(a, s); }
     }
     c = cgemm(wq.w_co, w.b_co, d, d, GEPI_RESID, 1);
     c.a_hi = att_hi; c.a_lo = att_lo; c.out = x;
-    cgo(c);
+    cgo(c, 4);
     c = cgemm(wq.w_fc1, w.b_fc1, 4 * d, d, GEPI_GELU, rt_for(4 * d));
     c.x = x; c.ln_w = w.mlp_ln_w; c.ln_b = w.mlp_ln_b; c.out_hi = hid_hi; c.out_lo = hid_lo;
-    cgo(c);
+    cgo(c, 5);
     c = cgemm(wq.w_fc2, w.b_fc2, d, 4 * d, GEPI_RESID, 1);
     c.a_hi = hid_hi; c.a_lo = hid_lo; c.out = x;
-    cgo(c);
+    cgo(c, 6);
   }
 }
 

@@ -391,9 +391,11 @@ float Engine::bench(const std::string& what, int batch, int arg, int iters) {
     for (size_t i = 0; i < stamp_meta_.size(); ++i) {
       const StampMeta& m = stamp_meta_[i];
       const double bg = (double)(got[2 * i] - t0) * 0.01, en = (double)(got[2 * i + 1] - t0) * 0.01;
-      const double bytes = (double)m.nb * 2.0 * 2.0 * d_ * (m.cross ? (double)cfg_.n_audio_ctx : keys_self);
-      iv.push_back({bg, en});
-      snprintf(line, sizeof line, "%zu,%s,%d,%d,%d,%.2f,%.2f,%.2f,%.0f,%.1f\n", i, m.cross ? "cross" : "self", m.layer, m.b0, m.nb, bg, en, en - bg, bytes,
+      static const char* const kinds[] = {"self", "cross", "qkv", "o", "co", "fc1", "fc2", "cq"};
+      const bool is_attn = m.cross <= 1;
+      const double bytes = is_attn ? (double)m.nb * 2.0 * 2.0 * d_ * (m.cross ? (double)cfg_.n_audio_ctx : keys_self) : 0.0;
+      if (is_attn) iv.push_back({bg, en});
+      snprintf(line, sizeof line, "%zu,%s,%d,%d,%d,%.2f,%.2f,%.2f,%.0f,%.1f\n", i, kinds[m.cross & 7], m.layer, m.b0, m.nb, bg, en, en - bg, bytes,
                en > bg ? bytes / ((en - bg) * 1e-6) / 1e9 : 0.0);
       table += line;
     }
