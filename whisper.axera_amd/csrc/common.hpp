@@ -321,7 +321,7 @@ struct DecAttnParams {
   int cap_blocks;             // allocated 64-key blocks per (slot, head): 24 cross, 7 self
   const DecState* state;
   const int* off;             // per-clip offsets [B]
-  const int* done;            // optional device [B]: clips whose flag is set are skipped (greedy loop past their eot)
+  const int* done;            // device [B], never null: clips whose flag is set are skipped (greedy loop past their eot); all zero where nobody stops
   h16* out_hi; h16* out_lo; int nbs; // normalised output as a fragment-major h16 pair instead of partials; with n_split > 1
                                      // the splits of a (clip, head) meet through mpart / mcnt and the last one to arrive writes it
   float* mpart; unsigned* mcnt;      // [B][H][n_split][66] / [B][H] (zero between launches), same clip origin as q / out

@@ -90,9 +90,10 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
   // A clip that has reached its eot keeps its slot in the batch but streams no K/V any more (the reference stops each
   // utterance at its own eot, Whisper.cpp:219-222). Its stale attention output feeds linear layers whose results
   // nobody reads: rows of different clips never mix, and advance_kernel re-seeds x[b] from the embedding every step.
-  // (measured, round 5: the flag requested here but looked at behind the first K/V / activation / weight requests — one round trip
-  //  less on paper — changes a 4-, 8- or 64-clip call by +-0.3 %: not kept)
-  if (p.done && p.done[b]) { stamp_end(); return; }
+  // The flag is REQUESTED here (an unconditional scalar load: the pointer is never null) and looked at behind the first K/V — and, with
+  // FUSE_Q, activation and weight — requests: a launch of the few-clip step is one dependent chain, and a finished clip's extra
+  // requests are one block of its own, allocated, K/V.
+  const int clip_done = p.done[b];
   const int bps = (cap_blocks + p.n_split - 1) / p.n_split;
   const int blk_begin = split * bps, blk_cap_end = min(cap_blocks, blk_begin + bps);
 
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
       else wc[i] = c < nch ? *reinterpret_cast<const u32x4*>(wr + c * 8) : u32x4{0u, 0u, 0u, 0u};
     }
     const float bq = p.bq[head * 64 + qrow];
+    if (clip_done) { stamp_end(); return; }  // (workgroup-uniform, in front of the first barrier)
     float s1 = (xv[0] + xv[1]) + (xv[2] + xv[3]);
     s1 = wave_sum(s1);
     if (lane == 0) s_red[wave] = s1;
@@ -225,6 +227,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
 
   stamp_at(3);
   const int n_keys = p.n_keys >= 0 ? p.n_keys : p.off[b] + 1;  // self-attention: this clip's own position
+  if (!FUSE_Q && clip_done) { stamp_end(); return; }  // (behind the query and position requests: one round trip for all three)
   const int blk_end = min((n_keys + 63) >> 6, blk_cap_end);
 
   float m_w = -INFINITY, l_lane = 0.f;

@@ -569,6 +569,7 @@ void Engine::ensure_capacity(int batch) {
   d_amax_idx_ = (int*)A((size_t)n_amax_part_ * B * 4, true);
   d_tok_ = (int*)A((size_t)B * 4, true);
   d_done_ = (int*)A((size_t)B * 4, true);
+  d_done_none_ = (int*)A((size_t)B * 4, true);  // all zero, never written: the "nobody has finished" flags of teacher-forced decodes
   d_off_ = (int*)A((size_t)B * 4, true);
   d_slot_map_ = (int*)A((size_t)B * 4, true);
   if (h_done_live_) { (void)hipHostFree(h_done_live_); h_done_live_ = nullptr; }

@@ -144,7 +144,7 @@ class Engine final : public IEngine {
   float* d_amax_val_ = nullptr; int* d_amax_idx_ = nullptr; int n_amax_part_ = 0;
   float* d_attn_mpart_ = nullptr;     // batched cross-attention in splits: partials and tickets (DecAttnParams::mpart / mcnt)
   unsigned* d_attn_mcnt_ = nullptr;
-  int *d_tok_ = nullptr, *d_done_ = nullptr, *d_nout_ = nullptr, *d_out_ids_ = nullptr, *d_max_new_clip_ = nullptr;
+  int *d_tok_ = nullptr, *d_done_ = nullptr, *d_done_none_ = nullptr, *d_nout_ = nullptr, *d_out_ids_ = nullptr, *d_max_new_clip_ = nullptr;
   int* d_off_ = nullptr;   // per-slot offsets (common.hpp: DecState)
   int n_cu_ = 0;            // compute units of the device
   // slot refill (stream_*): a slot is idle -> encoding (admitted, encoder in flight on admit_stream_) -> active (decoding)
@@ -176,7 +176,7 @@ class Engine final : public IEngine {
   int step_mask_ = 15;  // bench only: 1 GEMV/GEMM launches, 2 attention launches, 4 advance, 8 act_prep, 16 attention launches stamp themselves
   // bench "attn_stamp": every decode_attention launch of a captured step gets a {min begin, max end} slot (DecAttnParams::stamp)
   struct StampMeta { int layer, cross, b0, nb; };
-  static constexpr size_t kStampWgs = 4096, kStampLaunches = 128;
+  static constexpr size_t kStampWgs = 4096, kStampLaunches = 256;
   unsigned long long* d_stamp_ = nullptr;
   std::vector<StampMeta> stamp_meta_;
   unsigned long long* next_stamp(int layer, int cross, int b0, int nb);

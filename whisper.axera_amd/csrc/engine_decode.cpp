@@ -52,7 +52,7 @@ void Engine::enqueue_decode_step(int batch, int max_new, const int* d_forced, in
     a.q = d_qdec_; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = part; a.n_split = n_split;
     a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
     a.off = d_off_;
-    a.done = d_forced ? nullptr : d_done_;
+    a.done = d_forced ? d_done_none_ : d_done_;
     if (step_mask_ & 2) launch_decode_attention(a, s);
   };
 
@@ -140,7 +140,7 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
   float* x = d_xdec_ + (long)b0 * d;
   float* qd = d_qdec_ + (long)b0 * d;
   h16 *att_hi = d_att_[0] + frag0, *att_lo = d_att_[1] + frag0, *hid_hi = d_hidp_[0] + frag0, *hid_lo = d_hidp_[1] + frag0;
-  const int* done = forced ? nullptr : d_done_ + b0;
+  const int* done = (forced ? d_done_none_ : d_done_) + b0;  // (never null: the attention launches read the flag unconditionally)
   auto cgemm = [&](const h16* W, const float* bias, int N, int K, int epi, int rt) {
     DecCGemmParams c{};
     c.W = W; c.bias = bias; c.N = N; c.K = K; c.batch = nb; c.nbs = nbs_; c.epilogue = epi; c.rt = rt;
@@ -302,7 +302,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     a.q = d_qdec_; a.k = kc; a.v = vc; a.kv_batch_stride = stride; a.part = nullptr; a.n_split = 1;
     a.batch = batch; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
     a.off = d_off_;
-    a.done = d_forced ? nullptr : d_done_;
+    a.done = d_forced ? d_done_none_ : d_done_;
     a.out_hi = d_att_[0]; a.out_lo = d_att_[1]; a.nbs = nbs_;
     if (n_keys >= 0) {  // cross-attention: few (clip, head) pairs leave CUs with one workgroup beside CUs with two (turbo, 16 clips: 320)
       int c = 1;
