@@ -322,6 +322,7 @@ struct DecAttnParams {
   const DecState* state;
   const int* off;             // per-clip offsets [B]
   const int* done;            // device [B], never null: clips whose flag is set are skipped (greedy loop past their eot); all zero where nobody stops
+  int done_late;              // few clips (a launch is one dependent chain): the flag is looked at BEHIND the first requests, not before them
   h16* out_hi; h16* out_lo; int nbs; // normalised output as a fragment-major h16 pair instead of partials; with n_split > 1
                                      // the splits of a (clip, head) meet through mpart / mcnt and the last one to arrive writes it
   float* mpart; unsigned* mcnt;      // [B][H][n_split][66] / [B][H] (zero between launches), same clip origin as q / out

@@ -426,10 +426,10 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
         acc[t] = AXW_MFMA_16x16x32(f.w[t], f.l, acc[t]);
       }
     };
-    // twelve k-steps in flight per wave (144 VGPRs at RT = 1): K = 3072 (mlp.2 of d_model 768) is 12 k-steps per wave — ONE memory
-    // round trip instead of two with eight (the launch's last wave reached its MFMAs 2.5 us after its requests went out, the
-    // reduction barrier another 1.3 us later: profiles/r05_step_timeline_b4.txt) — and K = 5120 is 20, i.e. two instead of three
-    constexpr int DEPTH = 12;
+    // eight k-steps in flight per wave (96 VGPRs at RT = 1): K = 5120 is 20 k-steps per wave, i.e. 3 dependent round
+    // trips instead of 5 with four. (Twelve — all of mlp.2's K = 3072 in one round trip — measured the same at 4 clips, 6.04 us per
+    // launch: bytes through the CU, not round trips; and 160 VGPRs leave one workgroup per CU where 114 leave two: 256 clips -2.7 %.)
+    constexpr int DEPTH = 8;
     Frag f[DEPTH];
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i)

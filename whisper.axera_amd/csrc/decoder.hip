@@ -93,7 +93,10 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
   // The flag is REQUESTED here (an unconditional scalar load: the pointer is never null) and looked at behind the first K/V — and, with
   // FUSE_Q, activation and weight — requests: a launch of the few-clip step is one dependent chain, and a finished clip's extra
   // requests are one block of its own, allocated, K/V.
+  // At batch (done_late == 0) it is looked at first: a finished clip of a ragged batch then costs nothing at all (64 clips with
+  // budgets of 60-150 ids: 334 clips/s, against 323 with the late check everywhere).
   const int clip_done = p.done[b];
+  if (!p.done_late && clip_done) { stamp_end(); return; }
   const int bps = (cap_blocks + p.n_split - 1) / p.n_split;
   const int blk_begin = split * bps, blk_cap_end = min(cap_blocks, blk_begin + bps);
 

@@ -176,6 +176,7 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
     a.batch = nb; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
     a.off = d_off_ + b0;
     a.done = done;
+    a.done_late = nb <= 21 ? 1 : 0;  // one branch: the step is a chain of dependent launches (decoder.hip)
     a.out_hi = att_hi; a.out_lo = att_lo; a.nbs = nbs_;
     return a;
   };
