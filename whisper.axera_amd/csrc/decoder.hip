@@ -68,7 +68,7 @@ __device__ __forceinline__ uint4 ld_kv(const h16* base, long off) {
 
 // STAMP (measurement builds of the kernel only): thread 0 of every workgroup records its start and end time, so that a decoder step's attention launches can be placed on one time axis while two graph
 // branches run them side by side (a profiler serialises the branches; hipEvents see only whole replays).
-// NCHL > 0 (FUSE_Q at few clips, where the launch is one dependent chain and registers are free): d_model = 32 * NCHL, the lane's
+// NCHL > 0 (FUSE_Q at d_model 384 / 512 / 768 / 1024): d_model = 32 * NCHL, the lane's
 // NCHL weight chunks of the query projection are ALL requested up front, unconditionally — one memory round trip and straight-line
 // code instead of one round trip per 8 chunks behind per-chunk bounds checks (which hipcc turns into a branch per load).
 template <bool FUSE_Q, bool STAMP = false, int NCHL = 0>
@@ -398,7 +398,9 @@ void launch_decode_attention(const DecAttnParams& p, hipStream_t s) {
     if (p.d_model > 1024 || p.d_model % 32 != 0 || p.n_split > kAttnSplitMax || (p.n_split != 1 && !(p.out_hi && p.mpart && p.mcnt))) { fprintf(stderr, "[ax_whisper] fused query projection: d_model %d, n_split %d unsupported\n", p.d_model, p.n_split); abort(); }
     static const bool qall = [] { const char* e = getenv("AX_WHISPER_ATTN_QALL"); return !(e && e[0] == '0'); }();  // A/B
     const dim3 grid(p.n_split, p.n_head, p.batch);
-    const bool few = p.n_split > 1 && qall;  // the latency-bound regime (few clips): the projection's weights all up front
+    // the projection's weight chunks all up front, at every clip count: 14 more registers leave the same two workgroups per CU, and
+    // the launch is shorter at few clips (4 clips 11.3 -> 10.5 us) and at batch (64 clips: decode 510.8 -> 500.1 ms per call, 16: -1.5 %)
+    const bool few = qall;
     if (p.stamp) {
       if (few && p.d_model == 768) hipLaunchKernelGGL((decode_attention_kernel<true, true, 24>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
       else hipLaunchKernelGGL((decode_attention_kernel<true, true>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
