@@ -152,8 +152,8 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
   // = one per wave each): at few clips one workgroup per (clip, head) leaves most CUs idle behind 24 sequential blocks
   // (3 clips: attention 0.245 -> 0.209 ms per step with 6 splits); from ~24 clips on there are enough (clip, head)
   // pairs and splitting only repeats the query projection (64 clips: 525 -> 588 ms with 2 splits).
-  // At most ONE workgroup per CU (round 5; the bound was 320): the launch's last workgroup starts ~13 ns per workgroup after its
-  // first, and every split repeats the query projection — decode ms per call at Whisper-small dims by splits
+  // At most ONE workgroup per CU (round 5; the bound was 320): every split repeats the LayerNorm and the query projection and adds a
+  // record to the fold, and a second workgroup on a CU shares its memory path — decode ms per call at Whisper-small dims by splits
   // (profiles/r05_cross_split_sweep.txt): 4 clips 6: 249, 4: 241, 3: 241, 2: 246 | 6 clips 4: 259, 3: 250, 2: 251 |
   // 8 clips 6: 289, 4: 263, 3: 262, 2: 261 | 10 clips 2: 264.5, 1: 267 | 12 clips 2: 283, 1: 272.
   int cross_split = 1;
