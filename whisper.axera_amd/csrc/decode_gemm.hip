@@ -336,16 +336,24 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
     }
     // lane (r, q) holds x[clip r][k = ks*32 + 8q .. +8] of every k-step of this wave: exactly its MFMA B fragment
     const float* xr = p.x + (long)min(cb * 16 + r, p.batch - 1) * p.K;
-    f32x4 v[CH][2], gg[CH][2], bb[CH][2];
+    f32x4 v[CH][2];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int k0 = min(wave + 8 * c, KS - 1) * 32 + q * 8;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        v[c][u] = *reinterpret_cast<const f32x4*>(xr + k0 + 4 * u);
-        gg[c][u] = *reinterpret_cast<const f32x4*>(p.ln_w + k0 + 4 * u);
-        bb[c][u] = *reinterpret_cast<const f32x4*>(p.ln_b + k0 + 4 * u);
-      }
+      for (int u = 0; u < 2; ++u) v[c][u] = *reinterpret_cast<const f32x4*>(xr + k0 + 4 * u);
+    }
+    // The LayerNorm gain and bias go through LDS: the 16 clip lanes of a k-group need the SAME eight values, and as per-lane 16-byte
+    // global loads they were half of this prologue's vector-memory instructions (12 of 24 per wave) — the prologue is bound by how
+    // fast a CU issues them (the launch's last workgroup had its requests out after 1.3 us at 144 workgroups, 3.4 us at 288:
+    // profiles/r05_step_timeline_b4.txt). Two dword loads per thread instead, parked behind the first statistics barrier.
+    __shared__ __attribute__((aligned(16))) float s_ln[2][CH * 256];
+    float lnw_t[(CH * 256 + 511) / 512], lnb_t[(CH * 256 + 511) / 512];
+#pragma unroll
+    for (int i = 0; i < (CH * 256 + 511) / 512; ++i) {
+      const int kk = tid + 512 * i;
+      lnw_t[i] = kk < p.K ? p.ln_w[kk] : 0.f;
+      lnb_t[i] = kk < p.K ? p.ln_b[kk] : 0.f;
     }
     stamp_at(1);
     // two-pass statistics per clip: lanes (r, 0..3) of 8 waves hold one row between them
@@ -358,6 +366,11 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
       }
     s1 = sum_lanes_16_32(s1);
     if (q == 0) stat[0][wave][r] = s1;
+#pragma unroll
+    for (int i = 0; i < (CH * 256 + 511) / 512; ++i) {
+      const int kk = tid + 512 * i;
+      if (kk < CH * 256) { s_ln[0][kk] = lnw_t[i]; s_ln[1][kk] = lnb_t[i]; }
+    }
     __syncthreads();
     float mean = 0.f;
 #pragma unroll
@@ -384,15 +397,18 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
     for (int c = 0; c < CH; ++c)
       if (wave + 8 * c < KS) {
         h16x8 hi, lo;
+        const int k0 = (wave + 8 * c) * 32 + q * 8;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u) {
+          const f32x4 gg = *reinterpret_cast<const f32x4*>(s_ln[0] + k0 + 4 * u), bb = *reinterpret_cast<const f32x4*>(s_ln[1] + k0 + 4 * u);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float y = (v[c][u][e] - mean) * rstd * gg[c][u][e] + bb[c][u][e];
+            const float y = (v[c][u][e] - mean) * rstd * gg[e] + bb[e];
             h16 hh, ll;
             split_bf16(y, hh, ll);
             hi[4 * u + e] = hh; lo[4 * u + e] = ll;
           }
+        }
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
           acc[t] = AXW_MFMA_16x16x32(w[c][t], hi, acc[t]);
