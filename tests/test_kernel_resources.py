@@ -13,14 +13,31 @@ CSRC = os.path.join(ROOT, "whisper.axera_amd", "csrc")
 KERNEL_FILES = ["frontend", "gemm", "encoder_attn", "decoder", "decode_gemv", "decode_gemm", "decode_persistent", "decode_persistent2"]
 
 
-@pytest.mark.parametrize("f16", [0, 1], ids=["bf16", "fp16"])  # both builds of every kernel file (csrc/common.hpp AXW_F16)
-@pytest.mark.parametrize("name", KERNEL_FILES)
-def test_no_scratch_no_spills(name, f16, tmp_path):
-    out = tmp_path / f"{name}.s"
+def _compile(name, f16, out):
     r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
                         f"-DAXW_F16={f16}", "--cuda-device-only", "-S", "-o", str(out), os.path.join(CSRC, name + ".hip")],
                        capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
+    return r.returncode, r.stderr[-2000:]
+
+
+@pytest.fixture(scope="session")
+def assembly(tmp_path_factory):
+    """Every kernel file in both builds, compiled to assembly ONCE per session, six at a time (the 16 compilations are most of the
+    CPU suite's time one after the other)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    d = tmp_path_factory.mktemp("asm")
+    jobs = [(n, f) for n in KERNEL_FILES for f in (0, 1)]
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        res = list(ex.map(lambda j: _compile(j[0], j[1], d / f"{j[0]}.{j[1]}.s"), jobs))
+    return {j: (rc, err, d / f"{j[0]}.{j[1]}.s") for j, (rc, err) in zip(jobs, res)}
+
+
+@pytest.mark.parametrize("f16", [0, 1], ids=["bf16", "fp16"])  # both builds of every kernel file (csrc/common.hpp AXW_F16)
+@pytest.mark.parametrize("name", KERNEL_FILES)
+def test_no_scratch_no_spills(name, f16, assembly):
+    rc, err, out = assembly[(name, f16)]
+    assert rc == 0, err
     text = out.read_text()
     names = re.findall(r"^\s+\.name:\s+(\S+)", text, re.M)
     priv = [int(x) for x in re.findall(r"^\s+\.private_segment_fixed_size:\s+(\d+)", text, re.M)]
