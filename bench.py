@@ -34,6 +34,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achiev
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16/fp16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
 N_SAMP = 480000  # 30 s at 16 kHz
 PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
+ROCPROF_ATTN_FILE = os.path.join("profiles", "r06_b64_attn_per_launch.json")  # {"frac": .., "avg_launch_us": .., "bytes_per_launch": ..}
 
 
 def parse_args(argv=None):
@@ -201,6 +202,21 @@ def roofline_for(eng, dims, model, B, dec_steps, decode_ms_per_step, dtype_bytes
     return roof
 
 
+def step_chain_roofline(dims, B, n_steps, decode_ms, s=2):
+    """4+ clips per call without per-kernel replays: the decoder steps of one call as a whole against the HBM roofline.
+    Algorithmic bytes: layer weights + every clip's cross K/V on every step, the vocabulary projection on
+    the steps whose logits are used (all but the 3 SOT steps), self K/V of the t + 1 cached keys per clip. Duration: the
+    engine's hipEvents around the decode stage of the call (stage "decode"), averaged over the timed calls."""
+    d, L, nv = dims["d"], dims["dec_layers"], dims["n_vocab"]
+    total = n_steps * (s * L * 14 * d * d + B * s * 2 * L * 1500 * d) + max(n_steps - 3, 0) * s * nv * d \
+        + B * sum(s * 2 * L * (t + 1) * d for t in range(n_steps))
+    gbs = total / (decode_ms * 1e-3) / 1e9
+    return {"kernel": "one decoder step = one replay of the captured step graph (7 dependent launches per layer + vocabulary "
+                      "projection + token feedback), %d steps per call" % n_steps,
+            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": None, "bytes_per_step": int(total / n_steps), "us_per_decode_step": round(decode_ms * 1e3 / n_steps, 2)}
+
+
 def stage_rooflines(eng, dims, model, B):
     """The other two stages against their own rooflines: encoder = MFMA-bound; the front-end evaluates the
     400-point DFT of every frame as an exact-fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: the fp32 matrix peak
@@ -221,6 +237,63 @@ def stage_rooflines(eng, dims, model, B):
         stages["encoder"] = {"ms": round(ms_enc, 3), "TFLOPs": round(tf, 1), "bound": "mfma", "peak": MFMA_BF16_PEAK_TF,
                              "frac": round(tf / MFMA_BF16_PEAK_TF, 4)}
     return stages
+
+
+def other_configs_summary(out):
+    """The other BASELINE configs' numbers of this run inside `config` (the driver's record keeps `config`, `roofline` and
+    `cpu_baseline` whole and truncates the rest of the line). Every field is named for what it is; absent legs are absent."""
+    oc = {}
+
+    def get(path, d=out):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+
+    def put(name, v):
+        if v is not None:
+            oc[name] = v
+
+    put("batch64_clips_per_s", get(("batch64", "value")))  # configs[2]
+    put("batch64_ms_per_call", get(("batch64", "ms_per_step")))
+    put("batch64_step_frac_hbm", get(("batch64", "roofline", "decode_step", "frac_of_hbm_peak")))  # whole decoder step, hipEvents
+    put("batch64_step_ms", get(("batch64", "roofline", "decode_step", "ms")))
+    # attention-only replays with both graph branches overlapping (hipEvents) — NOT the per-launch figure of a serialised trace
+    put("batch64_attn_frac_overlapped_replays", get(("batch64", "roofline", "frac")))
+    prof = load_rocprof_attn()
+    if prof:  # static: from the rocprofv3 kernel-trace summary of this build committed under profiles/
+        put("batch64_attn_frac_per_launch_rocprof", prof.get("frac"))
+        put("batch64_attn_rocprof_source", prof.get("source"))
+    put("batch64_encoder_frac_mfma", get(("batch64", "stage_rooflines", "encoder", "frac")))
+    put("batch64_encoder_ms", get(("batch64", "stage_rooflines", "encoder", "ms")))
+    put("turbo_fp16_b16_clips_per_s", get(("turbo_fp16_b16", "value")))  # configs[3]
+    put("turbo_fp16_b16_step_frac_hbm", get(("turbo_fp16_b16", "roofline", "decode_step", "frac_of_hbm_peak")))
+    put("turbo_fp16_b16_encoder_frac_mfma", get(("turbo_fp16_b16", "stage_rooflines", "encoder", "frac")))
+    put("host_pcm_clips_per_s", get(("host_pcm", "clips_per_s")))  # SURVEY §8(d): H2D + D2H inside the timed call
+    put("host_pcm_rtf", get(("host_pcm", "rtf")))
+    put("config0_ids_agree", get(("config0", "ids_agree_prefix")))  # configs[0]: tiny / demo.wav, GPU vs CPU oracle
+    put("config0_gpu_rtf_true_duration", get(("config0", "gpu", "rtf_true_duration")))
+    put("low_load_clips_per_s", get(("low_load_clips_per_s",)))
+    for nb in (2, 3, 4, 8):
+        put("batch%d_frac_hbm" % nb, get(("batch%d" % nb, "roofline", "frac")))
+    put("batch64_len100_clips_per_s", get(("batch64_len100", "value")))
+    put("stream64_clips_per_s", get(("stream64", "value")))
+    put("stream64_steady_clips_per_s", get(("stream64", "steady_state_clips_per_s")))
+    put("stream128_clips_per_s", get(("stream128", "value")))
+    put("batch256_clips_per_s", get(("batch256", "value")))
+    put("encoder_frac_mfma_this_batch", get(("stage_rooflines", "encoder", "frac")))
+    put("single_gpu_same_batch_clips_per_s", get(("single_gpu_same_batch", "value")))  # N > 1 lines
+    return oc
+
+
+def load_rocprof_attn():
+    path = os.path.join(ROOT, ROCPROF_ATTN_FILE)
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    d["source"] = ROCPROF_ATTN_FILE
+    return d
 
 
 def ensure_model_dir(modelgen, model_dir, model, dims, dtype):
@@ -369,7 +442,8 @@ def config0_leg(torch, dev, dev_index, sync, model_dir, n_ids=32):
     ncpu = os.cpu_count() or 1
     threads = min(ncpu, 32)
     res = {}
-    for name, th in (("all_cores", threads), ("single_thread", 1)):
+    many = f"{threads}_threads"  # the oracle's decoder stops scaling beyond ~32 threads: named for what it uses, not "all cores"
+    for name, th in ((many, threads), ("single_thread", 1)):
         orc = oracle.Oracle(cfg, weights, bf16_policy=False, threads=th)
         t1 = time.perf_counter()
         cpu_ids = orc.transcribe(demo, "zh", max_new=n_ids)
@@ -389,7 +463,7 @@ def config0_leg(torch, dev, dev_index, sync, model_dir, n_ids=32):
             "gpu": {"ms": round(tg * 1e3, 3), "rtf_true_duration": round(tg / audio_s, 6), "dtype": "bf16",
                     "what": "AX_WHISPER_RunPCMBatchTokens (host PCM, H2D + D2H inside)"},
             "ids_agree_prefix": f"{agree}/{len(cpu_ids)}",
-            "speedup_vs_all_cores": round(res["all_cores"]["seconds"] / tg, 1)}
+            f"speedup_vs_{many}": round(res[many]["seconds"] / tg, 1)}
 
 
 def cpu_model_string():
@@ -456,8 +530,8 @@ def cpu_baseline(args, dims, mdir, clip, gpu_ids, dec_steps, dtype="bf16"):
     out["single_thread"] = {"value": round(1.0 / t_full1, 5), "unit": "clips/s", "cores": 1,
                             "sample": f"clip 0, {how1}: front-end {t_fe1 * 1e3:.1f} ms, encoder {t_enc1 - t_fe1:.2f} s, {steps_one} decoder steps "
                                       f"{(t_one - t_enc1) / steps_one * 1e3:.1f} ms/step = {t_one:.2f} s",
-                            "ids_equal_all_cores": ids1 == cpu_ids[:len(ids1)]}
-    fe = {"port_all_cores_ms": round(t_fe_all * 1e3, 2), "port_1_thread_ms": round(t_fe1 * 1e3, 2)}
+                            f"ids_equal_{threads}_threads": ids1 == cpu_ids[:len(ids1)]}
+    fe = {f"port_{threads}_threads_ms": round(t_fe_all * 1e3, 2), "port_1_thread_ms": round(t_fe1 * 1e3, 2)}
     if oracle.ref_lib() is not None:  # the reference's own librosa.h front-end, compiled by oracle/Makefile `ref`
         t6 = time.perf_counter()
         oracle.log_mel(clip, dims["n_mels"], use_ref=True)
@@ -709,6 +783,7 @@ def run_rank(args) -> int:
                 for nb in (4, 8):
                     leg, idsp = batch_leg(torch, dev, dev_index, sync, "small", dtype, nb, min(n2, 3), 0, args.model_dir, rooflines=False)
                     leg["clip0_ids_equal_batch1"] = idsp[0] == ids[0]
+                    leg["roofline"] = step_chain_roofline(dims, nb, len(idsp[0]) + 4, leg["stage_ms"]["decode_ms"])
                     out["batch%d" % nb] = leg
                 out["low_load_clips_per_s"] = {"1": out["value"], **{str(nb): out["batch%d" % nb]["value"] for nb in (2, 3, 4, 8)}}
             if not args.no_realistic and args.max_new == 0:
@@ -735,6 +810,9 @@ def run_rank(args) -> int:
         # ---- CPU baseline: the oracle ("port") on this box's host cores, one clip of the same workload
         if rank == 0 and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, dims, mdir, clips[0], ids[0], dec_steps, dtype)
+
+    if rank == 0 and not rehearsal:
+        out["config"]["other_configs"] = other_configs_summary(out)
 
     if use_dist:
         barrier()  # rank 0 has run its roofline legs meanwhile: leave together

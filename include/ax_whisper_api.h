@@ -95,7 +95,9 @@ AX_WHISPER_API int AX_WHISPER_RunDeviceBatchTokensRagged(AX_WHISPER_HANDLE handl
                                                          const int* num_samples, int batch, int max_new,
                                                          const int* max_new_clip, int32_t* ids, int* n_ids);
 /** ids -> bytes (base64 table of {type}-tokens.txt, Whisper.cpp:224-229); ids >= the table
- *  size are skipped. *result malloc'd. */
+ *  size are skipped. A table entry ends at its first NUL byte, as in the reference (its table load strcpy's the decoded
+ *  entry, Whisper.cpp:115-127, and appends it as a C string): the bytes of an entry from a NUL onward are dropped
+ *  (id 188 and the like decode to nothing). *result malloc'd. */
 AX_WHISPER_API int AX_WHISPER_Detokenize(AX_WHISPER_HANDLE handle, const int32_t* ids, int n, char** result);
 /** The zh post-pass of Whisper::run (cpp/src/Whisper.cpp:231-236: opencc::SimpleConverter("t2s.json").Convert)
  *  on its own: config_path names an OpenCC JSON configuration (cpp/t2s.json) whose .ocd2 dictionaries sit next
@@ -108,7 +110,8 @@ AX_WHISPER_API int AX_WHISPER_ConvertT2S(const char* config_path, const char* te
  *  malloc'd, the caller frees it; info (may be NULL): [0] sample rate, [1] channels. 0 ok, -1 error. */
 AX_WHISPER_API int AX_WHISPER_LoadAudioFile(const char* path, float** samples, int* n_samples, int* info);
 /** ids -> bytes through a {type}-tokens.txt file alone, host only (Whisper.cpp:115-127 table load, :224-229 + base64.cpp:84-120
- *  decode): the bytes AX_WHISPER_Detokenize returns, with their count (an entry may hold a NUL). *result malloc'd. */
+ *  decode): the bytes AX_WHISPER_Detokenize returns, with their count (entries end at their first NUL as there, so the
+ *  result holds none; n_bytes saves the caller a strlen). *result malloc'd. */
 AX_WHISPER_API int AX_WHISPER_DetokenizeWithTable(const char* tokens_path, const int32_t* ids, int n, char** result, int* n_bytes);
 
 /* ---- additions: stage-level entry points (parity tests, profiling) ------------------- */

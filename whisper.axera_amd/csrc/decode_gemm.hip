@@ -499,11 +499,12 @@ template <int RT>
 static void launch_cg(const DecCGemmParams& p, hipStream_t s) {
   const dim3 grid((p.N + 16 * RT - 1) / (16 * RT), (p.batch + 15) / 16);
   const int ch = p.ln_w ? (p.K / 32 + 7) / 8 : 0;
+  bool ch_has_stamp = true;
   if (p.stamp) {  // measurement builds: the shapes of d_model 768
     if (ch == 0) hipLaunchKernelGGL((decode_cgemm_kernel<RT, 0, true>), grid, dim3(512), 0, s, p);
     else if (ch == 3) hipLaunchKernelGGL((decode_cgemm_kernel<RT, 3, true>), grid, dim3(512), 0, s, p);
-    else { fprintf(stderr, "[ax_whisper] launch_decode_cgemm: no stamp build for K=%d\n", p.K); abort(); }
-    return;
+    else ch_has_stamp = false;  // no measurement build for this K: the production kernel runs, unstamped (a measurement switch never ends the process)
+    if (ch_has_stamp) return;
   }
   switch (ch) {
     case 0: hipLaunchKernelGGL((decode_cgemm_kernel<RT, 0>), grid, dim3(512), 0, s, p); break;

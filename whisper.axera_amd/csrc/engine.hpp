@@ -75,7 +75,7 @@ class Engine final : public IEngine {
                            int* d_argmax);
   void enqueue_decode_step_batched(int batch, int max_new, const int* d_forced, int n_forced, float* d_logits,
                                    long logits_stride, int* d_argmax);
-  void enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced);
+  void enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced, bool one_branch);
   int decode_branches(int batch) const;
   void ensure_branch_streams(int batch);
   hipGraphExec_t step_graph(int batch, int max_new);

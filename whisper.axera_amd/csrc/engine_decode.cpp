@@ -133,7 +133,7 @@ unsigned long long* Engine::next_stamp(int layer, int cross, int b0, int nb) {
 // consumer and the residual add the epilogue of its producer, so a layer is 7 launches instead of 11
 // (AX_WHISPER_BATCHED_LN=0: the older sequence with a separate LayerNorm/h16-pair preparation launch and split-K
 // partials). b0 is a multiple of 16: every per-clip buffer of the range starts at a whole clip block.
-void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
+void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced, bool one_branch) {
   const int d = cfg_.n_text_state, H = cfg_.n_text_head, L = cfg_.n_text_layer, Tc = cfg_.n_text_ctx;
   const long self_stride = (long)H * Tc * 64, cross_stride = (long)H * t_pad_ * 64;
   const long frag0 = (long)(b0 / 16) * 512;  // fragment-major pair layouts: clip blocks are 512 elements apart within a k-step
@@ -176,7 +176,7 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced) {
     a.batch = nb; a.n_head = H; a.d_model = d; a.n_keys = n_keys; a.cap_blocks = cap_blocks; a.state = d_state_;
     a.off = d_off_ + b0;
     a.done = done;
-    a.done_late = nb <= 21 ? 1 : 0;  // one branch: the step is a chain of dependent launches (decoder.hip)
+    a.done_late = one_branch ? 1 : 0;  // the step is ONE chain of dependent launches (decoder.hip); tail branches of a multi-branch step keep the early check
     a.out_hi = att_hi; a.out_lo = att_lo; a.nbs = nbs_;
     return a;
   };
@@ -331,7 +331,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
     // attention launches (a single chain leaves the chip idle between its ~85 dependent launches).
     const int nbr = decode_branches(batch);
     if (nbr == 1) {
-      enqueue_layers_cblock(0, batch, s, d_forced != nullptr);
+      enqueue_layers_cblock(0, batch, s, d_forced != nullptr, true);
     } else {
       const int per = ((batch + nbr - 1) / nbr + 15) / 16 * 16;
       HIP_CHECK(hipEventRecord(ev_fork_, s));
@@ -340,7 +340,7 @@ void Engine::enqueue_decode_step_batched(int batch, int max_new, const int* d_fo
         if (nb <= 0) break;
         hipStream_t bs = i == 0 ? s : branch_stream_[i - 1];
         if (i > 0) HIP_CHECK(hipStreamWaitEvent(bs, ev_fork_, 0));
-        enqueue_layers_cblock(b0, nb, bs, d_forced != nullptr);
+        enqueue_layers_cblock(b0, nb, bs, d_forced != nullptr, false);
         if (i > 0) {
           HIP_CHECK(hipEventRecord(ev_join_[i - 1], bs));
           HIP_CHECK(hipStreamWaitEvent(s, ev_join_[i - 1], 0));
@@ -467,26 +467,41 @@ hipGraphExec_t Engine::step_graph(int batch, int max_new) {
     recover_streams();
     throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(cap_err) + " capturing the decoder step");
   }
-  hipGraphExec_t exec = nullptr;
-  HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  // graph and exec are released on every path out of here (the probe below may throw)
+  struct Holder {
+    hipGraph_t g;
+    hipGraphExec_t e = nullptr;
+    ~Holder() {
+      if (e) (void)hipGraphExecDestroy(e);
+      if (g) (void)hipGraphDestroy(g);
+    }
+  } hold{graph};
+  HIP_CHECK(hipGraphInstantiate(&hold.e, graph, nullptr, nullptr, 0));
   {  // which hardware queue the graph's second branch runs on decides the slot stream's rate (engine_stream.cpp:
-     // graph_branch_shares_queue); AX_WHISPER_ALIGN_QUEUES=0: as it falls
+     // graph_branch_shares_queue); AX_WHISPER_ALIGN_QUEUES=0: as it falls.
+     // ORDER: the probe REPLAYS the step, i.e. runs real decoder steps on whatever state the buffers hold. Every caller
+     // therefore asks for its graph BEFORE it sets up the decode state of a request (greedy_loop, stream_begin, bench).
     static const bool align = [] { const char* e = getenv("AX_WHISPER_ALIGN_QUEUES"); return !(e && e[0] == '0'); }();
     if (align && !user_stream_ && batch > gemv_max_ && batched_ln_ && decode_branches(batch) >= 2 && step_mask_ == 15) {
+      constexpr size_t kMaxPadStreams = 8;  // per engine, whatever the number of distinct (batch, max_new) graphs a server sees
       int tries = 0;
-      while (!graph_branch_shares_queue(exec, branch_stream_[0]) && tries < 4) {
-        HIP_CHECK(hipGraphExecDestroy(exec));
-        exec = nullptr;
+      bool aligned = graph_branch_shares_queue(hold.e, branch_stream_[0]);
+      while (!aligned && tries < 4 && pad_streams_.size() < kMaxPadStreams) {
+        HIP_CHECK(hipGraphExecDestroy(hold.e));
+        hold.e = nullptr;
         hipStream_t pad = nullptr;
         HIP_CHECK(hipStreamCreateWithFlags(&pad, hipStreamNonBlocking));
         pad_streams_.push_back(pad);
-        HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIP_CHECK(hipGraphInstantiate(&hold.e, graph, nullptr, nullptr, 0));
         ++tries;
+        aligned = graph_branch_shares_queue(hold.e, branch_stream_[0]);  // the exec that is kept is the one that was probed
       }
       cfg_.ints["graph_queue_tries"] = tries;
+      cfg_.ints["graph_queue_aligned"] = aligned ? 1 : 0;
     }
   }
-  HIP_CHECK(hipGraphDestroy(graph));
+  hipGraphExec_t exec = hold.e;
+  hold.e = nullptr;  // kept: owned by graphs_ from here on
   graphs_[key] = exec;
   return exec;
 }

@@ -45,8 +45,13 @@ struct JsonValue {
     return it->second;
   }
   long as_int() const {
-    if (kind == Number) return (long)num;
-    if (kind == String) return std::stol(str);
+    if (kind == Number) {
+      if (!(num >= -9.2e18 && num <= 9.2e18)) throw std::runtime_error("json: number out of range");  // (also NaN) a cast outside long's range is undefined
+      return (long)num;
+    }
+    if (kind == String) {
+      try { return std::stol(str); } catch (const std::exception&) { throw std::runtime_error("json: not a number"); }
+    }
     if (kind == Bool) return b;
     throw std::runtime_error("json: not a number");
   }
@@ -72,7 +77,14 @@ class JsonParser {
   [[noreturn]] void fail(const char* m) { throw std::runtime_error(std::string("json: ") + m + " at " + std::to_string(p_)); }
   void ws() { while (p_ < s_.size() && (s_[p_] == ' ' || s_[p_] == '\n' || s_[p_] == '\t' || s_[p_] == '\r')) ++p_; }
   char peek() { ws(); if (p_ >= s_.size()) fail("unexpected end"); return s_[p_]; }
+  int depth_ = 0;
+  struct Depth {  // containers nest by recursion: a hostile header of 100 000 '[' must not exhaust the stack
+    JsonParser& p;
+    explicit Depth(JsonParser& q) : p(q) { if (++p.depth_ > 64) p.fail("nesting too deep"); }
+    ~Depth() { --p.depth_; }
+  };
   JsonValue value() {
+    Depth guard(*this);
     char c = peek();
     JsonValue v;
     if (c == '{') {
@@ -106,7 +118,9 @@ class JsonParser {
       size_t e = p_;
       while (e < s_.size() && (isdigit((unsigned char)s_[e]) || strchr("+-.eE", s_[e]))) ++e;
       if (e == p_) fail("unexpected character");
-      v.kind = JsonValue::Number; v.num = std::stod(s_.substr(p_, e - p_)); p_ = e;
+      v.kind = JsonValue::Number;
+      try { v.num = std::stod(s_.substr(p_, e - p_)); } catch (const std::exception&) { fail("bad number"); }
+      p_ = e;
     }
     return v;
   }
@@ -122,7 +136,14 @@ class JsonParser {
           case 'b': out += '\b'; break; case 'f': out += '\f'; break;
           case 'u': {
             if (p_ + 4 > s_.size()) fail("bad \\u");
-            unsigned cp = (unsigned)std::stoul(s_.substr(p_, 4), nullptr, 16); p_ += 4;
+            unsigned cp = 0;
+            for (int i = 0; i < 4; ++i) {
+              const char h = s_[p_ + i];
+              const int dv = h >= '0' && h <= '9' ? h - '0' : h >= 'a' && h <= 'f' ? h - 'a' + 10 : h >= 'A' && h <= 'F' ? h - 'A' + 10 : -1;
+              if (dv < 0) fail("bad \\u");
+              cp = cp * 16 + (unsigned)dv;
+            }
+            p_ += 4;
             if (cp < 0x80) out += (char)cp;
             else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
             else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
@@ -204,31 +225,47 @@ class SafeTensors {
     if (size_ < 8) throw std::runtime_error("weights file too small");
     base_ = (const uint8_t*)mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
     if (base_ == MAP_FAILED) { base_ = nullptr; throw std::runtime_error("mmap failed for " + path); }
-    uint64_t hl; memcpy(&hl, base_, 8);
-    if (hl > size_ - 8) throw std::runtime_error("bad safetensors header length");  // no 8 + hl: it can wrap
-    std::string hdr((const char*)base_ + 8, (size_t)hl);
+    parse_image(base_, size_, tensors_);
+  }
+
+ public:
+  // The header of a safetensors image [base, base + size): every tensor's dtype, shape and byte range, checked against the
+  // image's bounds (the views point into the image). Separate from the mmap so that tests can hand it arbitrary bytes.
+  static void parse_image(const uint8_t* base, size_t size, std::map<std::string, TensorView>& tensors) {
+    if (size < 8) throw std::runtime_error("weights file too small");
+    uint64_t hl; memcpy(&hl, base, 8);
+    if (hl > size - 8) throw std::runtime_error("bad safetensors header length");  // no 8 + hl: it can wrap
+    std::string hdr((const char*)base + 8, (size_t)hl);
     JsonValue j = JsonParser(hdr).parse();
-    const uint8_t* data0 = base_ + 8 + hl;
-    const size_t data_bytes = size_ - 8 - (size_t)hl;
+    if (j.kind != JsonValue::Object) throw std::runtime_error("safetensors header is not an object");
+    const uint8_t* data0 = base + 8 + hl;
+    const size_t data_bytes = size - 8 - (size_t)hl;
     for (auto& kv : j.obj) {
       if (kv.first == "__metadata__") continue;
       TensorView t;
       t.dtype = kv.second.at("dtype").as_str();
+      size_t numel = 1;
       for (auto& d : kv.second.at("shape").arr) {
         if (d.as_int() < 0) throw std::runtime_error("tensor '" + kv.first + "': negative dimension");
         t.shape.push_back(d.as_int());
+        if (d.as_int() != 0 && numel > (size_t)1 << 48) throw std::runtime_error("tensor '" + kv.first + "': shape too large");  // the product below cannot wrap
+        numel *= (size_t)d.as_int();
+        if (numel > (size_t)1 << 48) throw std::runtime_error("tensor '" + kv.first + "': shape too large");
       }
       auto& off = kv.second.at("data_offsets").arr;
+      if (off.size() != 2) throw std::runtime_error("tensor '" + kv.first + "': bad data_offsets");
       if (off.at(0).as_int() < 0 || off.at(1).as_int() < 0) throw std::runtime_error("tensor '" + kv.first + "': negative offset");
       size_t s = (size_t)off.at(0).as_int(), e = (size_t)off.at(1).as_int();
       if (e < s || e > data_bytes) throw std::runtime_error("tensor '" + kv.first + "' out of file bounds");
       t.data = data0 + s; t.nbytes = e - s;
       size_t es = t.dtype == "F32" ? 4 : (t.dtype == "BF16" || t.dtype == "F16") ? 2 : 0;
       if (!es) throw std::runtime_error("tensor '" + kv.first + "': unsupported dtype " + t.dtype);
-      if ((size_t)t.numel() * es != t.nbytes) throw std::runtime_error("tensor '" + kv.first + "': size mismatch");
-      tensors_[kv.first] = t;
+      if (numel * es != t.nbytes) throw std::runtime_error("tensor '" + kv.first + "': size mismatch");
+      tensors[kv.first] = t;
     }
   }
+
+ private:
   int fd_ = -1; size_t size_ = 0; const uint8_t* base_ = nullptr;
   std::map<std::string, TensorView> tensors_;
 };
@@ -257,9 +294,13 @@ inline bool base64_decode(const std::string& in, std::string& out) {
 
 // Decoded byte strings, index = rank (= line index). The reference keeps the base64 text and
 // decodes per token at run time (Whisper.cpp:224-229); decoding once at load is equivalent.
+inline std::vector<std::string> parse_token_table(std::istream& f);
 inline std::vector<std::string> load_token_table(const std::string& path) {
   std::ifstream f(path);
   if (!f.is_open()) throw std::runtime_error("cannot open tokens file " + path);
+  return parse_token_table(f);
+}
+inline std::vector<std::string> parse_token_table(std::istream& f) {
   std::vector<std::string> table; std::string line;
   while (std::getline(f, line)) {
     size_t i = line.find(' ');
@@ -276,10 +317,14 @@ inline std::vector<std::string> load_token_table(const std::string& path) {
 // ------------------------------------------------------------------------------- WAV
 struct WavData { int sample_rate = 0; int channels = 0; std::vector<float> mono; };
 
+inline bool load_wav_bytes(const std::vector<uint8_t>& d, WavData& out, std::string& err);
 inline bool load_wav(const std::string& path, WavData& out, std::string& err) {
   std::ifstream f(path, std::ios::binary);
   if (!f.is_open()) { err = "cannot open " + path; return false; }
   std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  return load_wav_bytes(d, out, err);
+}
+inline bool load_wav_bytes(const std::vector<uint8_t>& d, WavData& out, std::string& err) {
   if (d.size() < 44 || memcmp(d.data(), "RIFF", 4) || memcmp(d.data() + 8, "WAVE", 4)) { err = "not a RIFF/WAVE file"; return false; }
   auto u16 = [&](size_t o) { return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8); };
   auto u32 = [&](size_t o) { return u16(o) | (u16(o + 2) << 16); };
@@ -292,7 +337,7 @@ inline bool load_wav(const std::string& path, WavData& out, std::string& err) {
     } else if (!memcmp(d.data() + p, "data", 4)) {
       data_off = p + 8; data_len = std::min<size_t>(len, d.size() - data_off); break;
     }
-    p += 8 + len + (len & 1);
+    p += (size_t)8 + (size_t)len + (len & 1);  // in size_t: 8 + len wraps in 32 bits (a chunk length of 0xFFFFFFF8 would never advance)
   }
   if (!data_off || ch < 1 || !(fmt == 1 || fmt == 3)) { err = "unsupported WAV (need PCM or IEEE float)"; return false; }
   int bps = bits / 8;
@@ -351,7 +396,8 @@ inline bool load_aiff(const std::vector<uint8_t>& d, WavData& out, std::string& 
   if (start > d.size()) { err = "AIFF sound data offset out of bounds"; return false; }
   const size_t avail = std::min<size_t>(d.size() - start, ssnd_len >= 8 + offset ? ssnd_len - 8 - offset : 0);
   const size_t frames = std::min(frames_decl, avail / (bps * ch));
-  out.sample_rate = (int)(rate + 0.5); out.channels = ch; out.mono.resize(frames);
+  // (an 80-bit rate beyond int's range — or a NaN — must not reach the cast: undefined behaviour)
+  out.sample_rate = (rate >= 0.0 && rate < 2147483000.0) ? (int)(rate + 0.5) : 0; out.channels = ch; out.mono.resize(frames);
   auto sample = [&](size_t frame, int c) -> float {
     const uint8_t* s = d.data() + start + (frame * ch + c) * bps;
     if (bps == 1) return (float)(int8_t)s[0] / 128.f;

@@ -33,7 +33,8 @@ namespace ocd2 {
 struct Reader {
   const std::string& b;
   size_t p;
-  void need(size_t n) const { if (p + n > b.size()) throw std::runtime_error("ocd2: truncated file"); }
+  // (p may sit a few pad bytes beyond the end after a vector; n comes from the file: no p + n, it can wrap)
+  void need(size_t n) const { if (p > b.size() || n > b.size() - p) throw std::runtime_error("ocd2: truncated file"); }
   uint32_t u32() { need(4); uint32_t v; memcpy(&v, b.data() + p, 4); p += 4; return v; }
   uint64_t u64() { need(8); uint64_t v; memcpy(&v, b.data() + p, 8); p += 8; return v; }
   uint16_t u16() { need(2); uint16_t v; memcpy(&v, b.data() + p, 2); p += 2; return v; }
@@ -55,16 +56,19 @@ struct BitVector {
   void read(Reader& r) {
     const std::string u = r.vec(8);
     units.resize(u.size() / 8);
-    memcpy(units.data(), u.data(), u.size());
+    if (!u.empty()) memcpy(units.data(), u.data(), u.size());  // (an empty vector's data() may be null: not a memcpy argument)
     size = r.u32();
     num1 = r.u32();
     r.vec(12);  // rank index
     r.vec(4);   // select0 index
     r.vec(4);   // select1 index
-    if ((size + 63) / 64 > units.size()) throw std::runtime_error("ocd2: bad bit vector");
+    if (((size_t)size + 63) / 64 > units.size()) throw std::runtime_error("ocd2: bad bit vector");  // in size_t: size + 63 wraps in 32 bits
     for (uint32_t i = 0; i < size; ++i) (get(i) ? ones : zeros).push_back(i);
   }
-  bool get(size_t i) const { return (units[i >> 6] >> (i & 63)) & 1; }
+  bool get(size_t i) const {
+    if (i >= size) throw std::runtime_error("ocd2: bit index out of range");  // node ids come from the file's own links
+    return (units[i >> 6] >> (i & 63)) & 1;
+  }
   size_t rank1(size_t i) const { return std::lower_bound(ones.begin(), ones.end(), (uint32_t)i) - ones.begin(); }
   size_t select1(size_t k) const { if (k >= ones.size()) throw std::runtime_error("ocd2: select out of range"); return ones[k]; }
 };
@@ -79,9 +83,11 @@ struct FlagVector {
     value_size = r.u32();
     mask = r.u32();
     r.u64();  // number of values
+    if (value_size > 32) throw std::runtime_error("ocd2: bad flag vector");
   }
   uint32_t get(size_t i) const {
     const size_t pos = i * value_size, w = pos >> 6, o = pos & 63;
+    if (w + 1 >= units.size()) throw std::runtime_error("ocd2: flag index out of range");  // (one spare unit is allocated)
     uint64_t v = units[w] >> o;
     if (o + value_size > 64) v |= units[w + 1] << (64 - o);
     return (uint32_t)v & mask;
@@ -104,7 +110,7 @@ struct Trie {  // one level of marisa's LoudsTrie
     if (tail_end.size == 0) {
       for (size_t o = lnk; o < tail_buf.size() && tail_buf[o]; ++o) out.push_back(tail_buf[o]);
     } else {
-      for (size_t o = lnk; o < tail_buf.size(); ++o) { out.push_back(tail_buf[o]); if (tail_end.get(o)) break; }
+      for (size_t o = lnk; o < tail_buf.size() && o < tail_end.size; ++o) { out.push_back(tail_buf[o]); if (tail_end.get(o)) break; }
     }
   }
   // a node of a NEXT-level trie spells its string walking up to the root
@@ -146,8 +152,9 @@ struct T2SDict {
   std::unordered_map<std::string, std::string> map;
   size_t max_key = 0;
 
-  static T2SDict load_ocd2(const std::string& path) {
-    const std::string b = read_text_file(path);
+  static T2SDict load_ocd2(const std::string& path) { return load_ocd2_bytes(read_text_file(path), path); }
+  // the dictionary image itself (tests hand it mutated bytes); `path` only names it in messages
+  static T2SDict load_ocd2_bytes(const std::string& b, const std::string& path) {
     static const char kMagic[] = "OPENCC_MARISA_0.2.5";
     static const char kMarisa[16] = {'W', 'e', ' ', 'l', 'o', 'v', 'e', ' ', 'M', 'a', 'r', 'i', 's', 'a', '.', '\0'};
     const size_t ml = sizeof(kMagic) - 1;

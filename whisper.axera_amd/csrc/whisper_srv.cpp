@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "ax_whisper_api.h"
+#include "http_request.hpp"
 
 struct Job {
   std::vector<float> pcm;
@@ -262,8 +263,6 @@ static void send_response(int fd, int status, const std::string& body) {
   }
 }
 
-static std::string lower(std::string s) { std::transform(s.begin(), s.end(), s.begin(), ::tolower); return s; }
-
 struct ConnGuard { ~ConnGuard() { --g_conns; } };
 
 static void serve(int fd) {
@@ -278,13 +277,16 @@ static void serve(int fd) {
     hdr_end = buf.find("\r\n\r\n");
   }
   if (hdr_end == std::string::npos) { close(fd); return; }
-  const std::string head = buf.substr(0, hdr_end);
-  const std::string lhead = lower(head);
-  const std::string first = head.substr(0, head.find("\r\n"));
-  size_t clen = 0;
-  size_t p = lhead.find("content-length:");
-  if (p != std::string::npos) clen = strtoul(lhead.c_str() + p + 15, nullptr, 10);
-  if (lhead.find("expect: 100-continue") != std::string::npos) {
+  axw::HttpHead hh;
+  axw::parse_http_head(buf, hh);  // csrc/http_request.hpp: the parsing itself is socket-free (and runs under ASan / UBSan in tests/)
+  if (!hh.length_ok) {
+    send_response(fd, 400, R"({"error": "Bad Content-Length"})");
+    shutdown(fd, SHUT_RDWR);
+    close(fd);
+    return;
+  }
+  const size_t clen = hh.content_length;
+  if (hh.expect_continue) {
     const char* c = "HTTP/1.1 100 Continue\r\n\r\n";
     (void)!send(fd, c, strlen(c), MSG_NOSIGNAL);
   }
@@ -306,7 +308,8 @@ static void serve(int fd) {
     close(fd);
     return;
   }
-  if (first.rfind("GET /health", 0) == 0) {
+  const axw::HttpRoute route = axw::http_route(hh);
+  if (route == axw::HttpRoute::Health) {
     long giveups = 0;
     for (AX_WHISPER_HANDLE m : g_models) giveups += std::max(0, AX_WHISPER_GetConfigInt(m, "persistent_giveups"));
     size_t queued;
@@ -315,21 +318,14 @@ static void serve(int fd) {
     snprintf(hb, sizeof hb, "{\"status\": \"ok\", \"devices\": %d, \"queued\": %zu, \"busy_slots\": %d, \"connections\": %d, \"served\": %ld, \"persistent_giveups\": %ld}",
              (int)g_models.size(), queued, g_busy_slots.load(), g_conns.load(), g_served.load(), giveups);
     send_response(fd, 200, hb);
-  } else if (first.rfind("OPTIONS ", 0) == 0) {
+  } else if (route == axw::HttpRoute::Options) {
     send_response(fd, 200, "{}");
-  } else if (first.rfind("POST /asr", 0) != 0) {
+  } else if (route == axw::HttpRoute::NotFound) {
     send_response(fd, 404, R"({"error": "Not found"})");
+  } else if (const char* bad = axw::asr_request_error(hh, body.size())) {
+    send_response(fd, 400, bad);
   } else {
-    size_t ct = lhead.find("content-type:");
-    size_t ct_end = ct == std::string::npos ? ct : lhead.find("\r\n", ct);
-    std::string ctv = ct == std::string::npos ? "" : lhead.substr(ct, ct_end == std::string::npos ? std::string::npos : ct_end - ct);
-    if (ctv.find("application/octet-stream") == std::string::npos) {                       // hpp:50-55
-      send_response(fd, 400, R"({"error": "Content-Type must be application/octet-stream"})");
-    } else if (body.empty()) {                                                               // hpp:58-62
-      send_response(fd, 400, R"({"error": "Request body is empty"})");
-    } else if (body.size() % sizeof(float) != 0) {                                           // hpp:65-71
-      send_response(fd, 400, R"({"error": "Data size must be multiple of 4 bytes"})");
-    } else {
+    {
       Job job;
       job.pcm.resize(body.size() / sizeof(float));
       memcpy(job.pcm.data(), body.data(), body.size());                                      // hpp:103-113
