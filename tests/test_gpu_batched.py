@@ -201,3 +201,58 @@ def test_ragged_small_batch_with_split_cross_attention(built_lib, micro_case, B)
         assert again == uniform
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("model_type,kind,B,seed", [("micro", "benign", 4, 11), ("mini", "realistic", 7, 42), ("micro", "benign", 40, 11),
+                                                    ("w512", "realistic", 20, 43)])
+def test_clip_block_query_fold_equals_the_fused_projection(built_lib, oracle_mod, tmp_path, monkeypatch, model_type, kind, B, seed):
+    """Round 6 (decode_gemm.hip "QUERY FOLD"): the clip-block step folds the cross-attention query through the self-attention
+    output projection — A0 from the QKV launch, T = A0 + M a + d and the block statistics from the o launch, the cross-attention
+    workgroups start with r (T - mu s) + c. Against the fused projection of the same build (AX_WHISPER_CBLOCK_QFOLD=0), the same
+    arithmetic in another association: teacher-forced logits within 2e-5 (benign) / 4e-4 (trained-model statistics) of the logit
+    scale; and against the policy oracle as every other batched test. One branch with key splits (4, 7, 20 clips) and two
+    branches (40 clips)."""
+    from conftest import ModelCase
+    import modelgen
+
+    case = ModelCase(tmp_path, model_type, seed, kind=kind)
+    n_mels = case.dims["n_mels"]
+    clips = [load_demo_pcm(), modelgen.synth_clip(seed, 200000), modelgen.synth_clip(seed + 1, 90000)]
+    n = 12
+    out = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("AX_WHISPER_CBLOCK_QFOLD", "2" if fold == "1" else "0")  # "2": the fold in multi-branch steps too (production: one-branch steps)
+        e = built_lib.Whisper(model_type, case.root, "zh", device=0, max_batch=B)
+        try:
+            assert e.L.AX_WHISPER_GetConfigInt(e.h, b"cblock_qfold") == (2 if fold == "1" else 0)
+            mels = np.stack([e.compute_mel(clips[b % 3]) for b in range(B)])
+            e.encode_mel(mels)
+            if fold == "1":
+                ids = e.decode_greedy(B, max_new=n)
+                forced = np.array([(ids[b] + [50257] * n)[:n] for b in range(B)], dtype=np.int32)
+            lg, am = e.decode_forced(B, forced)
+            out[fold] = (lg, am, e.decode_greedy(B, max_new=n))
+        finally:
+            e.close()
+    (l1, a1, g1), (l0, a0, g0) = out["1"], out["0"]
+    scale = float(np.abs(l0).max())
+    err = float(np.abs(l1 - l0).max())
+    print(f"{model_type} ({kind}) B={B}: folded vs fused-projection logits differ by {err:.3e} at |logit| <= {scale:.1f}")
+    # M enters as an (hi, lo) h16 pair (2^-17 relative) where the fused projection multiplies the exact W_cq rows, and a last-bit fp32
+    # difference in a query flips the 16-bit rounding of a stored self-attention K/V entry here and there: measured 6.6e-5 at
+    # |logit| <= 1.1 (micro, 4 clips) — the size of the difference between any two batched paths (1.5e-4 vs the oracle above)
+    rel = 1.5e-4 if kind == "benign" else 4e-4
+    assert err < rel * max(scale, 1.0) + 2e-5, (err, scale)
+    for b in range(B):  # greedy ids: equal, or a tie at the first difference measured on the forced logits of that clip
+        if g1[b] != g0[b]:
+            i = next(i for i in range(min(len(g1[b]), len(g0[b]))) if g1[b][i] != g0[b][i])
+            srt = np.sort(l0[b, i])
+            assert srt[-1] - srt[-2] < 2 * float(np.abs(l1[b, i] - l0[b, i]).max()) + 1e-4, (b, i)
+    # the policy oracle on clip 0 and 1 (teacher-forced along the same ids)
+    for b in (0, 1):
+        mel = oracle_mod.log_mel(clips[b % 3], n_mels)[0]
+        ck, cv = case.oracle_bf16.encoder(mel)
+        _, lg = case.oracle_bf16.greedy(ck, cv, "zh", max_new=n, forced=[int(t) for t in forced[b]], want_logits=True)
+        eo = float(np.abs(l1[b, : len(lg)] - lg).max())
+        print(f"  clip {b}: folded vs policy oracle {eo:.3e}")
+        assert eo < (5e-3 if kind == "benign" else 0.2), eo

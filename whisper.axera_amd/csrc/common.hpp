@@ -329,6 +329,9 @@ struct DecAttnParams {
   // fused query projection (batched cross-attention): q = Wq[head rows] . LayerNorm(x[b]) + bq computed by the
   // (clip, head) workgroup itself while its first K/V block is in flight; wq == nullptr: q is read from `q`
   const float* x; const float* ln_w; const float* ln_b; const h16* wq; const float* bq;
+  // folded query (decode_gemm.hip "QUERY FOLD"; tq != nullptr): q[j] = rstd (tq[b][j] - mean fold_s[j]) + fold_c[j], mean / rstd of
+  // the clip's residual row from its stat_part[b][d_model / 16][2] block statistics
+  const float* tq; const float* stat_part; const float* fold_s; const float* fold_c;
   // measurement only (Engine::bench "attn_stamp"): [workgroups][2] = {begin, end} of every workgroup of this launch in
   // 100 MHz wall-clock ticks, written by the kernel itself (a separate template instantiation: the production kernel
   // carries no stamp code)
@@ -373,6 +376,12 @@ struct DecCGemmParams {
   h16* k_cache; h16* v_cache; long kv_batch_stride; int d_model; int n_ctx_pad;
   const DecState* state;
   const int* off;                          // per-clip offsets [batch]
+  // query fold of the clip-block step (decode_gemm.hip "QUERY FOLD"); fold_row0 == 0: none
+  int fold_row0;                           // rows >= fold_row0 are fold rows (QKV launch: 3 d_model; o launch: d_model)
+  const float* ln_w2;                      // LayerNorm-prologue launch: the fold rows' input is ln_w2 . x (no statistics, no shift)
+  const h16* W_lo;                         // pair-input launch: lo halves of the fold rows' weights (fragment-major, row block 0 = fold_row0)
+  float* out2;                             // the fold rows' output / residual target [batch][N - fold_row0]
+  float* stat_part;                        // GEPI_RESID: [batch][fold_row0 / 16][2] = (sum, squares about the block mean) of the new rows
   // measurement only (Engine::bench "attn_stamp"): [workgroups][2] = {begin, time at stamp_point} of every workgroup, 100 MHz ticks;
   // a separate template instantiation (the production kernel carries no stamp code)
   unsigned long long* stamp; int stamp_point;
@@ -383,6 +392,7 @@ bool decode_logits_resident_ok(int K, int batch);  // rt == 0 (one workgroup per
 void launch_act_prep(float* x, const float* g, const float* be, h16* hi, h16* lo, int batch, int K, bool do_ln, int nbs,
                      const float* part, int n_part, int part_batch, const float* part_bias, hipStream_t s);
 void launch_pack_weight_frag(const h16* w, h16* wp, int N, int K, hipStream_t s);
+void launch_pack_weight_frag_split(const float* w, h16* hi, h16* lo, int N, int K, hipStream_t s);  // fp32 -> (hi, lo) h16 pair
 
 struct AdvanceParams {
   const float* amax_val; const int* amax_idx; int n_part; int amax_stride;

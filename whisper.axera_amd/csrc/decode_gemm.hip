@@ -125,6 +125,25 @@ void launch_pack_weight_frag(const h16* w, h16* wp, int N, int K, hipStream_t s)
   hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(2048), dim3(256), 0, s, w, wp, N, K);
 }
 
+// row-major fp32 [N][K] -> TWO fragment-major h16 arrays, hi = h16(m) and lo = h16(m - hi) (the query fold's product matrix M)
+__global__ void pack_weight_frag_split_kernel(const float* __restrict__ w, h16* __restrict__ hi, h16* __restrict__ lo, int N, int K) {
+  const int KS = K / 32;
+  const long total = (long)((N + 15) / 16) * KS * 512;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long tile = i >> 9;
+    const int ks = (int)(tile % KS), nb = (int)(tile / KS);
+    const int row = nb * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + j;
+    h16 h = (h16)0.f, l = (h16)0.f;
+    if (row < N) split_bf16(w[(long)row * K + k], h, l);
+    hi[i] = h;
+    lo[i] = l;
+  }
+}
+void launch_pack_weight_frag_split(const float* w, h16* hi, h16* lo, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(pack_weight_frag_split_kernel, dim3(2048), dim3(256), 0, s, w, hi, lo, N, K);
+}
+
 template <int RT, int NB>
 __global__ __launch_bounds__(512) void decode_gemm_kernel(DecGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -283,6 +302,17 @@ __device__ __forceinline__ float sum_lanes_16_32(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// sum over the 16 lanes of a DPP row (equal lane >> 4), in every lane of the row
+__device__ __forceinline__ float row16_sum_f(float v) {
+#define AXW_DPP_ROW(CTRL, X) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), CTRL, 0xf, 0xf, true))
+  v += AXW_DPP_ROW(0xB1, v);   // quad_perm [1,0,3,2]
+  v += AXW_DPP_ROW(0x4E, v);   // quad_perm [2,3,0,1]
+  v += AXW_DPP_ROW(0x141, v);  // row_half_mirror
+  v += AXW_DPP_ROW(0x140, v);  // row_mirror
+#undef AXW_DPP_ROW
+  return v;
+}
+
 // ---------------------------------------------------------------------------- clip-block GEMM (DecCGemmParams)
 // grid = (weight-row blocks of 16*RT, clip blocks of 16); 8 waves split K (k-steps w, w+8, ...), reduce through LDS;
 // at most one output per thread (RT <= 2), so the bias and the residual value are requested before anything else.
@@ -290,7 +320,15 @@ __device__ __forceinline__ float sum_lanes_16_32(float v) {
 // STAMP (measurement builds only, Engine::bench "attn_stamp"): thread 0 of every workgroup records its start and the time it reaches
 // point p.stamp_point: 1 every request of the prologue is out | 2 LayerNorm statistics done (CH > 0) | 3 MFMAs issued | 4 the eight
 // waves' partial sums are in LDS (behind the barrier) | 0 end
-template <int RT, int CH, bool STAMP = false>
+// QUERY FOLD (round 6; p.fold_row0 > 0): the cross-attention query of the clip-block step is folded through the self-attention output
+// projection as in the one-clip launch (decode_persistent.hip header): cq = r (T - mu s) + c with T = A0 + M a + d,
+// A0 = W_cq (g . x0), M = W_cq diag(g) W_o. Rows >= fold_row0 of a launch are those extra rows:
+//   QKV launch (CH > 0), rows [3d, 4d): W_cq against g_cross . x0 (no statistics, no shift) -> out2 = A0
+//   o launch (FOLD), rows [d, 2d): M as an (hi, lo) h16 pair against the attention vector, added onto out2 with bias d -> out2 = T;
+//   its ordinary rows also leave (sum, centred squares) of the new residual rows per 16-row block in stat_part.
+// decode_attention_kernel<2> then builds its head's query from 64 T values, the 48 partial statistics and two constant vectors:
+// no LayerNorm barriers, no 98 KB of W_cq through every (clip, head) workgroup, 50 registers fewer.
+template <int RT, int CH, bool STAMP = false, bool FOLD = false>
 __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
   __shared__ __attribute__((aligned(16))) float red[8 * RT * 256];  // [wave][t][clip][row]
   __shared__ float stat[2][8][16];
@@ -306,13 +344,16 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
   const int n0 = blockIdx.x * (16 * RT), cb = blockIdx.y;
   const int KS = p.K / 32;
   const int nb0 = blockIdx.x * RT, n_rb = (p.N + 15) / 16;
+  const int fr0 = p.fold_row0 > 0 ? p.fold_row0 : 0x7fffffff;  // first query-fold row (a multiple of 16 RT)
+  const bool fw = n0 >= fr0;                                   // workgroup-uniform: this workgroup's rows are fold rows
+  const int nx = min(p.N, fr0);                                // row length of the primary output
 
   // this thread's output: weight row n0 + tid % (16 RT), clip cb*16 + tid / (16 RT)
   const int o_n = n0 + tid % (16 * RT), o_b = cb * 16 + tid / (16 * RT);
   const bool has_out = tid < RT * 256 && o_n < p.N && o_b < p.batch;
   float bias_t = 0.f, old_t = 0.f;
   if (has_out && p.bias) bias_t = p.bias[o_n];
-  if (has_out && p.epilogue == GEPI_RESID) old_t = p.out[(long)o_b * p.N + o_n];
+  if (has_out && p.epilogue == GEPI_RESID) old_t = fw ? p.out2[(long)o_b * (p.N - fr0) + (o_n - fr0)] : p.out[(long)o_b * nx + o_n];
   const int step = (has_out && p.epilogue == GEPI_QKV_CACHE) ? p.off[o_b] : 0;  // this thread's clip: its own cache row
 
   const h16* wrow[RT];
@@ -352,8 +393,8 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
 #pragma unroll
     for (int i = 0; i < (CH * 256 + 511) / 512; ++i) {
       const int kk = tid + 512 * i;
-      lnw_t[i] = kk < p.K ? p.ln_w[kk] : 0.f;
-      lnb_t[i] = kk < p.K ? p.ln_b[kk] : 0.f;
+      lnw_t[i] = kk < p.K ? (fw ? p.ln_w2[kk] : p.ln_w[kk]) : 0.f;  // fold rows: g_cross . x, unnormalised, unshifted
+      lnb_t[i] = (kk < p.K && !fw) ? p.ln_b[kk] : 0.f;
     }
     stamp_at(1);
     // two-pass statistics per clip: lanes (r, 0..3) of 8 waves hold one row between them
@@ -375,7 +416,7 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
     float mean = 0.f;
 #pragma unroll
     for (int w2 = 0; w2 < 8; ++w2) mean += stat[0][w2][r];
-    mean /= (float)p.K;
+    mean = fw ? 0.f : mean / (float)p.K;
     float s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c)
@@ -391,7 +432,7 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
     float var = 0.f;
 #pragma unroll
     for (int w2 = 0; w2 < 8; ++w2) var += stat[1][w2][r];
-    const float rstd = rsqrtf(var / (float)p.K + 1e-5f);
+    const float rstd = fw ? 1.f : rsqrtf(var / (float)p.K + 1e-5f);
     stamp_at(2);
 #pragma unroll
     for (int c = 0; c < CH; ++c)
@@ -425,10 +466,19 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
     const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a_hi + (long)cb * 512), 0, (int)a_bytes, 0x27000);
     const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a_lo + (long)cb * 512), 0, (int)a_bytes, 0x27000);
     const int a_off = cb * 16 + r < p.batch ? lane * 16 : 0x7ffffff0;
-    struct Frag { h16x8 w[RT], h, l; };
+    struct Frag { h16x8 w[RT], wl[FOLD ? RT : 1], h, l; };
+    const h16* wlrow[RT];  // FOLD: the lo halves of the fold rows' weights (their own array, row block 0 = row fold_row0)
+#pragma unroll
+    for (int t = 0; t < RT; ++t) wlrow[t] = (FOLD && fw) ? p.W_lo + (long)(nb0 + t - fr0 / 16) * KS * 512 + lane * 8 : nullptr;
     auto load = [&](Frag& f, int ks) {
 #pragma unroll
       for (int t = 0; t < RT; ++t) f.w[t] = *reinterpret_cast<const h16x8*>(wrow[t] + (long)ks * 512);
+      if constexpr (FOLD) {
+        if (fw) {
+#pragma unroll
+          for (int t = 0; t < RT; ++t) f.wl[t] = *reinterpret_cast<const h16x8*>(wlrow[t] + (long)ks * 512);
+        }
+      }
       const int so = (int)(ks * a_step * 2);  // wave-uniform: the scalar offset of the k-step
       const u32x4 uh = __builtin_amdgcn_raw_buffer_load_b128(rs_hi, a_off, so, 0);
       const u32x4 ul = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, a_off, so, 0);
@@ -440,12 +490,18 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
       for (int t = 0; t < RT; ++t) {
         acc[t] = AXW_MFMA_16x16x32(f.w[t], f.h, acc[t]);
         acc[t] = AXW_MFMA_16x16x32(f.w[t], f.l, acc[t]);
+        if constexpr (FOLD) {
+          if (fw) {  // M = M_hi + M_lo: the product matrix keeps 16 significant bits
+            acc[t] = AXW_MFMA_16x16x32(f.wl[t], f.h, acc[t]);
+            acc[t] = AXW_MFMA_16x16x32(f.wl[t], f.l, acc[t]);
+          }
+        }
       }
     };
     // eight k-steps in flight per wave (96 VGPRs at RT = 1): K = 5120 is 20 k-steps per wave, i.e. 3 dependent round
     // trips instead of 5 with four. (Twelve — all of mlp.2's K = 3072 in one round trip — measured the same at 4 clips, 6.04 us per
     // launch: bytes through the CU, not round trips; and 160 VGPRs leave one workgroup per CU where 114 leave two: 256 clips -2.7 %.)
-    constexpr int DEPTH = 8;
+    constexpr int DEPTH = FOLD ? 4 : 8;  // FOLD: K = d_model <= 1024 is at most 4 k-steps per wave
     Frag f[DEPTH];
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i)
@@ -476,12 +532,25 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
   const int n = o_n, b = o_b;
   switch (p.epilogue) {
     case GEPI_STORE: p.out[(long)b * p.N + n] = y; break;
-    case GEPI_RESID: p.out[(long)b * p.N + n] = old_t + y; break;
+    case GEPI_RESID: {
+      const float xn = old_t + y;
+      if (fw) { p.out2[(long)b * (p.N - fr0) + (n - fr0)] = xn; break; }
+      p.out[(long)b * nx + n] = xn;
+      if (p.stat_part) {  // the 16 rows of this block for one clip sit in one DPP row (RT == 1: launch_decode_cgemm checks)
+        const float s1 = row16_sum_f(xn);
+        const float dm = xn - s1 * (1.f / 16.f);
+        const float q2 = row16_sum_f(dm * dm);
+        if (nn == 0) *reinterpret_cast<f32x2_t*>(p.stat_part + ((long)b * (nx >> 4) + blockIdx.x) * 2) = f32x2_t{s1, q2};
+      }
+      break;
+    }
     case GEPI_GELU: store_pair_frag(gelu_erf(y), p.out_hi, p.out_lo, b, n, p.nbs); break;
     case GEPI_QKV_CACHE: {
       const int d = p.d_model;
       if (n < d) {
         p.out[(long)b * d + n] = y;
+      } else if (n >= 3 * d) {  // query-fold rows: A0
+        p.out2[(long)b * d + (n - 3 * d)] = y;
       } else {
         const int cc = (n < 2 * d) ? n - d : n - 2 * d;
         const int head = cc >> 6, dd = cc & 63;
@@ -499,13 +568,16 @@ template <int RT>
 static void launch_cg(const DecCGemmParams& p, hipStream_t s) {
   const dim3 grid((p.N + 16 * RT - 1) / (16 * RT), (p.batch + 15) / 16);
   const int ch = p.ln_w ? (p.K / 32 + 7) / 8 : 0;
+  const bool fold_pair = ch == 0 && p.fold_row0 > 0;  // the o launch with its M rows
   bool ch_has_stamp = true;
   if (p.stamp) {  // measurement builds: the shapes of d_model 768
-    if (ch == 0) hipLaunchKernelGGL((decode_cgemm_kernel<RT, 0, true>), grid, dim3(512), 0, s, p);
+    if (fold_pair) hipLaunchKernelGGL((decode_cgemm_kernel<RT, 0, true, true>), grid, dim3(512), 0, s, p);
+    else if (ch == 0) hipLaunchKernelGGL((decode_cgemm_kernel<RT, 0, true>), grid, dim3(512), 0, s, p);
     else if (ch == 3) hipLaunchKernelGGL((decode_cgemm_kernel<RT, 3, true>), grid, dim3(512), 0, s, p);
     else ch_has_stamp = false;  // no measurement build for this K: the production kernel runs, unstamped (a measurement switch never ends the process)
     if (ch_has_stamp) return;
   }
+  if (fold_pair) { hipLaunchKernelGGL((decode_cgemm_kernel<RT, 0, false, true>), grid, dim3(512), 0, s, p); return; }
   switch (ch) {
     case 0: hipLaunchKernelGGL((decode_cgemm_kernel<RT, 0>), grid, dim3(512), 0, s, p); break;
     case 1: case 2: hipLaunchKernelGGL((decode_cgemm_kernel<RT, 2>), grid, dim3(512), 0, s, p); break;
@@ -517,6 +589,10 @@ static void launch_cg(const DecCGemmParams& p, hipStream_t s) {
 }
 void launch_decode_cgemm(const DecCGemmParams& p, hipStream_t s) {
   if (p.K % 128 != 0) { fprintf(stderr, "[ax_whisper] launch_decode_cgemm: unsupported K=%d\n", p.K); abort(); }
+  if (p.fold_row0 > 0 && (p.fold_row0 % (16 * (p.rt == 2 ? 2 : 1)) != 0 || !p.out2 || (p.ln_w ? !p.ln_w2 : (!p.W_lo || p.K > 1024)) || (p.stat_part && p.rt == 2))) {
+    fprintf(stderr, "[ax_whisper] launch_decode_cgemm: bad query-fold launch (fold_row0=%d, rt=%d)\n", p.fold_row0, p.rt);
+    abort();
+  }
   if (p.rt == 2) launch_cg<2>(p, s);
   else launch_cg<1>(p, s);
 }

@@ -71,8 +71,12 @@ __device__ __forceinline__ uint4 ld_kv(const h16* base, long off) {
 // NCHL > 0 (FUSE_Q at d_model 384 / 512 / 768 / 1024): d_model = 32 * NCHL, the lane's
 // NCHL weight chunks of the query projection are ALL requested up front, unconditionally — one memory round trip and straight-line
 // code instead of one round trip per 8 chunks behind per-chunk bounds checks (which hipcc turns into a branch per load).
-template <bool FUSE_Q, bool STAMP = false, int NCHL = 0>
+// QM (query mode): 0 = q is read from p.q; 1 = FUSE_Q above; 2 = FOLDED (decode_gemm.hip "QUERY FOLD"): the head's 64 query values are
+// r (T - mu s) + c from the clip's T row (written by the o launch), the 48 block statistics of its residual row and two constant
+// vectors — one round trip of small loads behind the first K/V requests, one barrier, no weights.
+template <int QM, bool STAMP = false, int NCHL = 0>
 __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, int cap_blocks, int stamp_point) {
+  constexpr bool FUSE_Q = QM == 1;
   __shared__ float s_part[4][kPartStride];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the block loop below is wave-uniform control flow
@@ -223,6 +227,29 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 64; ++c) qv[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_q[c])));
+  } else if constexpr (QM == 2) {
+    __shared__ float s_q[64];
+    const int d = p.d_model, nst = d >> 4;  // nst <= 64 (d_model <= 1024)
+    float tq = 0.f, sj = 0.f, cj = 0.f;
+    f32x2_t sp = {0.f, 0.f};
+    if (wave == 0) {  // the first wave builds the query: T, s, c of its lane's dimension and one block statistic each
+      tq = p.tq[(long)b * d + head * 64 + lane];
+      sj = p.fold_s[head * 64 + lane];
+      cj = p.fold_c[head * 64 + lane];
+      if (lane < nst) sp = *reinterpret_cast<const f32x2_t*>(p.stat_part + ((long)b * nst + lane) * 2);
+    }
+    if (clip_done) { stamp_end(); return; }  // (workgroup-uniform, in front of the barrier)
+    if (wave == 0) {
+      // Chan et al.: the row's mean from the block sums, its centred squares from the blocks' own + 16 (block mean - mean)^2
+      const float mean = wave_sum(sp[0]) / (float)d;
+      const float dm = sp[0] * (1.f / 16.f) - mean;
+      const float m2 = wave_sum(lane < nst ? sp[1] + 16.f * dm * dm : 0.f);
+      const float rstd = rsqrtf(m2 / (float)d + 1e-5f);
+      s_q[lane] = rstd * (tq - mean * sj) + cj;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 64; ++c) qv[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_q[c])));
   } else {
 #pragma unroll
     for (int c = 0; c < 64; ++c) qv[c] = qp[c];
@@ -230,7 +257,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
 
   stamp_at(3);
   const int n_keys = p.n_keys >= 0 ? p.n_keys : p.off[b] + 1;  // self-attention: this clip's own position
-  if (!FUSE_Q && clip_done) { stamp_end(); return; }  // (behind the query and position requests: one round trip for all three)
+  if (QM == 0 && clip_done) { stamp_end(); return; }  // (behind the query and position requests: one round trip for all three)
   const int blk_end = min((n_keys + 63) >> 6, blk_cap_end);
 
   float m_w = -INFINITY, l_lane = 0.f;
@@ -394,7 +421,13 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
 
 void launch_decode_attention(const DecAttnParams& p, hipStream_t s) {
   static const int stamp_point = [] { const char* e = getenv("AX_WHISPER_ATTN_STAMP_POINT"); return e ? atoi(e) : 0; }();
-  if (p.wq) {
+  if (p.tq) {  // folded query
+    if (p.d_model > 1024 || p.d_model % 64 != 0 || !p.stat_part || !p.fold_s || !p.fold_c || p.n_split > kAttnSplitMax ||
+        (p.n_split != 1 && !(p.out_hi && p.mpart && p.mcnt))) { fprintf(stderr, "[ax_whisper] folded query: d_model %d, n_split %d unsupported\n", p.d_model, p.n_split); abort(); }
+    const dim3 grid(p.n_split, p.n_head, p.batch);
+    if (p.stamp) hipLaunchKernelGGL((decode_attention_kernel<2, true>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+    else hipLaunchKernelGGL((decode_attention_kernel<2>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+  } else if (p.wq) {
     if (p.d_model > 1024 || p.d_model % 32 != 0 || p.n_split > kAttnSplitMax || (p.n_split != 1 && !(p.out_hi && p.mpart && p.mcnt))) { fprintf(stderr, "[ax_whisper] fused query projection: d_model %d, n_split %d unsupported\n", p.d_model, p.n_split); abort(); }
     static const bool qall = [] { const char* e = getenv("AX_WHISPER_ATTN_QALL"); return !(e && e[0] == '0'); }();  // A/B
     const dim3 grid(p.n_split, p.n_head, p.batch);
@@ -402,16 +435,16 @@ void launch_decode_attention(const DecAttnParams& p, hipStream_t s) {
     // the launch is shorter at few clips (4 clips 11.3 -> 10.5 us) and at batch (64 clips: decode 510.8 -> 500.1 ms per call, 16: -1.5 %)
     const bool few = qall;
     if (p.stamp) {
-      if (few && p.d_model == 768) hipLaunchKernelGGL((decode_attention_kernel<true, true, 24>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
-      else hipLaunchKernelGGL((decode_attention_kernel<true, true>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
-    } else if (few && p.d_model == 384) hipLaunchKernelGGL((decode_attention_kernel<true, false, 12>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
-    else if (few && p.d_model == 512) hipLaunchKernelGGL((decode_attention_kernel<true, false, 16>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
-    else if (few && p.d_model == 768) hipLaunchKernelGGL((decode_attention_kernel<true, false, 24>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
-    else if (few && p.d_model == 1024) hipLaunchKernelGGL((decode_attention_kernel<true, false, 32>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
-    else hipLaunchKernelGGL((decode_attention_kernel<true>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+      if (few && p.d_model == 768) hipLaunchKernelGGL((decode_attention_kernel<1, true, 24>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+      else hipLaunchKernelGGL((decode_attention_kernel<1, true>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+    } else if (few && p.d_model == 384) hipLaunchKernelGGL((decode_attention_kernel<1, false, 12>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+    else if (few && p.d_model == 512) hipLaunchKernelGGL((decode_attention_kernel<1, false, 16>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+    else if (few && p.d_model == 768) hipLaunchKernelGGL((decode_attention_kernel<1, false, 24>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+    else if (few && p.d_model == 1024) hipLaunchKernelGGL((decode_attention_kernel<1, false, 32>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+    else hipLaunchKernelGGL((decode_attention_kernel<1>), grid, dim3(256), 0, s, p, p.cap_blocks, stamp_point);
   } else {
-    if (p.stamp) hipLaunchKernelGGL((decode_attention_kernel<false, true>), dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks, stamp_point);
-    else hipLaunchKernelGGL((decode_attention_kernel<false>), dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+    if (p.stamp) hipLaunchKernelGGL((decode_attention_kernel<0, true>), dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks, stamp_point);
+    else hipLaunchKernelGGL((decode_attention_kernel<0>), dim3(p.n_split, p.n_head, p.batch), dim3(256), 0, s, p, p.cap_blocks, stamp_point);
   }
 }
 

@@ -136,6 +136,7 @@ void Engine::construct(const std::string& model_type, const std::string& model_p
     // with eight k-steps in flight per wave) and equal at 64, which keeps the split-K sequence
     batched_ln_ = !(e && e[0] == '0') && d % 128 == 0 && (d <= 1024 || (e && e[0] == '2' && d <= 1280));  // '2': force (A/B runs)
     cfg_.ints["batched_ln"] = batched_ln_ ? 1 : 0;
+    build_cblock_fold();  // (needs the fold arena above and batched_ln_)
   }
   {
     enc_split_k_ = true;
@@ -476,9 +477,18 @@ void Engine::load_weights(const SafeTensors& st) {
   };
   dec_packed_.resize(L);
   for (int i = 0; i < L; ++i) {
-    dec_packed_[i].w_qkv = pack(dec_[i].w_qkv, 3 * d, d);
-    dec_packed_[i].w_o = pack(dec_[i].w_o, d, d);
-    dec_packed_[i].w_cq = pack(dec_[i].w_cq, d, d);
+    // fragment-major row blocks are contiguous, so packed [W_qkv; W_cq] is packed W_qkv followed by packed W_cq, and the query
+    // fold's M_hi rows follow packed W_o (build_cblock_fold fills them; d % 16 == 0 for every Whisper size)
+    h16* qc = new_h16((size_t)4 * d * d);
+    launch_pack_weight_frag(dec_[i].w_qkv, qc, 3 * d, d, s);
+    launch_pack_weight_frag(dec_[i].w_cq, qc + (size_t)3 * d * d, d, d, s);
+    dec_packed_[i].w_qkv = qc;
+    dec_packed_[i].w_cq = qc + (size_t)3 * d * d;
+    h16* om = new_h16((size_t)2 * d * d);
+    launch_pack_weight_frag(dec_[i].w_o, om, d, d, s);
+    dec_packed_[i].w_o = om;
+    dec_packed_[i].m_hi = om + (size_t)d * d;
+    dec_packed_[i].m_lo = nullptr;
     dec_packed_[i].w_co = pack(dec_[i].w_co, d, d);
     dec_packed_[i].w_fc1 = pack(dec_[i].w_fc1, 4 * d, d);
     dec_packed_[i].w_fc2 = pack(dec_[i].w_fc2, d, 4 * d);
@@ -549,6 +559,8 @@ void Engine::ensure_capacity(int batch) {
   d_self_k_ = (h16*)A((size_t)L * B * H * Tc * 64 * 2, true);
   d_self_v_ = (h16*)A((size_t)L * B * H * Tc * 64 * 2, true);
   d_xdec_ = (float*)A((size_t)B * d * 4, true);
+  d_a0_ = (float*)A((size_t)B * d * 4, true);
+  d_statp_ = (float*)A((size_t)B * (d / 16 + 1) * 2 * 4, true);
   d_qdec_ = (float*)A((size_t)B * d * 4, true);
   d_hid_ = (float*)A((size_t)B * 4 * d * 4, true);
   nbs_ = (B + 15) / 16;
@@ -659,6 +671,39 @@ void Engine::run_frontend(const float* d_pcm, int stride, const int* n_samples, 
   p.mel_tm = d_mel_tm_; p.mel_rows = mel_rows_; p.max_frames = max_frames; p.openai = feature_openai_ ? 1 : 0;
   if (staged && over_used_) { p.overflow = d_over_; p.over_off = d_over_off_; }
   launch_frontend(p, stream());
+}
+
+// The clip-block step's query fold (decode_gemm.hip "QUERY FOLD"): M of the fold arena as an (hi, lo) h16 pair in fragment order
+// behind packed W_o, and the per-layer vectors. Needs the fold arena (d_model <= 768) and the clip-block sequence;
+// AX_WHISPER_CBLOCK_QFOLD=0 keeps the fused query projection (A/B, tests).
+void Engine::build_cblock_fold() {
+  const char* e = getenv("AX_WHISPER_CBLOCK_QFOLD");
+  const int d = cfg_.n_text_state, L = cfg_.n_text_layer;
+  cfg_.ints["cblock_qfold"] = 0;
+  if (!d_qfold_ || !batched_ln_ || d % 64 != 0 || (e && e[0] == '0')) return;
+  hipStream_t s = own_stream_;
+  cfold_.resize(L);
+  for (int l = 0; l < L; ++l) {
+    const float* qf = d_qfold_ + (size_t)l * qfold_floats(d, 1);  // per-layer block: M [d][d], then d, s, c [d] each (decode_persistent_common.hpp)
+    const float* vecs = qf + (size_t)d * d;  // d, s, c
+    DecLayerWP& wp = dec_packed_[l];
+    wp.m_lo = (h16*)dalloc((size_t)d * d * 2, true);
+    allocs_.push_back(wp.m_lo);
+    launch_pack_weight_frag_split(qf, wp.m_hi, wp.m_lo, d, d, s);
+    CblockFold& c = cfold_[l];
+    c.b_qkv4 = (float*)dalloc((size_t)4 * d * 4, true);  // [b_qkv; 0]: the A0 rows have no bias
+    c.b_o2 = (float*)dalloc((size_t)2 * d * 4, true);    // [b_o; d]
+    allocs_.push_back(c.b_qkv4);
+    allocs_.push_back(c.b_o2);
+    HIP_CHECK(hipMemcpyAsync(c.b_qkv4, dec_[l].b_qkv, (size_t)3 * d * 4, hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(c.b_o2, dec_[l].b_o, (size_t)d * 4, hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(c.b_o2 + d, vecs, (size_t)d * 4, hipMemcpyDeviceToDevice, s));
+    c.s = vecs + d;
+    c.c = vecs + 2 * d;
+  }
+  HIP_CHECK(hipStreamSynchronize(s));
+  cfold_all_ = e && e[0] == '2';
+  cfg_.ints["cblock_qfold"] = cfold_all_ ? 2 : 1;
 }
 
 // ------------------------------------------------------------------------------ encoder

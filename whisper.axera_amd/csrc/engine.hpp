@@ -111,7 +111,14 @@ class Engine final : public IEngine {
   std::vector<EncLayer> enc_;
   std::vector<DecLayerW> dec_;       // per-layer views into the two arenas below
   h16* dec_w_arena_ = nullptr; float* dec_f_arena_ = nullptr;
-  struct DecLayerWP { const h16 *w_qkv, *w_o, *w_cq, *w_co, *w_fc1, *w_fc2; };
+  // w_qkv and w_cq are ONE buffer of 4 d rows ([W_qkv; W_cq]); w_o heads a buffer of 2 d rows whose second half takes the query
+  // fold's M_hi, m_lo its lo halves (decode_gemm.hip "QUERY FOLD"; filled by build_cblock_fold)
+  struct DecLayerWP { const h16 *w_qkv, *w_o, *w_cq, *w_co, *w_fc1, *w_fc2; h16 *m_hi, *m_lo; };
+  struct CblockFold { float *b_qkv4, *b_o2; const float *s, *c; };  // per layer: [b_qkv; 0], [b_o; d], s = W_cq g, c = W_cq beta + b_cq
+  std::vector<CblockFold> cfold_;      // empty: the clip-block step keeps the fused query projection
+  bool cfold_all_ = false;             // AX_WHISPER_CBLOCK_QFOLD=2: also in multi-branch steps (A/B, tests)
+  float *d_a0_ = nullptr, *d_statp_ = nullptr;  // [B][d] A0 -> T; [B][d/16][2] block statistics of the residual rows
+  void build_cblock_fold();
   std::vector<DecLayerWP> dec_packed_;  // fragment-major copies for the batched decode path
   const h16* tok_emb_packed_ = nullptr;
   int nbs_ = 1;                         // allocated clip blocks of 16

@@ -163,6 +163,14 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced, b
       if (c <= kCrossSplitMax && blocks % c == 0 && nb * H * c <= std::max(n_cu_, 64)) { cross_split = c; break; }
     if (cross_split_env_ > 0 && cross_split_env_ <= kCrossSplitMax && blocks % cross_split_env_ == 0) cross_split = cross_split_env_;
   }
+  // Folded query: a split repeats nothing but a 3 KB gather, so the grid is sized for whole waves of workgroups instead (three
+  // 136-register workgroups per CU are resident): AX_WHISPER_CROSS_SPLIT_FOLD forces a count (sweeps)
+  int cross_split_fold = cross_split;
+  {
+    static const int env = [] { const char* e = getenv("AX_WHISPER_CROSS_SPLIT_FOLD"); return e ? atoi(e) : 0; }();
+    const int blocks = t_pad_ / 64;
+    if (env > 0 && env <= kCrossSplitMax && blocks % env == 0) cross_split_fold = env;
+  }
   static const int gemm_stamp_point = [] { const char* e = getenv("AX_WHISPER_GEMM_STAMP_POINT"); return e ? atoi(e) : 0; }();
   int cur_layer = 0;
   // kind: 2 qkv, 3 o, 4 co, 5 fc1, 6 fc2 (0 / 1 are the attention launches) — bench "attn_stamp" puts every launch of the step on one axis
@@ -193,15 +201,35 @@ void Engine::enqueue_layers_cblock(int b0, int nb, hipStream_t s, bool forced, b
     h16* sv = d_self_v_ + ((size_t)l * cap_ + b0) * self_stride;
     const h16* ck = d_cross_k_ + ((size_t)l * cap_ + b0) * cross_stride;
     const h16* cv = d_cross_v_ + ((size_t)l * cap_ + b0) * cross_stride;
-    DecCGemmParams c = cgemm(wq.w_qkv, w.b_qkv, 3 * d, d, GEPI_QKV_CACHE, rt_for(3 * d));
+    // query fold (decode_gemm.hip "QUERY FOLD"): the QKV launch also computes A0 = W_cq (g_cross . x0), the o launch T = A0 + M a + d
+    // and the block statistics of the new residual rows; the cross-attention workgroups start with their query
+    // Measured (profiles/r06_cblock_qfold_ab.txt, Whisper-small, step at t = 224): 4 clips 0.4915 -> 0.4784 ms, 8: 0.5317 -> 0.5119,
+    // 16: 0.6244 -> 0.6115; 64 clips (two branches): 1.091 -> 1.135 — the attention launches gain 1 % there (the W_cq rows come from L2
+    // beside 147 MB of K/V per launch) and the two fatter GEMM launches cost 7 % of the chain. So: one-branch steps only.
+    const bool qfold = !cfold_.empty() && fuse_cq && d <= 1024 && (one_branch || cfold_all_);
+    float* a0 = d_a0_ + (long)b0 * d;
+    float* statp = d_statp_ + (long)b0 * (d / 16) * 2;
+    DecCGemmParams c = qfold ? cgemm(wq.w_qkv, cfold_[l].b_qkv4, 4 * d, d, GEPI_QKV_CACHE, rt_for(4 * d))
+                             : cgemm(wq.w_qkv, w.b_qkv, 3 * d, d, GEPI_QKV_CACHE, rt_for(3 * d));
     c.x = x; c.ln_w = w.attn_ln_w; c.ln_b = w.attn_ln_b;
     c.out = qd; c.k_cache = sk; c.v_cache = sv; c.kv_batch_stride = self_stride;
+    if (qfold) { c.fold_row0 = 3 * d; c.ln_w2 = w.cross_ln_w; c.out2 = a0; }
     cgo(c, 2);
     if (step_mask_ & 2) { DecAttnParams a = attn(sk, sv, self_stride, -1, Tc / 64); a.stamp = next_stamp(l, 0, b0, nb); launch_decode_attention(a, s); }
-    c = cgemm(wq.w_o, w.b_o, d, d, GEPI_RESID, 1);
+    c = qfold ? cgemm(wq.w_o, cfold_[l].b_o2, 2 * d, d, GEPI_RESID, 1) : cgemm(wq.w_o, w.b_o, d, d, GEPI_RESID, 1);
     c.a_hi = att_hi; c.a_lo = att_lo; c.out = x;
+    if (qfold) { c.fold_row0 = d; c.W_lo = wq.m_lo; c.out2 = a0; c.stat_part = statp; }
     cgo(c, 3);
-    if (fuse_cq && d <= 1024) {  // the cross-attention workgroups project their own queries (decode_attention_kernel<true>)
+    if (qfold) {
+      DecAttnParams a = attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64);
+      a.q = nullptr;
+      a.n_split = cross_split_fold;
+      a.mpart = d_attn_mpart_ + (long)b0 * H * kCrossSplitMax * 66;
+      a.mcnt = d_attn_mcnt_ + (long)b0 * H;
+      a.tq = a0; a.stat_part = statp; a.fold_s = cfold_[l].s; a.fold_c = cfold_[l].c;
+      a.stamp = next_stamp(l, 1, b0, nb);
+      if (step_mask_ & 2) launch_decode_attention(a, s);
+    } else if (fuse_cq && d <= 1024) {  // the cross-attention workgroups project their own queries (decode_attention_kernel<1>)
       DecAttnParams a = attn(ck, cv, cross_stride, cfg_.n_audio_ctx, t_pad_ / 64);
       a.q = nullptr;
       a.n_split = cross_split;
