@@ -33,7 +33,7 @@ for p in (ROOT, os.path.join(ROOT, "whisper.axera_amd", "tools")):
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16/fp16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
 N_SAMP = 480000  # 30 s at 16 kHz
-PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r06_pmc_traffic.json")
 ROCPROF_ATTN_FILE = os.path.join("profiles", "r06_b64_attn_per_launch.json")  # {"frac": .., "avg_launch_us": .., "bytes_per_launch": ..}
 
 
