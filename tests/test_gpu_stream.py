@@ -111,11 +111,6 @@ def test_stream_beyond_64_slots(built_lib, micro_case):
             assert_ids_equal_or_tie(e, mel, got[i], ids, lg, f"clip {i} through 72 slots")
         # the 150 clips are 8 distinct ones: a clip that sits on a tie differs in every instance whose budget reaches that step
         assert len({i % 8 for i in diff}) <= 2, sorted({i % 8 for i in diff})
-        # The slot stream's rate depends on which hardware queue the step graph's second branch landed on (335 against
-        # 367 clips/s at 64 slots): a fresh multi-branch graph is probed and re-instantiated until that branch shares the idle
-        # capture stream's queue. The placement rests on an undocumented dealing rule of the runtime, so the outcome is asserted:
-        # a ROCm update that breaks it fails here instead of silently costing 9 %.
-        assert e.L.AX_WHISPER_GetConfigInt(e.h, b"graph_queue_aligned") == 1, e.L.AX_WHISPER_GetConfigInt(e.h, b"graph_queue_tries")
     finally:
         e.close()
 
