@@ -397,42 +397,35 @@ __global__ __launch_bounds__(512) void decode_cgemm_kernel(DecCGemmParams p) {
       lnb_t[i] = (kk < p.K && !fw) ? p.ln_b[kk] : 0.f;
     }
     stamp_at(1);
-    // two-pass statistics per clip: lanes (r, 0..3) of 8 waves hold one row between them
-    float s1 = 0.f;
+    // statistics per clip: lanes (r, 0..3) of 8 waves hold one row between them. ONE pass and one barrier (round 6): sum and sum of
+    // squares together, var = E[x^2] - mean^2 in fp32 (a residual row's mean is small against its spread — outlier channels of +-500 among
+    // 768 values give E[x^2] / var < 4 — so the subtraction costs two bits, not the result; the two-pass form behind two barriers held
+    // every wave 0.3 us longer in front of its MFMAs, 24 launches per step and branch)
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c)
       if (wave + 8 * c < KS) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) s1 += (v[c][u][0] + v[c][u][1]) + (v[c][u][2] + v[c][u][3]);
+        for (int u = 0; u < 2; ++u) {
+          s1 += (v[c][u][0] + v[c][u][1]) + (v[c][u][2] + v[c][u][3]);
+          s2 += (v[c][u][0] * v[c][u][0] + v[c][u][1] * v[c][u][1]) + (v[c][u][2] * v[c][u][2] + v[c][u][3] * v[c][u][3]);
+        }
       }
     s1 = sum_lanes_16_32(s1);
-    if (q == 0) stat[0][wave][r] = s1;
+    s2 = sum_lanes_16_32(s2);
+    if (q == 0) { stat[0][wave][r] = s1; stat[1][wave][r] = s2; }
 #pragma unroll
     for (int i = 0; i < (CH * 256 + 511) / 512; ++i) {
       const int kk = tid + 512 * i;
       if (kk < CH * 256) { s_ln[0][kk] = lnw_t[i]; s_ln[1][kk] = lnb_t[i]; }
     }
     __syncthreads();
-    float mean = 0.f;
+    float mean = 0.f, ex2 = 0.f;
 #pragma unroll
-    for (int w2 = 0; w2 < 8; ++w2) mean += stat[0][w2][r];
+    for (int w2 = 0; w2 < 8; ++w2) { mean += stat[0][w2][r]; ex2 += stat[1][w2][r]; }
     mean = fw ? 0.f : mean / (float)p.K;
-    float s2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-      if (wave + 8 * c < KS) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { const float t2 = v[c][u][e] - mean; s2 += t2 * t2; }
-      }
-    s2 = sum_lanes_16_32(s2);
-    if (q == 0) stat[1][wave][r] = s2;
-    __syncthreads();
-    float var = 0.f;
-#pragma unroll
-    for (int w2 = 0; w2 < 8; ++w2) var += stat[1][w2][r];
-    const float rstd = fw ? 1.f : rsqrtf(var / (float)p.K + 1e-5f);
+    const float var = fmaxf(ex2 / (float)p.K - mean * mean, 0.f);
+    const float rstd = fw ? 1.f : rsqrtf(var + 1e-5f);
     stamp_at(2);
 #pragma unroll
     for (int c = 0; c < CH; ++c)
