@@ -164,18 +164,15 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecAttnParams p, 
     }
     const float bq = p.bq[head * 64 + qrow];
     if (clip_done) { stamp_end(); return; }  // (workgroup-uniform, in front of the first barrier)
+    // statistics in one pass behind one barrier (round 6, as in the clip-block GEMM prologue: decode_gemm.hip): var = E[x^2] - mean^2
     float s1 = (xv[0] + xv[1]) + (xv[2] + xv[3]);
+    float s2 = (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);  // (elements beyond d were loaded as 0)
     s1 = wave_sum(s1);
-    if (lane == 0) s_red[wave] = s1;
+    s2 = wave_sum(s2);
+    if (lane == 0) { s_red[wave] = s1; s_red[4 + wave] = s2; }
     __syncthreads();
     const float mean = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / d;
-    float s2 = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { const float t = tid + 256 * e < d ? xv[e] - mean : 0.f; s2 += t * t; }
-    s2 = wave_sum(s2);
-    if (lane == 0) s_red[4 + wave] = s2;
-    __syncthreads();
-    const float rstd = rsqrtf(((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])) / d + 1e-5f);
+    const float rstd = rsqrtf(fmaxf(((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])) / d - mean * mean, 0.f) + 1e-5f);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const int c = tid + 256 * e; if (c < d) s_act[c] = (xv[e] - mean) * rstd * gg[e] + bb[e]; }
     __syncthreads();
